@@ -1,0 +1,171 @@
+/*
+ * vggsfm_amd -- C-ABI of the MI355X (gfx950) geometry hot path of VGGSfM.
+ *
+ * This is the drop-in boundary: plain pointers + sizes, no torch / pycolmap types.  Every pointer
+ * named *device* is HBM memory of the current HIP device; `stream` is a hipStream_t passed as void*.
+ * All entry points are asynchronous on `stream` unless stated, never allocate, and return VGG_OK (0)
+ * or a negative VGG_ERR_* code.  Each one names the reference interface it replaces (paths under
+ * /root/reference); the Python host side in vggsfm_amd/ mirrors the reference signatures on top.
+ *
+ * Layout conventions (the reference's own): extrinsics (S,3,4) row-major
+ * [R|t] with x_cam = R X + t (OpenCV frame); intrinsics (S,3,3) row-major; tracks (S,P,2) pixels
+ * (float32 as produced by the tracker, or float64); masks uint8 0/1; all geometry float64.
+ */
+#ifndef VGGSFM_AMD_H
+#define VGGSFM_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VGG_OK 0
+#define VGG_ERR_INVALID_ARGUMENT (-1)
+#define VGG_ERR_HIP (-2)
+#define VGG_ERR_WORKSPACE (-3)
+#define VGG_ERR_UNSUPPORTED (-4)
+
+/* library / build identification ("gfx950"), for loud failure when the wrong object is loaded */
+const char* vgg_build_arch(void);
+int vgg_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * project_3D_points + img_from_cam       vggsfm/utils/triangulation_helpers.py:311-395
+ * out_uv (S,P,2) and/or out_cam (S,3,P) may be NULL; intrinsics NULL == only_points_cam.
+ * num_extra in {0,1,2,4} (SIMPLE_RADIAL / RADIAL / OPENCV distortion, distortion.py:102-159). */
+int vgg_project_points(const double* points3D, int P, const double* extrinsics, const double* intrinsics,
+                       const double* extra_params, int num_extra, int S, double* out_uv, double* out_cam,
+                       void* stream);
+
+/* filter_all_points3D(_single_chunk)      vggsfm/utils/triangulation_helpers.py:133-307
+ * reprojection error^2 <= max^2 with depth > 0 (else `behind_value`: 1e6 there, 1e9 in refine_pose,
+ * triangulation.py:308-312), >= 2 inlier views, |X| <= hard_max (<=0 disables), optional "some inlier
+ * pair subtends >= min_tri_angle degrees".  out_mask (P); out_detail (S,P) or NULL.
+ * workspace: vgg_filter_points_workspace_bytes(S) device bytes (only read when check_triangle). */
+size_t vgg_filter_points_workspace_bytes(int S);
+int vgg_filter_points(const double* points3D, int P, const void* tracks, int tracks_are_f64, const double* extrinsics,
+                      const double* intrinsics, const double* extra_params, int num_extra, int S,
+                      double max_reproj_error, double min_tri_angle, int check_triangle, double hard_max,
+                      double behind_value, uint8_t* out_mask, uint8_t* out_detail, void* workspace, void* stream);
+
+/* cam_from_img + iterative_undistortion   vggsfm/utils/triangulation_helpers.py:398-428,
+ *                                         vggsfm/utils/distortion.py:27-99
+ * out (S,P,2) f64.  With num_extra > 0 runs the reference's Newton iteration incl. its tensor-global
+ * stopping rule; this SYNCHRONISES the stream every 8 iterations; *iterations_run (host) may be NULL. */
+size_t vgg_cam_from_img_workspace_bytes(int S, int P, int max_iterations);
+int vgg_cam_from_img(const void* tracks, int tracks_are_f64, const double* intrinsics, const double* extra_params,
+                     int num_extra, int S, int P, double* out, int max_iterations, double max_step_norm,
+                     double rel_step_size, double eps, void* workspace, int* iterations_run, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * triangulate_tracks_single_chunk         vggsfm/utils/triangulation.py:776-956
+ * LO-RANSAC multi-view DLT for N tracks of one chunk.  `pairs` (H,2) int32 device: the hypothesis
+ * view pairs (the caller reproduces the reference's host-side torch.randperm draw, :804-813).
+ * invalid_vis_conf (S,N) uint8 = (vis <= 0.05) | (score <= 0.5)  (:867-874).
+ * Pass 1 writes per-hypothesis (inlier_num, mean inlier error) into workspace and the chunk-global
+ * max of the mean errors; vgg_triangulate_select then applies calculate_residual_indicator
+ * (vggsfm/two_view_geo/utils.py:63-87) with that chunk-global threshold and gathers the winner.
+ * Outputs: points (N,3) f64, inlier_num (N) int64, inlier_mask (N,S) uint8. */
+size_t vgg_triangulate_workspace_bytes(int S, int N, int H, int lo_num);
+int vgg_triangulate_tracks(const double* extrinsics, const double* tracks_normalized, const uint8_t* invalid_vis_conf,
+                           const int32_t* pairs, int S, int N, int H, int lo_num, double max_angular_error_deg,
+                           double min_tri_angle_deg, double* out_points, int64_t* out_inlier_num,
+                           uint8_t* out_inlier_mask, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Bundle adjustment / pose refinement = what the reference obtains from
+ *   pycolmap.bundle_adjustment   vggsfm/utils/triangulation.py:213,1050,1142; runners/video_runner.py:508
+ *   pycolmap.pose_refinement     vggsfm/utils/triangulation.py:387,590; runners/video_runner.py:1001
+ * (COLMAP BundleAdjuster on Ceres' Levenberg-Marquardt, Schur elimination of the points).
+ *
+ * State and structure live on the device in flat arrays; nothing is marshalled through host objects.
+ * Observations are given twice: point-major CSR (row_ptr/obs_*) and camera-major CSR (col_ptr/cobs_*),
+ * both sorted ascending in the minor index.  `tile_*` is the block-sparse Schur work list built by the
+ * host side (vggsfm_amd/ba.py: build_schur_tiles): cameras are grouped 16 at a time, a "segment" is the
+ * run of one point's observations inside one camera group, an "entry" pairs two segments of one point. */
+typedef struct {
+  int32_t num_cams, num_pts, num_obs, num_intr;   /* num_intr == 1 (shared camera) or == num_cams */
+  int32_t camera_model;                           /* 0 SIMPLE_PINHOLE  1 SIMPLE_RADIAL */
+  int32_t refine_focal, refine_extra;             /* principal point is always constant */
+  int32_t loss;                                   /* 0 trivial 1 Cauchy 2 Huber 3 SoftL1 */
+  double loss_scale;
+  /* state, in/out (device) */
+  double* cam_q;              /* [num_cams,4] unit quaternion x,y,z,w */
+  double* cam_t;              /* [num_cams,3] */
+  double* intr;               /* [num_intr,4] f,cx,cy,k */
+  double* pts;                /* [num_pts,3] */
+  /* structure (device) */
+  const int32_t* row_ptr;     /* [num_pts+1] */
+  const int32_t* obs_cam;     /* [num_obs] */
+  const float* obs_uv;        /* [num_obs,2] */
+  const int32_t* col_ptr;     /* [num_cams+1] */
+  const int32_t* cobs_pt;     /* [num_obs] */
+  const float* cobs_uv;       /* [num_obs,2] */
+  const uint8_t* cam_const;   /* [num_cams] bit0: pose constant; bit1..3: t_x,t_y,t_z constant; or NULL */
+  const uint8_t* intr_const;  /* [num_intr] or NULL */
+  const uint8_t* pt_const;    /* [num_pts] or NULL */
+  /* Schur tile work list (device) */
+  int32_t num_chunks;
+  const int32_t* chunk_desc;  /* [num_chunks,4] = groupI, groupJ, entry_begin, entry_end */
+  const int32_t* entries;     /* [num_entries,4] = point, obs_begin_A, obs_begin_B, cntA | cntB<<8 */
+} vgg_ba_problem;
+
+typedef struct {
+  int32_t max_num_iterations;
+  int32_t max_num_consecutive_invalid_steps;
+  int32_t jacobi_scaling;
+  double function_tolerance, gradient_tolerance, parameter_tolerance;
+  double initial_trust_region_radius, max_trust_region_radius, min_trust_region_radius;
+  double min_lm_diagonal, max_lm_diagonal, min_relative_decrease;
+} vgg_ba_options;
+
+typedef struct {
+  int32_t iteration;
+  int32_t successful;
+  double cost, cost_change, gradient_max_norm, step_norm, relative_decrease, radius;
+} vgg_ba_iteration;
+
+typedef struct {
+  double initial_cost, final_cost;
+  int32_t num_iterations, num_successful_steps, num_unsuccessful_steps;
+  int32_t termination;        /* 0 iteration cap, 1 gradient, 2 function, 3 parameter, 4 radius, 5 failure */
+  int32_t n_reduced, num_log;
+} vgg_ba_summary;
+
+/* device bytes vgg_ba_solve needs in `workspace` (256-byte aligned base) */
+size_t vgg_ba_workspace_bytes(const vgg_ba_problem* problem, const vgg_ba_options* options);
+
+/* Runs the whole LM loop on `stream` (device-side control flow: the host enqueues
+ * max_num_iterations iterations, a device flag turns the rest into no-ops after termination),
+ * then synchronises ONCE to copy summary + per-iteration log (log_cap entries, may be NULL). */
+int vgg_ba_solve(const vgg_ba_problem* problem, const vgg_ba_options* options, void* workspace,
+                 size_t workspace_bytes, vgg_ba_summary* summary, vgg_ba_iteration* log, int log_cap, void* stream);
+
+/* Multi-GPU (points sharded across ranks, cameras replicated): the same loop split into phases so
+ * that the host can interleave RCCL all-reduces on the same stream.
+ *   vgg_ba_begin    : init control block
+ *   phase 0 LINEARIZE: camera-side J^T J / J^T r / cost of the local points  -> reduce buffer 0 (SUM)
+ *   phase 1 SCHUR    : point blocks, reduced camera system of the local points -> reduce buffer 1 (SUM),
+ *                      gradient max of local points                            -> reduce buffer 2 (MAX)
+ *   phase 2 STEP     : Cholesky + back-substitution + candidate cost         -> reduce buffer 3 (SUM)
+ *   phase 3 UPDATE   : trust-region decision, commit
+ * vgg_ba_reduce_buffer returns the device address / element count (doubles) of each reduce buffer. */
+int vgg_ba_begin(const vgg_ba_problem* problem, const vgg_ba_options* options, void* workspace, size_t workspace_bytes,
+                 int rank, int world_size, void* stream);
+int vgg_ba_phase(const vgg_ba_problem* problem, const vgg_ba_options* options, void* workspace, int phase,
+                 void* stream);
+int vgg_ba_reduce_buffer(const vgg_ba_problem* problem, const vgg_ba_options* options, void* workspace, int which,
+                         double** device_ptr, size_t* count);
+int vgg_ba_finish(const vgg_ba_problem* problem, const vgg_ba_options* options, void* workspace,
+                  vgg_ba_summary* summary, vgg_ba_iteration* log, int log_cap, void* stream);
+
+/* Dense symmetric positive-definite solve of the reduced camera system (exposed for tests):
+ * A (n,n) row-major lower triangle is overwritten by its Cholesky factor, b by the solution.
+ * *device_fail (int32, device) is set non-zero on a non-positive pivot. */
+int vgg_cholesky_solve(double* A, double* b, int n, int32_t* device_fail, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VGGSFM_AMD_H */

@@ -1,0 +1,101 @@
+"""GPU parity: projection / filter / normalisation kernels (through the C-ABI) vs the golden vectors
+generated from the reference and vs the numpy oracle on larger seeded inputs.
+Bar: masks bit-exact; floating point within 1e-12 relative (same arithmetic, fp64)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import geometry as G
+from vggsfm_amd.scene import make_scene, perturb_for_ba
+from vggsfm_amd.utils import triangulation_helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def D(x):
+    return None if x is None else torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def _load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name), allow_pickle=False))
+
+
+@pytest.mark.parametrize("name", ["pinhole", "radial"])
+def test_project_and_cam_from_img_golden(golden_dir, name):
+    g = _load(golden_dir, f"geom_{name}.npz")
+    extra = g.get("extra_params")
+    p2, pc = H.project_3D_points(D(g["points3D"]), D(g["extrinsics"]), D(g["intrinsics"]), D(extra),
+                                 return_points_cam=True)
+    p2, pc = p2.cpu().numpy(), pc.cpu().numpy()
+    np.testing.assert_allclose(pc, g["proj_cam"], rtol=1e-13, atol=1e-13)
+    big = np.abs(g["proj2D"]) > 1e300
+    assert np.array_equal(np.abs(p2) > 1e300, big)
+    np.testing.assert_allclose(p2[~big], g["proj2D"][~big], rtol=1e-11, atol=1e-9)
+    only = H.project_3D_points(D(g["points3D"]), D(g["extrinsics"]), only_points_cam=True).cpu().numpy()
+    np.testing.assert_allclose(only, g["proj_cam"], rtol=1e-13, atol=1e-13)
+    tn = H.cam_from_img(D(g["tracks"]), D(g["intrinsics"]), D(extra)).cpu().numpy()
+    np.testing.assert_allclose(tn, g["tracks_normalized"], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["pinhole", "radial"])
+@pytest.mark.parametrize("chk", [0, 1])
+@pytest.mark.parametrize("thr", [4, 1])
+def test_filter_golden_bit_exact(golden_dir, name, chk, thr):
+    g = _load(golden_dir, f"geom_{name}.npz")
+    m, d = H.filter_all_points3D(D(g["points3D"]), D(g["tracks"]), D(g["extrinsics"]), D(g["intrinsics"]),
+                                 D(g.get("extra_params")), max_reproj_error=thr, check_triangle=bool(chk),
+                                 return_detail=True)
+    assert np.array_equal(m.cpu().numpy(), g[f"filter_mask_chk{chk}_thr{thr}"])
+    assert np.array_equal(d.cpu().numpy(), g[f"filter_detail_chk{chk}_thr{thr}"])
+
+
+@pytest.mark.parametrize("S,N,cam", [(50, 3000, "SIMPLE_PINHOLE"), (130, 1500, "SIMPLE_RADIAL"), (3, 70, "SIMPLE_PINHOLE")])
+def test_filter_vs_oracle_seeded(S, N, cam):
+    sc = make_scene(S, N, cam, shared_camera=(cam == "SIMPLE_RADIAL"), seed=21)
+    ext, K, extra, pts = perturb_for_ba(sc, seed=21, point=0.01)
+    pts[::37] *= -1.0
+    pts[5] = 1e4
+    for chk in (False, True):
+        for thr in (8, 2):
+            m, d = H.filter_all_points3D(D(pts), D(sc.tracks), D(ext), D(K), D(extra), max_reproj_error=thr,
+                                         check_triangle=chk, return_detail=True)
+            mo, do = G.filter_all_points3D(pts, sc.tracks.astype(np.float64), ext, K, extra, max_reproj_error=thr,
+                                           check_triangle=chk, return_detail=True)
+            assert np.array_equal(m.cpu().numpy(), mo)
+            assert np.array_equal(d.cpu().numpy(), do)
+
+
+def test_filter_empty_and_property_at_scale():
+    dev = torch.device("cuda")
+    m, d = H.filter_all_points3D(torch.zeros((0, 3), dtype=torch.float64, device=dev),
+                                 torch.zeros((4, 0, 2), dtype=torch.float32, device=dev),
+                                 torch.zeros((4, 3, 4), dtype=torch.float64, device=dev),
+                                 torch.zeros((4, 3, 3), dtype=torch.float64, device=dev), return_detail=True)
+    assert m.shape == (0,) and d.shape == (4, 0)
+    # full-size property (BASELINE configs[2] shape): exact projections of GT points pass, every
+    # visible non-outlier observation is an inlier at 4 px, and detail implies the mask
+    sc = make_scene(200, 100000, "SIMPLE_RADIAL", shared_camera=True, seed=0)
+    tr = D(sc.tracks) * D(sc.mask[..., None].astype(np.float32))
+    m, d = H.filter_all_points3D(D(sc.points3D), tr, D(sc.extrinsics), D(sc.intrinsics), D(sc.extra_params),
+                                 max_reproj_error=4, check_triangle=True, return_detail=True)
+    good = D(sc.mask & ~sc.outlier)
+    assert bool(m.all())
+    assert int((good & ~d).sum()) <= 20          # 0.5 px noise: essentially never beyond 4 px
+    assert bool((d.sum(0) >= 2)[m].all())
+
+
+def test_undistortion_roundtrip_property():
+    # cam_from_img(radial) followed by re-distortion reproduces (u,v) to the Newton tolerance
+    sc = make_scene(20, 5000, "SIMPLE_RADIAL", shared_camera=True, seed=5)
+    K, extra = D(sc.intrinsics), D(sc.extra_params)
+    tn = H.cam_from_img(D(sc.tracks), K, extra)
+    u, v = tn[..., 0], tn[..., 1]
+    r2 = u * u + v * v
+    k = extra[:, 0][:, None]
+    ud, vd = u * (1 + k * r2), v * (1 + k * r2)
+    ref = (D(sc.tracks).double() - 512.0) / K[:, 0, 0][:, None, None]
+    assert float((torch.stack([ud, vd], -1) - ref).abs().max()) < 1e-9
+    tn_o = G.cam_from_img(sc.tracks.astype(np.float64), sc.intrinsics, sc.extra_params)
+    np.testing.assert_allclose(tn.cpu().numpy(), tn_o, rtol=1e-12, atol=1e-14)

@@ -1,0 +1,315 @@
+"""Device-resident bundle adjustment: host side of the HIP Levenberg-Marquardt solver.
+
+Replaces the round trip ``batch_matrix_to_pycolmap -> pycolmap.bundle_adjustment ->
+pycolmap_to_batch_matrix`` of the reference (vggsfm/utils/tensor_to_pycolmap.py:16-214 and the call
+sites vggsfm/utils/triangulation.py:197-223,1038-1064,1131-1156): no Python loop over S*P, no host
+copies -- the problem is compiled into flat device arrays with torch ops and handed to
+``vgg_ba_solve`` (include/vggsfm_amd.h).  Semantics restated from the reference + COLMAP 3.10:
+
+* a 3D point per track with >= 2 masked observations, observations of a point with a coordinate
+  >= ``max_points3D_val`` dropped (tensor_to_pycolmap.py:62-146);
+* the controller deletes negative-depth observations first; a track of length <= 2 hit by such a
+  deletion disappears (its row comes back as zeros, handled at triangulation.py:289-295);
+* image 0 pose constant, image 1 x-translation constant; TRIVIAL loss; focal / extra refined,
+  principal point constant; one camera per frame or one shared camera.
+"""
+import ctypes
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .ba_options import LOSS_ID, TERMINATION, BundleAdjustmentOptions
+
+MODEL_ID = {"SIMPLE_PINHOLE": 0, "SIMPLE_RADIAL": 1}
+GROUP = 16          # cameras per Schur tile side (must match kGroup in csrc/ba.hip)
+CHUNK = 256         # tile entries per workgroup
+
+
+# ------------------------------------------------------------------ rotations (Eigen conventions)
+def rotmat_to_quat(R):
+    """(…,3,3) -> unit quaternion (x,y,z,w), Eigen's Quaternion(Matrix3) branch structure."""
+    R = R.to(torch.float64)
+    m00, m11, m22 = R[..., 0, 0], R[..., 1, 1], R[..., 2, 2]
+    tr = m00 + m11 + m22
+    # trace > 0
+    t0 = torch.sqrt(torch.clamp(tr + 1.0, min=1e-300))
+    q_tr = torch.stack([(R[..., 2, 1] - R[..., 1, 2]) * (0.5 / t0), (R[..., 0, 2] - R[..., 2, 0]) * (0.5 / t0),
+                        (R[..., 1, 0] - R[..., 0, 1]) * (0.5 / t0), 0.5 * t0], -1)
+    outs = []
+    for i in range(3):
+        j, k = (i + 1) % 3, (i + 2) % 3
+        t = torch.sqrt(torch.clamp(R[..., i, i] - R[..., j, j] - R[..., k, k] + 1.0, min=1e-300))
+        q = [None] * 4
+        q[i] = 0.5 * t
+        q[3] = (R[..., k, j] - R[..., j, k]) * (0.5 / t)
+        q[j] = (R[..., j, i] + R[..., i, j]) * (0.5 / t)
+        q[k] = (R[..., k, i] + R[..., i, k]) * (0.5 / t)
+        outs.append(torch.stack(q, -1))
+    i1 = m11 > m00
+    best = torch.where(i1, m11, m00)
+    i2 = m22 > best
+    q_neg = torch.where(i2[..., None], outs[2], torch.where(i1[..., None], outs[1], outs[0]))
+    q = torch.where((tr > 0)[..., None], q_tr, q_neg)
+    return q / q.norm(dim=-1, keepdim=True)
+
+
+def quat_to_rotmat(q):
+    x, y, z, w = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    tx, ty, tz = 2 * x, 2 * y, 2 * z
+    twx, twy, twz = tx * w, ty * w, tz * w
+    txx, txy, txz = tx * x, ty * x, tz * x
+    tyy, tyz, tzz = ty * y, tz * y, tz * z
+    R = torch.stack([1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx,
+                     txz - twy, tyz + twx, 1 - (txx + tyy)], -1)
+    return R.reshape(q.shape[:-1] + (3, 3))
+
+
+# ------------------------------------------------------------------ problem on the device
+@dataclass
+class DeviceProblem:
+    """Flat device arrays of one BA problem (layout documented in include/vggsfm_amd.h)."""
+    cam_q: torch.Tensor
+    cam_t: torch.Tensor
+    intr: torch.Tensor
+    pts: torch.Tensor
+    row_ptr: torch.Tensor
+    obs_cam: torch.Tensor
+    obs_uv: torch.Tensor
+    col_ptr: torch.Tensor
+    cobs_pt: torch.Tensor
+    cobs_uv: torch.Tensor
+    chunk_desc: torch.Tensor
+    entries: torch.Tensor
+    camera_model: int
+    cam_const: Optional[torch.Tensor] = None
+    intr_const: Optional[torch.Tensor] = None
+    pt_const: Optional[torch.Tensor] = None
+    refine_focal: bool = True
+    refine_extra: bool = True
+    loss: int = 0
+    loss_scale: float = 1.0
+
+    @property
+    def num_obs(self):
+        return int(self.obs_cam.shape[0])
+
+    def c_struct(self):
+        P = _lib.BAProblem()
+        P.num_cams, P.num_pts, P.num_obs, P.num_intr = (self.cam_t.shape[0], self.pts.shape[0], self.num_obs,
+                                                        self.intr.shape[0])
+        P.camera_model, P.refine_focal, P.refine_extra = self.camera_model, int(self.refine_focal), int(self.refine_extra)
+        P.loss, P.loss_scale = self.loss, self.loss_scale
+        for name in ("cam_q", "cam_t", "intr", "pts", "row_ptr", "obs_cam", "obs_uv", "col_ptr", "cobs_pt", "cobs_uv",
+                     "cam_const", "intr_const", "pt_const", "chunk_desc", "entries"):
+            t = getattr(self, name)
+            setattr(P, name, None if t is None else t.data_ptr())
+        P.num_chunks = self.chunk_desc.shape[0]
+        return P
+
+
+def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK):
+    """Block-sparse Schur work list (device, torch ops; structure is fixed for the whole solve).
+
+    A *segment* is the run of one point's observations that falls into one group of `group`
+    consecutive cameras; an *entry* pairs two segments (gI <= gJ) of the same point; entries are
+    sorted by tile (gI, gJ) and cut into chunks of <= `chunk` entries, one workgroup each.
+    Returns (chunk_desc (n,4) int32 = gI,gJ,begin,end ; entries (E,4) int32 = point,obsA,obsB,cntA|cntB<<8)."""
+    dev = obs_cam.device
+    O = obs_cam.shape[0]
+    P = row_ptr.shape[0] - 1
+    if O == 0:
+        z = torch.zeros((0, 4), dtype=torch.int32, device=dev)
+        return z, z.clone()
+    counts = (row_ptr[1:] - row_ptr[:-1]).long()
+    obs_pt = torch.repeat_interleave(torch.arange(P, device=dev), counts)
+    grp = (obs_cam // group).long()
+    is_start = torch.ones(O, dtype=torch.bool, device=dev)
+    is_start[1:] = (obs_pt[1:] != obs_pt[:-1]) | (grp[1:] != grp[:-1])
+    seg_begin = torch.nonzero(is_start).squeeze(1)
+    nseg = seg_begin.shape[0]
+    seg_cnt = torch.diff(seg_begin, append=torch.tensor([O], device=dev))
+    seg_pt = obs_pt[seg_begin]
+    seg_grp = grp[seg_begin]
+    ngroups = int((obs_cam.max().item() // group) + 1)
+    pseg_ptr = torch.zeros(P + 1, dtype=torch.long, device=dev)
+    pseg_ptr[1:] = torch.cumsum(torch.bincount(seg_pt, minlength=P), 0)
+    idx = torch.arange(nseg, device=dev)
+    npair = pseg_ptr[seg_pt + 1] - idx
+    total = int(npair.sum().item())
+    A = torch.repeat_interleave(idx, npair)
+    pair_start = torch.cumsum(npair, 0) - npair
+    B = A + (torch.arange(total, device=dev) - pair_start[A])
+    key = seg_grp[A] * ngroups + seg_grp[B]
+    order = torch.argsort(key, stable=True)
+    A, B, key = A[order], B[order], key[order]
+    entries = torch.stack([seg_pt[A], seg_begin[A], seg_begin[B], seg_cnt[A] | (seg_cnt[B] << 8)], 1).to(torch.int32)
+    ukeys, kcounts = torch.unique_consecutive(key, return_counts=True)
+    tile_start = torch.cumsum(kcounts, 0) - kcounts
+    nchunks = (kcounts + chunk - 1) // chunk
+    ctile = torch.repeat_interleave(torch.arange(ukeys.shape[0], device=dev), nchunks)
+    cfirst = torch.cumsum(nchunks, 0) - nchunks
+    local = torch.arange(ctile.shape[0], device=dev) - cfirst[ctile]
+    begin = tile_start[ctile] + local * chunk
+    end = torch.minimum(begin + chunk, tile_start[ctile] + kcounts[ctile])
+    chunk_desc = torch.stack([ukeys[ctile] // ngroups, ukeys[ctile] % ngroups, begin, end], 1).to(torch.int32)
+    return chunk_desc.contiguous(), entries.contiguous()
+
+
+def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_params=None, shared_camera=False,
+                    camera_type="SIMPLE_PINHOLE", max_points3D_val=3000, filter_negative_depth=True,
+                    gauge="colmap"):
+    """tensors (reference layout, on the GPU) -> DeviceProblem + bookkeeping.
+    Returns (problem, valid_idx (P',) long, deleted (P',) bool)."""
+    if camera_type not in MODEL_ID:
+        raise ValueError(f"Camera type {camera_type} is not supported yet")
+    dev = tracks.device
+    S = extrinsics.shape[0]
+    ext = extrinsics.to(torch.float64)
+    K = intrinsics.to(torch.float64)
+    masks = masks.bool()
+    length0 = masks.sum(0)
+    valid_idx = torch.nonzero(length0 >= 2).squeeze(1)
+    pts = points3d.to(torch.float64)[valid_idx].contiguous()
+    m = masks[:, valid_idx].clone()
+    m[:, ~(pts < max_points3D_val).all(-1)] = False
+    deleted = torch.zeros(valid_idx.shape[0], dtype=torch.bool, device=dev)
+    if filter_negative_depth:
+        # ObservationManager::FilterObservationsWithNegativeDepth, vectorised: observations are visited
+        # image by image; one is deleted when its depth < eps, and the whole point goes once a deletion
+        # meets a track of length <= 2  <=>  (initial length - number of bad observations) <= 1.
+        z = torch.einsum("sj,pj->sp", ext[:, 2, :3], pts) + ext[:, 2, 3][:, None]
+        bad = m & ~(z >= torch.finfo(torch.float64).eps)
+        nbad = bad.sum(0)
+        deleted = (nbad >= 1) & ((m.sum(0) - nbad) <= 1)
+        m = m & ~bad
+        m[:, deleted] = False
+    P = pts.shape[0]
+    pm = torch.nonzero(m.t())                       # point-major: sorted by point, then frame
+    obs_cam = pm[:, 1].to(torch.int32).contiguous()
+    counts = m.sum(0)
+    row_ptr = torch.zeros(P + 1, dtype=torch.int32, device=dev)
+    row_ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    tr = tracks.to(torch.float32)
+    obs_uv = tr[pm[:, 1], valid_idx[pm[:, 0]]].contiguous()
+    cm = torch.nonzero(m)                           # camera-major: sorted by frame, then point
+    cobs_pt = cm[:, 1].to(torch.int32).contiguous()
+    col_ptr = torch.zeros(S + 1, dtype=torch.int32, device=dev)
+    col_ptr[1:] = torch.cumsum(m.sum(1), 0).to(torch.int32)
+    cobs_uv = tr[cm[:, 0], valid_idx[cm[:, 1]]].contiguous()
+    cam_q = rotmat_to_quat(ext[:, :, :3]).contiguous()
+    cam_t = ext[:, :, 3].contiguous()
+    n_intr = 1 if shared_camera else S
+    intr = torch.zeros((n_intr, 4), dtype=torch.float64, device=dev)
+    src = slice(0, 1) if shared_camera else slice(None)
+    intr[:, 0] = K[src, 0, 0]
+    intr[:, 1] = K[src, 0, 2]
+    intr[:, 2] = K[src, 1, 2]
+    if camera_type == "SIMPLE_RADIAL":
+        intr[:, 3] = extra_params.to(torch.float64)[src, 0]
+    cam_const = torch.zeros(S, dtype=torch.uint8, device=dev)
+    if gauge == "colmap":
+        cam_const[0] = 1                            # SetConstantCamPose(first registered image)
+        if S > 1:
+            cam_const[1] = 2                        # SetConstantCamPositions(second image, {0})
+    chunk_desc, entries = build_schur_tiles(row_ptr, obs_cam)
+    prob = DeviceProblem(cam_q, cam_t, intr, pts, row_ptr, obs_cam, obs_uv, col_ptr, cobs_pt, cobs_uv, chunk_desc,
+                         entries, MODEL_ID[camera_type], cam_const=cam_const)
+    return prob, valid_idx, deleted
+
+
+def _c_options(options: BundleAdjustmentOptions):
+    so = options.solver_options
+    return _lib.BAOptions(so.max_num_iterations, so.max_num_consecutive_invalid_steps, int(so.jacobi_scaling),
+                          so.function_tolerance, so.gradient_tolerance, so.parameter_tolerance,
+                          so.initial_trust_region_radius, so.max_trust_region_radius, so.min_trust_region_radius,
+                          so.min_lm_diagonal, so.max_lm_diagonal, so.min_relative_decrease)
+
+
+def _summary_dict(summ, log, n):
+    its = [dict(iteration=l.iteration, cost=l.cost, cost_change=l.cost_change, gradient_max_norm=l.gradient_max_norm,
+                step_norm=l.step_norm, relative_decrease=l.relative_decrease, radius=l.radius,
+                successful=bool(l.successful)) for l in log[:n]]
+    return dict(initial_cost=summ.initial_cost, final_cost=summ.final_cost, num_iterations=summ.num_iterations,
+                num_successful_steps=summ.num_successful_steps, num_unsuccessful_steps=summ.num_unsuccessful_steps,
+                termination=summ.termination, termination_str=TERMINATION.get(summ.termination, "?"),
+                n_reduced=summ.n_reduced, iterations=its)
+
+
+def solve(problem: DeviceProblem, options: Optional[BundleAdjustmentOptions] = None, workspace=None):
+    """Run the LM loop of `problem` in place on the current stream; one host sync at the end."""
+    L = _lib.lib()
+    options = options or BundleAdjustmentOptions()
+    problem.refine_focal = options.refine_focal_length
+    problem.refine_extra = options.refine_extra_params
+    problem.loss = LOSS_ID[options.loss_function_type]
+    problem.loss_scale = options.loss_function_scale
+    cp = problem.c_struct()
+    co = _c_options(options)
+    nbytes = int(L.vgg_ba_workspace_bytes(ctypes.byref(cp), ctypes.byref(co)))
+    if workspace is None or workspace.numel() < nbytes:
+        workspace = torch.empty(nbytes, dtype=torch.uint8, device=problem.pts.device)
+    summ = _lib.BASummary()
+    cap = options.solver_options.max_num_iterations + 2
+    log = (_lib.BAIteration * cap)()
+    rc = L.vgg_ba_solve(ctypes.byref(cp), ctypes.byref(co), _lib.ptr(workspace), ctypes.c_size_t(workspace.numel()),
+                        ctypes.byref(summ), log, cap, _lib.stream_ptr())
+    _lib.check(rc, "vgg_ba_solve")
+    out = _summary_dict(summ, log, summ.num_log)
+    if options.print_summary:
+        print(f"Bundle adjustment report: residuals {problem.num_obs * 2}, parameters reduced {summ.n_reduced}, "
+              f"iterations {summ.num_iterations}, cost {summ.initial_cost:.6g} -> {summ.final_cost:.6g}, "
+              f"{out['termination_str']}")
+    return out, workspace
+
+
+def normalize_reconstruction(extrinsics, points3D, alive=None, extent=5.0, p0=0.1, p1=0.9):
+    """Reconstruction.normalize(5.0, 0.1, 0.9, True) (vggsfm/utils/triangulation.py:1217) on tensors."""
+    S = extrinsics.shape[0]
+    if S < 2:
+        return extrinsics, points3D
+    R, t = extrinsics[:, :, :3], extrinsics[:, :, 3]
+    centers = -torch.einsum("sji,sj->si", R, t)
+    c32, _ = torch.sort(centers.to(torch.float32), dim=0)
+    P0 = int(p0 * (S - 1)) if S > 3 else 0
+    P1 = int(p1 * (S - 1)) if S > 3 else S - 1
+    bmin, bmax = c32[P0].double(), c32[P1].double()
+    mean = c32[P0:P1 + 1].double().sum(0) / (P1 - P0 + 1)
+    old_extent = (bmax - bmin).norm()
+    scale = torch.where(old_extent < torch.finfo(torch.float64).eps, torch.ones_like(old_extent), extent / old_extent)
+    ext = extrinsics.clone()
+    ext[:, :, 3] = scale * (t + torch.einsum("sij,j->si", R, mean))
+    pts = points3D.clone()
+    if alive is None:
+        pts = scale * (pts - mean)
+    else:
+        pts[alive] = scale * (pts[alive] - mean)
+    return ext, pts
+
+
+def bundle_adjustment(points3d, extrinsics, intrinsics, tracks, masks, image_size=None, extra_params=None,
+                      shared_camera=False, camera_type="SIMPLE_PINHOLE", options=None, normalize=False):
+    """Tensor-in / tensor-out equivalent of the reference's three-call round trip.
+    Returns (points3D_opt (P',3), extrinsics (S,3,4), intrinsics (S,3,3), extra_params (S,1)|None, summary);
+    P' = number of tracks with >= 2 masked observations, rows of deleted points are zero."""
+    _lib.require_gpu(points3d, extrinsics, intrinsics, tracks, masks)
+    prob, valid_idx, deleted = compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_params,
+                                               shared_camera, camera_type)
+    summary, _ = solve(prob, options)
+    S = extrinsics.shape[0]
+    ext = torch.cat([quat_to_rotmat(prob.cam_q), prob.cam_t[:, :, None]], -1)
+    pts = prob.pts
+    pts[deleted] = 0.0
+    if normalize:
+        ext, pts = normalize_reconstruction(ext, pts, ~deleted)
+    idx = torch.zeros(S, dtype=torch.long, device=pts.device) if shared_camera else torch.arange(S, device=pts.device)
+    K = torch.zeros((S, 3, 3), dtype=torch.float64, device=pts.device)
+    K[:, 0, 0] = K[:, 1, 1] = prob.intr[idx, 0]
+    K[:, 0, 2] = prob.intr[idx, 1]
+    K[:, 1, 2] = prob.intr[idx, 2]
+    K[:, 2, 2] = 1.0
+    extra = prob.intr[idx, 3][:, None].clone() if camera_type == "SIMPLE_RADIAL" else None
+    summary["valid_idx"] = valid_idx
+    summary["deleted"] = deleted
+    return pts, ext, K, extra, summary

@@ -1,0 +1,1096 @@
+// Levenberg-Marquardt bundle adjustment with a block-sparse Schur complement, gfx950 (CDNA4).
+//
+// Replaces pycolmap.bundle_adjustment / pycolmap.pose_refinement as the reference uses them
+// (vggsfm/utils/triangulation.py:213,387,590,1050,1142; vggsfm/runners/video_runner.py:508,831,1001):
+// COLMAP's BundleAdjuster on Ceres' trust-region LM.  The Ceres control flow that decides the
+// trajectory (Jacobi scaling frozen at iteration 0, D^2 = clamp(diag J^T J)/radius, step quality,
+// radius update, invalid steps) is restated on the device so that the host never synchronises inside
+// the loop.  SURVEY.md Appendix A is the working spec.
+//
+// Data layout (all resident in HBM for the whole solve, float64 unless noted):
+//   cameras   cam_q[C,4] cam_t[C,3] intr[NI,4]        replicated on every GPU
+//   points    pts[P,3]                                 sharded by point index across GPUs
+//   observations, twice:  point-major CSR (row_ptr, obs_cam i32, obs_uv f32x2)
+//                         camera-major CSR (col_ptr, cobs_pt i32, cobs_uv f32x2)
+//   reduced camera system S[n,n] (lower, row-major), n = 6C + kd*NI
+// Kernels per LM iteration (algorithmic bytes in DESIGN.md):
+//   cam_pass<LIN>   camera-major: U_c = F^T F, g_c = F^T r, cost            (only after an accepted step)
+//   point_pass      point-major, one wavefront per point: V_p = E^T E + D^2, its Cholesky inverse,
+//                   h_p = V^-1 E^T r, shared-intrinsics coupling
+//   cam_pass<RHS>   camera-major: F^T (r - E h_p) and the shared-intrinsics Schur terms
+//   schur_tile      S -= sum_p Y_p Y_p^T on 16x16-camera tiles; thread (a,b) owns the 6x6 (7x7, 8x8)
+//                   block of cameras (I*16+a, J*16+b) in registers, Y blocks staged through LDS
+//   assemble        diagonal blocks, damping, constant columns
+//   cholesky        chol.hip (matrix-core trailing update)
+//   point_step      back-substitution, model cost change, candidate cost
+//   control         Ceres' accept / reject logic, one workgroup
+#include "camera_model.hpp"
+#include "../../include/vggsfm_amd.h"
+
+namespace vgg {
+
+int cholesky_solve_enqueue(double* A, double* b, int n, int32_t* device_fail, const int32_t* skip_flag, hipStream_t st);
+
+constexpr int kGroup = 16;       // cameras per Schur tile side
+constexpr int kBatch = 8;        // tile entries staged per barrier
+constexpr int kMaxWG = 2048;
+
+struct Ctl {
+  double radius, decrease_factor, x_cost, initial_cost, gmax_cams, gmax, cand_cost, mcc, step_norm, rel;
+  int32_t iteration, done, termination, need_lin, scale_ready, invalid_streak, num_succ, num_unsucc;
+  int32_t linear_fail, accept, rank, world, grad_logged, pad0, pad1, pad2;
+};
+
+struct Dims {
+  int C, P, O, NI, model, kd, only_k, shared, BDp, n_red, kdsh, loss;
+  double loss_scale;
+};
+
+struct Ws {  // device workspace carve-up (pointers into the caller's buffer)
+  Ctl* ctl;
+  vgg_ba_iteration* log;
+  double *cand_q, *cand_t, *cand_intr, *cand_pts;
+  double *scale_c, *scale_p, *colsq_c, *dsq_c, *dy;
+  uint8_t* active;            // [n_red]
+  double* lin;                // reduce buffer 0: U[C][BDp*BDp] | g[C][BDp] | cost[C]
+  double *U, *g, *costc;
+  double* sys;                // reduce buffer 1: S[n*n] | rhs[n]
+  double *S, *rhs;
+  double* gmax_pts;           // reduce buffer 2 (MAX): 1 double (padded to 8)
+  double* stepsum;            // reduce buffer 3: cost, mcc, step_sq, xnorm_sq  (padded to 8)
+  double *G, *hs, *Ms;        // per point: 6, 3, 3*kdsh
+  double* T;                  // [C][BDp][1+kdsh]
+  double* part_B;             // [kMaxWG] per-workgroup gradient max
+  double* part_F;             // [kMaxWG][4]
+  double* cam_part;           // [C+1][2] step^2 / x^2 of camera-side parameters
+  size_t lin_count, sys_count, total_bytes;
+};
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static Dims make_dims(const vgg_ba_problem* pb) {
+  Dims d;
+  d.C = pb->num_cams; d.P = pb->num_pts; d.O = pb->num_obs; d.NI = pb->num_intr; d.model = pb->camera_model;
+  const int rf = pb->refine_focal ? 1 : 0, rk = (pb->refine_extra && pb->camera_model == kSimpleRadial) ? 1 : 0;
+  d.kd = rf + rk;
+  d.only_k = (!rf && rk) ? 1 : 0;
+  d.shared = (pb->num_intr == 1) ? 1 : 0;
+  d.BDp = 6 + d.kd;
+  d.n_red = 6 * d.C + d.kd * d.NI;
+  d.kdsh = d.shared ? d.kd : 0;
+  d.loss = pb->loss; d.loss_scale = pb->loss_scale;
+  return d;
+}
+
+static Ws carve(const Dims& d, int max_iters, void* base) {
+  Ws w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return (char*)base + o; };
+  w.ctl = (Ctl*)take(sizeof(Ctl));
+  w.log = (vgg_ba_iteration*)take(sizeof(vgg_ba_iteration) * (size_t)(max_iters + 2));
+  w.cand_q = (double*)take(8ull * 4 * d.C); w.cand_t = (double*)take(8ull * 3 * d.C);
+  w.cand_intr = (double*)take(8ull * 4 * d.NI); w.cand_pts = (double*)take(8ull * 3 * d.P);
+  w.scale_c = (double*)take(8ull * d.n_red); w.scale_p = (double*)take(8ull * 3 * d.P);
+  w.colsq_c = (double*)take(8ull * d.n_red); w.dsq_c = (double*)take(8ull * d.n_red);
+  w.dy = (double*)take(8ull * d.n_red);
+  w.active = (uint8_t*)take(d.n_red);
+  w.lin_count = (size_t)d.C * d.BDp * d.BDp + (size_t)d.C * d.BDp + d.C;
+  w.lin = (double*)take(8ull * w.lin_count);
+  w.U = w.lin; w.g = w.U + (size_t)d.C * d.BDp * d.BDp; w.costc = w.g + (size_t)d.C * d.BDp;
+  w.sys_count = (size_t)d.n_red * d.n_red + d.n_red;
+  w.sys = (double*)take(8ull * w.sys_count);
+  w.S = w.sys; w.rhs = w.S + (size_t)d.n_red * d.n_red;
+  w.gmax_pts = (double*)take(64);
+  w.stepsum = (double*)take(64);
+  w.G = (double*)take(8ull * 6 * d.P); w.hs = (double*)take(8ull * 3 * d.P);
+  w.Ms = (double*)take(8ull * 3 * (d.kdsh ? d.kdsh : 1) * d.P);
+  w.T = (double*)take(8ull * d.C * d.BDp * (1 + d.kdsh));
+  w.part_B = (double*)take(8ull * kMaxWG);
+  w.part_F = (double*)take(8ull * kMaxWG * 4);
+  w.cam_part = (double*)take(8ull * (d.C + 1) * 2);
+  w.total_bytes = off;
+  return w;
+}
+
+struct DevProblem {  // by-value kernel argument
+  Dims d;
+  const double *cam_q, *cam_t, *intr, *pts;
+  const int32_t *row_ptr, *obs_cam, *col_ptr, *cobs_pt;
+  const float2 *obs_uv, *cobs_uv;
+  const uint8_t *cam_const, *intr_const, *pt_const;
+};
+
+static DevProblem dev_problem(const vgg_ba_problem* pb, const Dims& d) {
+  DevProblem p;
+  p.d = d; p.cam_q = pb->cam_q; p.cam_t = pb->cam_t; p.intr = pb->intr; p.pts = pb->pts;
+  p.row_ptr = pb->row_ptr; p.obs_cam = pb->obs_cam; p.col_ptr = pb->col_ptr; p.cobs_pt = pb->cobs_pt;
+  p.obs_uv = (const float2*)pb->obs_uv; p.cobs_uv = (const float2*)pb->cobs_uv;
+  p.cam_const = pb->cam_const; p.intr_const = pb->intr_const; p.pt_const = pb->pt_const;
+  return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One observation: corrected residual and corrected, constant-masked, UNSCALED Jacobians.
+//   F[2][6+KD]  (pose tangent 6, refined intrinsics KD), E[2][3] (point)
+template <int KD>
+__device__ __forceinline__ double eval_full(const Dims& d, const double* q, const double* t, const double* in4,
+                                            const double* X, float2 uv, unsigned camflag, bool intr_c, bool pt_c,
+                                            double* r, double* F, double* E) {
+  constexpr int BD = 6 + KD;
+  double Jp[12], Ji[4];
+  obs_eval(d.model, q, t, in4, X, (double)uv.x, (double)uv.y, r, Jp, Ji, E);
+#pragma unroll
+  for (int row = 0; row < 2; ++row) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) F[row * BD + k] = Jp[row * 6 + k];
+    if (KD == 2) { F[row * BD + 6] = Ji[row * 2]; F[row * BD + 7] = Ji[row * 2 + 1]; }
+    if (KD == 1) F[row * BD + 6] = d.only_k ? Ji[row * 2 + 1] : Ji[row * 2];
+  }
+  const double s = r[0] * r[0] + r[1] * r[1];
+  double rho[3];
+  loss_eval(d.loss, d.loss_scale, s, rho);
+  if (d.loss != kLossTrivial) {
+    Corrector c(s, rho);
+    c.jac<BD>(r, F);
+    c.jac<3>(r, E);
+    r[0] *= c.residual_scaling; r[1] *= c.residual_scaling;
+  }
+  if (camflag) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (camflag & 1u) { F[k] = 0; F[BD + k] = 0; }
+      if ((camflag & 1u) || (camflag & (2u << k))) { F[3 + k] = 0; F[BD + 3 + k] = 0; }
+    }
+  }
+  if (intr_c) {
+#pragma unroll
+    for (int k = 0; k < KD; ++k) { F[6 + k] = 0; F[BD + 6 + k] = 0; }
+  }
+  if (pt_c) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) E[k] = 0;
+  }
+  return rho[0];
+}
+
+__device__ __forceinline__ double loss_rho0(const Dims& d, double s) {
+  double rho[3];
+  loss_eval(d.loss, d.loss_scale, s, rho);
+  return rho[0];
+}
+
+// block-wide sum of NV per-thread values (256 threads); result valid on thread 0..NV-1 via out[]
+template <int NV>
+__device__ __forceinline__ void block_sum(double* v, double* lds /* [4][NV] */, double* out /* lds [NV] */) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const double s = wave_sum(v[i]);
+    if (lane == 0) lds[wave * NV + i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) out[threadIdx.x] = lds[threadIdx.x] + lds[NV + threadIdx.x] + lds[2 * NV + threadIdx.x] + lds[3 * NV + threadIdx.x];
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void init_kernel(DevProblem pb, Ws w, vgg_ba_options opt, int rank, int world) {
+  const Dims& d = pb.d;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j == 0) {
+    Ctl c;
+    memset(&c, 0, sizeof(c));
+    c.radius = opt.initial_trust_region_radius; c.decrease_factor = 2.0; c.need_lin = 1; c.rank = rank; c.world = world;
+    *w.ctl = c;
+    w.gmax_pts[0] = 0; for (int i = 0; i < 4; ++i) w.stepsum[i] = 0;
+  }
+  if (j < d.n_red) {
+    bool act;
+    if (j < 6 * d.C) {
+      const int c = j / 6, k = j - 6 * c;
+      const unsigned f = pb.cam_const ? pb.cam_const[c] : 0u;
+      act = (pb.col_ptr[c + 1] > pb.col_ptr[c]) || world > 1;
+      if (f & 1u) act = false;
+      if (k >= 3 && (f & (2u << (k - 3)))) act = false;
+    } else {
+      const int a = (j - 6 * d.C) / d.kd;
+      act = !(pb.intr_const && pb.intr_const[a]);
+      if (!d.shared && world == 1 && !(pb.col_ptr[a + 1] > pb.col_ptr[a])) act = false;
+    }
+    w.active[j] = act ? 1 : 0;
+    w.scale_c[j] = 1.0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// camera-major pass.  MODE 0: linearisation terms U_c, g_c, cost.  MODE 1: T_c = F^T [r - E hs | -E Ms].
+template <int KD, int MODE>
+__global__ __launch_bounds__(256) void cam_pass_kernel(DevProblem pb, Ws w) {
+  constexpr int BD = 6 + KD;
+  constexpr int NU = BD * (BD + 1) / 2;
+  constexpr int NV = (MODE == 0) ? (NU + BD + 1) : (BD * (1 + KD));
+  __shared__ double red[4 * NV];
+  __shared__ double tot[NV];
+  if (w.ctl->done) return;
+  if (MODE == 0 && !w.ctl->need_lin) return;
+  const Dims& d = pb.d;
+  const int c = blockIdx.x;
+  double q[4], t[3], in4[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) q[k] = pb.cam_q[4 * c + k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) t[k] = pb.cam_t[3 * c + k];
+  const int a = d.shared ? 0 : c;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) in4[k] = pb.intr[4 * a + k];
+  const unsigned camflag = pb.cam_const ? pb.cam_const[c] : 0u;
+  const bool intr_c = pb.intr_const ? pb.intr_const[a] != 0 : false;
+  const int kdsh = d.kdsh;
+  double acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = 0.0;
+  for (int j = pb.col_ptr[c] + threadIdx.x; j < pb.col_ptr[c + 1]; j += 256) {
+    const int p = pb.cobs_pt[j];
+    const float2 uv = pb.cobs_uv[j];
+    double X[3] = {pb.pts[3 * p], pb.pts[3 * p + 1], pb.pts[3 * p + 2]};
+    const bool pt_c = pb.pt_const ? pb.pt_const[p] != 0 : false;
+    double r[2], F[2 * BD], E[6];
+    const double rho0 = eval_full<KD>(d, q, t, in4, X, uv, camflag, intr_c, pt_c, r, F, E);
+    if (MODE == 0) {
+      int u = 0;
+#pragma unroll
+      for (int i = 0; i < BD; ++i)
+#pragma unroll
+        for (int k = i; k < BD; ++k) acc[u++] += F[i] * F[k] + F[BD + i] * F[BD + k];
+#pragma unroll
+      for (int i = 0; i < BD; ++i) acc[NU + i] += F[i] * r[0] + F[BD + i] * r[1];
+      acc[NU + BD] += rho0;
+    } else {
+      const double h0 = w.hs[3 * p], h1 = w.hs[3 * p + 1], h2 = w.hs[3 * p + 2];
+      double R0[1 + KD], R1[1 + KD];
+      R0[0] = r[0] - (E[0] * h0 + E[1] * h1 + E[2] * h2);
+      R1[0] = r[1] - (E[3] * h0 + E[4] * h1 + E[5] * h2);
+#pragma unroll
+      for (int m = 0; m < KD; ++m) {
+        if (m < kdsh) {
+          const double* M = w.Ms + ((size_t)p * kdsh + m) * 3;
+          R0[1 + m] = -(E[0] * M[0] + E[1] * M[1] + E[2] * M[2]);
+          R1[1 + m] = -(E[3] * M[0] + E[4] * M[1] + E[5] * M[2]);
+        } else { R0[1 + m] = 0; R1[1 + m] = 0; }
+      }
+#pragma unroll
+      for (int i = 0; i < BD; ++i)
+#pragma unroll
+        for (int m = 0; m < 1 + KD; ++m) acc[i * (1 + KD) + m] += F[i] * R0[m] + F[BD + i] * R1[m];
+    }
+  }
+  block_sum<NV>(acc, red, tot);
+  if (MODE == 0) {
+    double* U = w.U + (size_t)c * BD * BD;
+    if (threadIdx.x < NU) {
+      int i = 0, rem = threadIdx.x;
+      while (rem >= BD - i) { rem -= BD - i; ++i; }
+      const int k = i + rem;
+      U[i * BD + k] = tot[threadIdx.x];
+      U[k * BD + i] = tot[threadIdx.x];
+    }
+    if (threadIdx.x < BD) w.g[(size_t)c * BD + threadIdx.x] = tot[NU + threadIdx.x];
+    if (threadIdx.x == 0) w.costc[c] = tot[NU + BD];
+  } else {
+    // stored with row stride (1 + kdsh)
+    if (threadIdx.x < BD * (1 + KD)) {
+      const int i = threadIdx.x / (1 + KD), m = threadIdx.x - i * (1 + KD);
+      if (m < 1 + kdsh) w.T[((size_t)c * BD + i) * (1 + kdsh) + m] = tot[threadIdx.x];
+    }
+  }
+}
+
+// after (the all-reduce of) buffer 0: column norms, Jacobi scaling (first time), camera-side gradient max, cost
+template <int KD>
+__global__ __launch_bounds__(256) void prep_kernel(DevProblem pb, Ws w, vgg_ba_options opt) {
+  constexpr int BD = 6 + KD;
+  __shared__ double red[256];
+  Ctl* ctl = w.ctl;
+  if (ctl->done || !ctl->need_lin) return;
+  const Dims& d = pb.d;
+  const bool first = !ctl->scale_ready;
+  double gmax = 0.0, cost = 0.0;
+  for (int c = threadIdx.x; c < d.C; c += 256) {
+    const double* U = w.U + (size_t)c * BD * BD;
+    const double* g = w.g + (size_t)c * BD;
+    cost += w.costc[c];
+    for (int k = 0; k < 6; ++k) w.colsq_c[6 * c + k] = U[k * BD + k];
+    if (!d.shared) for (int k = 0; k < KD; ++k) w.colsq_c[6 * d.C + KD * c + k] = U[(6 + k) * BD + 6 + k];
+    // |Plus(x, -g) - x|_inf for this camera (Ceres projected-gradient norm)
+    double dl[3], qn[4];
+    for (int k = 0; k < 3; ++k) dl[k] = w.active[6 * c + k] ? -g[k] : 0.0;
+    quat_plus(pb.cam_q + 4 * c, dl, qn);
+    for (int k = 0; k < 4; ++k) gmax = fmax(gmax, fabs(qn[k] - pb.cam_q[4 * c + k]));
+    for (int k = 3; k < 6; ++k) if (w.active[6 * c + k]) gmax = fmax(gmax, fabs(g[k]));
+    if (!d.shared) for (int k = 0; k < KD; ++k) if (w.active[6 * d.C + KD * c + k]) gmax = fmax(gmax, fabs(g[6 + k]));
+  }
+  red[threadIdx.x] = cost; __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+  const double cost_total = red[0]; __syncthreads();
+  red[threadIdx.x] = gmax; __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]); __syncthreads(); }
+  double gm = red[0]; __syncthreads();
+  if (d.shared && KD > 0) {
+    // shared intrinsics: sum the per-camera parts in camera order (deterministic)
+    if (threadIdx.x < KD) {
+      const int k = threadIdx.x;
+      double cs = 0, gs = 0;
+      for (int c = 0; c < d.C; ++c) { cs += w.U[(size_t)c * BD * BD + (6 + k) * BD + 6 + k]; gs += w.g[(size_t)c * BD + 6 + k]; }
+      w.colsq_c[6 * d.C + k] = cs;
+      red[k] = w.active[6 * d.C + k] ? fabs(gs) : 0.0;
+    }
+    __syncthreads();
+    for (int k = 0; k < KD; ++k) gm = fmax(gm, red[k]);
+    __syncthreads();
+  }
+  if (first) {
+    for (int j = threadIdx.x; j < d.n_red; j += 256)
+      w.scale_c[j] = opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(w.colsq_c[j])) : 1.0;
+  }
+  if (threadIdx.x == 0) {
+    ctl->gmax_cams = gm;
+    if (first) { ctl->x_cost = 0.5 * cost_total; ctl->initial_cost = ctl->x_cost; }
+  }
+}
+
+// LM damping of the reduced columns for the current radius
+__global__ void damping_kernel(Ws w, vgg_ba_options opt, int n_red) {
+  if (w.ctl->done) return;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_red) return;
+  const double s = w.scale_c[j];
+  double dd = w.colsq_c[j] * s * s;
+  dd = fmin(fmax(dd, opt.min_lm_diagonal), opt.max_lm_diagonal);
+  w.dsq_c[j] = dd / w.ctl->radius;
+}
+
+// ---------------------------------------------------------------------------------------------
+// point-major pass: one wavefront per point
+template <int KD>
+__global__ __launch_bounds__(256) void point_pass_kernel(DevProblem pb, Ws w, vgg_ba_options opt) {
+  constexpr int BD = 6 + KD;
+  __shared__ double wmax[4];
+  Ctl* ctl = w.ctl;
+  if (ctl->done) return;
+  const Dims& d = pb.d;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nw = gridDim.x * 4;
+  const bool first = !ctl->scale_ready;
+  const double radius = ctl->radius;
+  const int kdsh = d.kdsh;
+  double gmax = 0.0;
+  for (int p = blockIdx.x * 4 + wave; p < d.P; p += nw) {
+    const int o0 = pb.row_ptr[p], o1 = pb.row_ptr[p + 1];
+    const double X[3] = {pb.pts[3 * p], pb.pts[3 * p + 1], pb.pts[3 * p + 2]};
+    const bool pt_c = pb.pt_const ? pb.pt_const[p] != 0 : false;
+    double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0}, Wa[3 * (KD ? KD : 1)];
+#pragma unroll
+    for (int i = 0; i < 3 * (KD ? KD : 1); ++i) Wa[i] = 0;
+    for (int o = o0 + lane; o < o1; o += 64) {
+      const int c = pb.obs_cam[o];
+      const int a = d.shared ? 0 : c;
+      double r[2], F[2 * BD], E[6];
+      eval_full<KD>(d, pb.cam_q + 4 * c, pb.cam_t + 3 * c, pb.intr + 4 * a, X, pb.obs_uv[o],
+                    pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
+      V[0] += E[0] * E[0] + E[3] * E[3]; V[1] += E[0] * E[1] + E[3] * E[4]; V[2] += E[0] * E[2] + E[3] * E[5];
+      V[3] += E[1] * E[1] + E[4] * E[4]; V[4] += E[1] * E[2] + E[4] * E[5]; V[5] += E[2] * E[2] + E[5] * E[5];
+      g[0] += E[0] * r[0] + E[3] * r[1]; g[1] += E[1] * r[0] + E[4] * r[1]; g[2] += E[2] * r[0] + E[5] * r[1];
+      if (KD > 0 && kdsh) {
+#pragma unroll
+        for (int m = 0; m < KD; ++m)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) Wa[m * 3 + b] += F[6 + m] * E[b] + F[BD + 6 + m] * E[3 + b];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) V[i] = wave_sum(V[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g[i] = wave_sum(g[i]);
+    if (KD > 0 && kdsh) {
+#pragma unroll
+      for (int i = 0; i < 3 * KD; ++i) Wa[i] = wave_sum(Wa[i]);
+    }
+    // every lane now holds the totals; lane 0 writes
+    double s[3];
+    const double colsq[3] = {V[0], V[3], V[5]};
+    if (first) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) s[k] = opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(colsq[k])) : 1.0;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) s[k] = w.scale_p[3 * p + k];
+    }
+    double Gm[6] = {0, 0, 0, 0, 0, 0}, hs[3] = {0, 0, 0};
+    double Ms[3 * (KD ? KD : 1)];
+#pragma unroll
+    for (int i = 0; i < 3 * (KD ? KD : 1); ++i) Ms[i] = 0;
+    if (!pt_c && o1 > o0) {
+      double dd[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dd[k] = fmin(fmax(colsq[k] * s[k] * s[k], opt.min_lm_diagonal), opt.max_lm_diagonal) / radius;
+      const double a00 = V[0] * s[0] * s[0] + dd[0], a10 = V[1] * s[0] * s[1], a20 = V[2] * s[0] * s[2];
+      const double a11 = V[3] * s[1] * s[1] + dd[1], a21 = V[4] * s[1] * s[2], a22 = V[5] * s[2] * s[2] + dd[2];
+      bool ok = a00 > 0;
+      const double l00 = sqrt(a00);
+      const double l10 = a10 / l00, l20 = a20 / l00;
+      const double d11 = a11 - l10 * l10;
+      ok = ok && d11 > 0;
+      const double l11 = sqrt(d11);
+      const double l21 = (a21 - l20 * l10) / l11;
+      const double d22 = a22 - l20 * l20 - l21 * l21;
+      ok = ok && d22 > 0;
+      const double l22 = sqrt(d22);
+      if (!ok) { if (lane == 0) ctl->linear_fail = 1; }
+      // Linv (lower): i00 i10 i11 i20 i21 i22
+      const double i00 = 1 / l00, i11 = 1 / l11, i22 = 1 / l22;
+      const double i10 = -l10 * i00 * i11;
+      const double i21 = -l21 * i11 * i22;
+      const double i20 = -(l20 * i00 + l21 * i10) * i22;
+      // G = S_p * Linv^T (upper triangular): G[b][m], b <= m   stored as G00 G01 G02 G11 G12 G22
+      Gm[0] = s[0] * i00; Gm[1] = s[0] * i10; Gm[2] = s[0] * i20; Gm[3] = s[1] * i11; Gm[4] = s[1] * i21; Gm[5] = s[2] * i22;
+      // z = Linv * (s o g) ; hs = G z
+      const double gs0 = s[0] * g[0], gs1 = s[1] * g[1], gs2 = s[2] * g[2];
+      const double z0 = i00 * gs0, z1 = i10 * gs0 + i11 * gs1, z2 = i20 * gs0 + i21 * gs1 + i22 * gs2;
+      hs[0] = Gm[0] * z0 + Gm[1] * z1 + Gm[2] * z2; hs[1] = Gm[3] * z1 + Gm[4] * z2; hs[2] = Gm[5] * z2;
+      if (KD > 0 && kdsh) {
+#pragma unroll
+        for (int m = 0; m < KD; ++m) {
+          const double sa = w.scale_c[6 * d.C + m];
+          // W_a (scaled) row m: sa * Wa[m][b] * s[b];  Ms[:,m] = G G^T (S_p^-1 ...)  -> S_p V^-1 W_a^T = G (Linv (s o Wa^T)) * sa
+          const double w0 = sa * s[0] * Wa[m * 3], w1 = sa * s[1] * Wa[m * 3 + 1], w2 = sa * s[2] * Wa[m * 3 + 2];
+          const double y0 = i00 * w0, y1 = i10 * w0 + i11 * w1, y2 = i20 * w0 + i21 * w1 + i22 * w2;
+          Ms[m * 3] = Gm[0] * y0 + Gm[1] * y1 + Gm[2] * y2; Ms[m * 3 + 1] = Gm[3] * y1 + Gm[4] * y2; Ms[m * 3 + 2] = Gm[5] * y2;
+        }
+      }
+      gmax = fmax(gmax, fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2]))));
+    }
+    if (lane == 0) {
+      if (first) { w.scale_p[3 * p] = s[0]; w.scale_p[3 * p + 1] = s[1]; w.scale_p[3 * p + 2] = s[2]; }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) w.G[6 * (size_t)p + i] = Gm[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) w.hs[3 * (size_t)p + i] = hs[i];
+      if (KD > 0 && kdsh) {
+#pragma unroll
+        for (int i = 0; i < 3 * KD; ++i) w.Ms[(size_t)p * 3 * kdsh + i] = Ms[i];
+      }
+    }
+  }
+  if (lane == 0) wmax[wave] = gmax;
+  __syncthreads();
+  if (threadIdx.x == 0) w.part_B[blockIdx.x] = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
+}
+
+__global__ __launch_bounds__(256) void reduce_gmax_kernel(Ws w, int nparts) {
+  __shared__ double red[256];
+  if (w.ctl->done) return;
+  double m = 0;
+  for (int i = threadIdx.x; i < nparts; i += 256) m = fmax(m, w.part_B[i]);
+  red[threadIdx.x] = m; __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]); __syncthreads(); }
+  if (threadIdx.x == 0) w.gmax_pts[0] = red[0];
+}
+
+// start-of-iteration checks (Ceres FinalizeIterationAndCheckIfMinimizerCanContinue)
+__global__ void begin_iteration_kernel(Ws w, vgg_ba_options opt) {
+  Ctl* c = w.ctl;
+  if (c->done) return;
+  if (c->need_lin) {
+    c->gmax = fmax(c->gmax_cams, w.gmax_pts[0]);
+    w.log[c->iteration].gradient_max_norm = c->gmax;
+    if (c->iteration == 0) {
+      vgg_ba_iteration z;
+      z.iteration = 0; z.successful = 1; z.cost = c->x_cost; z.cost_change = 0; z.gradient_max_norm = c->gmax;
+      z.step_norm = 0; z.relative_decrease = 0; z.radius = c->radius;
+      w.log[0] = z;
+    }
+    if (c->gmax <= opt.gradient_tolerance) { c->done = 1; c->termination = 1; return; }
+  }
+  if (c->iteration >= opt.max_num_iterations) { c->done = 1; c->termination = 0; return; }
+  if (c->radius <= opt.min_trust_region_radius) { c->done = 1; c->termination = 4; return; }
+  c->scale_ready = 1;
+  c->need_lin = 0;
+  c->iteration += 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Block-sparse Schur complement:  S[(cI,a),(cJ,b)] -= sum_p Y_{p,a} Y_{p,b}^T over the entries of one chunk.
+// Thread (a,b) of the 16x16 workgroup owns the BDxBD block of cameras (gI*16+a, gJ*16+b).
+//   Y_i = s_c o ((F_i^T E_i) G_p)   (BD x 3), recomputed from the raw observation: 16 B of HBM per
+//   observation instead of a 144-192 B cached block.
+template <int KD, int BD>
+struct TileCam {  // camera staged in LDS
+  double q[4], t[3], in4[4], s[BD];
+  unsigned flag; int intr_c;
+};
+
+template <int KD, int BD>
+__global__ __launch_bounds__(256) void schur_tile_kernel(DevProblem pb, Ws w, const int32_t* __restrict__ chunk_desc,
+                                                         const int32_t* __restrict__ entries) {
+  constexpr int YS = BD * 3;                      // doubles per Y block
+  __shared__ TileCam<KD, BD> cams[2][kGroup];
+  __shared__ __attribute__((aligned(16))) double Y[kBatch][2][kGroup][YS];
+  __shared__ unsigned present[kBatch][2];
+  if (w.ctl->done) return;
+  const Dims& d = pb.d;
+  const int tid = threadIdx.x;
+  const int gI = chunk_desc[4 * blockIdx.x], gJ = chunk_desc[4 * blockIdx.x + 1];
+  const int e0 = chunk_desc[4 * blockIdx.x + 2], e1 = chunk_desc[4 * blockIdx.x + 3];
+  const bool diag = (gI == gJ);
+  // stage the (up to) 32 cameras
+  if (tid < 2 * kGroup) {
+    const int side = tid >> 4, l = tid & 15;
+    const int c = (side ? gJ : gI) * kGroup + l;
+    TileCam<KD, BD>& tc = cams[side][l];
+    if (c < d.C) {
+      const int a = d.shared ? 0 : c;
+      for (int k = 0; k < 4; ++k) { tc.q[k] = pb.cam_q[4 * c + k]; tc.in4[k] = pb.intr[4 * a + k]; }
+      for (int k = 0; k < 3; ++k) tc.t[k] = pb.cam_t[3 * c + k];
+      for (int k = 0; k < 6; ++k) tc.s[k] = w.scale_c[6 * c + k];
+      for (int k = 0; k < BD - 6; ++k) tc.s[6 + k] = w.scale_c[6 * d.C + KD * c + k];
+      tc.flag = pb.cam_const ? pb.cam_const[c] : 0u;
+      tc.intr_c = (pb.intr_const && pb.intr_const[a]) ? 1 : 0;
+    }
+  }
+  if (tid < kBatch * 2) present[tid >> 1][tid & 1] = 0u;
+  const int a = tid >> 4, b = tid & 15;
+  double acc[BD * BD];
+#pragma unroll
+  for (int i = 0; i < BD * BD; ++i) acc[i] = 0.0;
+  bool touched = false;
+  __syncthreads();
+  for (int eb = e0; eb < e1; eb += kBatch) {
+    // ---- stage: one thread per (entry, side, slot) computes one Y block
+    {
+      const int be = tid >> 5, side = (tid >> 4) & 1, k = tid & 15;
+      const int e = eb + be;
+      if (e < e1 && !(diag && side)) {
+        const int4 en = reinterpret_cast<const int4*>(entries)[e];
+        const int cnt = side ? ((en.w >> 8) & 0xff) : (en.w & 0xff);
+        if (k < cnt) {
+          const int o = (side ? en.z : en.y) + k;
+          const int c = pb.obs_cam[o];
+          const int l = c - (side ? gJ : gI) * kGroup;
+          const TileCam<KD, BD>& tc = cams[side][l];
+          const int p = en.x;
+          const double X[3] = {pb.pts[3 * p], pb.pts[3 * p + 1], pb.pts[3 * p + 2]};
+          double r[2], F[2 * (6 + KD)], E[6];
+          // intrinsics columns only take part in the tile when they are per-camera (BD > 6)
+          eval_full<KD>(d, tc.q, tc.t, tc.in4, X, pb.obs_uv[o], tc.flag, tc.intr_c != 0,
+                        pb.pt_const ? pb.pt_const[p] != 0 : false, r, F, E);
+          const double* Gp = w.G + 6 * (size_t)p;
+          const double G00 = Gp[0], G01 = Gp[1], G02 = Gp[2], G11 = Gp[3], G12 = Gp[4], G22 = Gp[5];
+          double* y = &Y[be][side][l][0];
+          constexpr int FB = 6 + KD;
+#pragma unroll
+          for (int i = 0; i < BD; ++i) {
+            const double w0 = F[i] * E[0] + F[FB + i] * E[3], w1 = F[i] * E[1] + F[FB + i] * E[4],
+                         w2 = F[i] * E[2] + F[FB + i] * E[5];
+            const double sc = tc.s[i];
+            y[i * 3 + 0] = sc * (w0 * G00);
+            y[i * 3 + 1] = sc * (w0 * G01 + w1 * G11);
+            y[i * 3 + 2] = sc * (w0 * G02 + w1 * G12 + w2 * G22);
+          }
+          atomicOr(&present[be][side], 1u << l);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- accumulate
+#pragma unroll 1
+    for (int be = 0; be < kBatch; ++be) {
+      const unsigned mA = present[be][0], mB = diag ? mA : present[be][1];
+      if (((mA >> a) & 1u) && ((mB >> b) & 1u) && (!diag || a <= b)) {
+        touched = true;
+        const double* ya = &Y[be][0][a][0];
+        const double* yb = &Y[be][diag ? 0 : 1][b][0];
+        double A[YS];
+#pragma unroll
+        for (int i = 0; i < YS; ++i) A[i] = ya[i];
+#pragma unroll
+        for (int j = 0; j < BD; ++j) {
+          const double b0 = yb[j * 3], b1 = yb[j * 3 + 1], b2 = yb[j * 3 + 2];
+#pragma unroll
+          for (int i = 0; i < BD; ++i) acc[i * BD + j] += A[i * 3] * b0 + A[i * 3 + 1] * b1 + A[i * 3 + 2] * b2;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < kBatch * 2) present[tid >> 1][tid & 1] = 0u;
+    // (the next stage's atomicOr happens after the threads pass the zeroing in program order of the
+    //  same wave only; a barrier is needed because other waves write the masks)
+    __syncthreads();
+  }
+  if (!touched) return;
+  const int ca = gI * kGroup + a, cb = gJ * kGroup + b;
+  const int n = d.n_red;
+#pragma unroll
+  for (int i = 0; i < BD; ++i) {
+    const int ri = (i < 6) ? 6 * ca + i : 6 * d.C + KD * ca + (i - 6);
+#pragma unroll
+    for (int j = 0; j < BD; ++j) {
+      const int cj = (j < 6) ? 6 * cb + j : 6 * d.C + KD * cb + (j - 6);
+      if (ca == cb && cj > ri) continue;          // symmetric diagonal block: lower half only
+      const int hi = ri > cj ? ri : cj, lo = ri > cj ? cj : ri;
+      const double v = acc[i * BD + j];
+      if (v != 0.0) unsafeAtomicAdd(&w.S[(size_t)hi * n + lo], -v);
+    }
+  }
+}
+
+// diagonal blocks, camera/intrinsics coupling, damping, right-hand side.  One workgroup (64) per camera,
+// plus one extra for the shared-intrinsics block.  Only rank 0 adds the terms that were already summed
+// over ranks (U, damping); the per-rank systems are then all-reduced.
+template <int KD>
+__global__ __launch_bounds__(64) void assemble_kernel(DevProblem pb, Ws w) {
+  constexpr int BD = 6 + KD;
+  if (w.ctl->done) return;
+  const int global_terms = (w.ctl->rank == 0);
+  const Dims& d = pb.d;
+  const int n = d.n_red, kdsh = d.kdsh, tw = 1 + kdsh;
+  const int c = blockIdx.x, tid = threadIdx.x;
+  if (c < d.C) {
+    const double* U = w.U + (size_t)c * BD * BD;
+    const double* T = w.T + (size_t)c * BD * tw;
+    const int ia = 6 * d.C + (d.shared ? 0 : KD * c);
+    // BD x BD block (lower part), rows/cols mapped to reduced indices
+    for (int e = tid; e < BD * BD; e += 64) {
+      const int i = e / BD, j = e - i * BD;
+      const int ri = (i < 6) ? 6 * c + i : ia + (i - 6), cj = (j < 6) ? 6 * c + j : ia + (j - 6);
+      if (cj > ri) continue;
+      if (d.shared && i >= 6 && j >= 6) continue;           // intr-intr of the shared block: extra workgroup
+      double v = 0.0;
+      if (global_terms) {
+        v = w.scale_c[ri] * w.scale_c[cj] * U[i * BD + j];
+        if (ri == cj) v += w.dsq_c[ri];
+      }
+      if (d.shared && i >= 6) v += w.scale_c[cj] * T[j * tw + 1 + (i - 6)];   // -F_pose^T E M
+      w.S[(size_t)ri * n + cj] += v;
+    }
+    if (tid < 6) w.rhs[6 * c + tid] += w.scale_c[6 * c + tid] * T[tid * tw];
+    if (!d.shared && tid >= 6 && tid < BD) w.rhs[ia + tid - 6] += w.scale_c[ia + tid - 6] * T[tid * tw];
+  } else if (d.shared && KD > 0) {
+    const int ia = 6 * d.C;
+    if (tid < KD * KD) {
+      const int i = tid / KD, j = tid - i * KD;
+      if (j <= i) {
+        double v = 0.0;
+        for (int cc = 0; cc < d.C; ++cc) {
+          if (global_terms) v += w.scale_c[ia + i] * w.scale_c[ia + j] * w.U[(size_t)cc * BD * BD + (6 + i) * BD + 6 + j];
+          v += w.scale_c[ia + i] * w.T[((size_t)cc * BD + 6 + i) * tw + 1 + j];
+        }
+        if (global_terms && i == j) v += w.dsq_c[ia + i];
+        w.S[(size_t)(ia + i) * n + ia + j] += v;
+      }
+    }
+    if (tid < KD) {
+      double v = 0.0;
+      for (int cc = 0; cc < d.C; ++cc) v += w.T[((size_t)cc * BD + 6 + tid) * tw];
+      w.rhs[ia + tid] += w.scale_c[ia + tid] * v;
+    }
+  }
+}
+
+// constant / unobserved columns: unit diagonal, zero right-hand side (their Jacobian columns are zero)
+__global__ void fix_constant_kernel(Ws w, int n) {
+  if (w.ctl->done) return;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n || w.active[j]) return;
+  w.S[(size_t)j * n + j] = 1.0;
+  w.rhs[j] = 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// candidate cameras: x (+) (-s o y); also the camera-side part of |step| and |x|
+template <int KD>
+__global__ void cam_update_kernel(DevProblem pb, Ws w) {
+  if (w.ctl->done) return;
+  const Dims& d = pb.d;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > d.C) return;
+  double step = 0, xn = 0;
+  if (c < d.C) {
+    double dl[6];
+    for (int k = 0; k < 6; ++k) {
+      const int j = 6 * c + k;
+      const double dyv = w.active[j] ? w.scale_c[j] * w.rhs[j] : 0.0;
+      w.dy[j] = dyv;
+      dl[k] = -dyv;
+    }
+    double qn[4];
+    quat_plus(pb.cam_q + 4 * c, dl, qn);
+    for (int k = 0; k < 4; ++k) { w.cand_q[4 * c + k] = qn[k]; const double df = qn[k] - pb.cam_q[4 * c + k]; step += df * df; xn += pb.cam_q[4 * c + k] * pb.cam_q[4 * c + k]; }
+    for (int k = 0; k < 3; ++k) { const double tn = pb.cam_t[3 * c + k] + dl[3 + k]; w.cand_t[3 * c + k] = tn; step += dl[3 + k] * dl[3 + k]; xn += pb.cam_t[3 * c + k] * pb.cam_t[3 * c + k]; }
+  }
+  // intrinsics block a == c (per camera) or block 0 handled by the extra thread c == C (shared)
+  const int a = d.shared ? ((c == d.C) ? 0 : -1) : ((c < d.C) ? c : -1);
+  if (a >= 0) {
+    double in4[4];
+    for (int k = 0; k < 4; ++k) in4[k] = pb.intr[4 * a + k];
+    for (int k = 0; k < KD; ++k) {
+      const int j = 6 * d.C + KD * a + k;
+      const double dyv = w.active[j] ? w.scale_c[j] * w.rhs[j] : 0.0;
+      w.dy[j] = dyv;
+      const int slot = (KD == 2) ? (k == 0 ? 0 : 3) : (d.only_k ? 3 : 0);
+      in4[slot] -= dyv;
+      step += dyv * dyv;
+    }
+    for (int k = 0; k < 4; ++k) { w.cand_intr[4 * a + k] = in4[k]; xn += pb.intr[4 * a + k] * pb.intr[4 * a + k]; }
+  }
+  w.cam_part[2 * c] = step;
+  w.cam_part[2 * c + 1] = xn;
+}
+
+// back-substitution, model cost change, candidate point and candidate cost: one wavefront per point
+template <int KD>
+__global__ __launch_bounds__(256) void point_step_kernel(DevProblem pb, Ws w) {
+  constexpr int BD = 6 + KD;
+  __shared__ double red[4][4];
+  if (w.ctl->done) return;
+  const Dims& d = pb.d;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nw = gridDim.x * 4;
+  double s_cost = 0, s_mcc = 0, s_step = 0, s_xn = 0;
+  for (int p = blockIdx.x * 4 + wave; p < d.P; p += nw) {
+    const int o0 = pb.row_ptr[p], o1 = pb.row_ptr[p + 1];
+    const double X[3] = {pb.pts[3 * p], pb.pts[3 * p + 1], pb.pts[3 * p + 2]};
+    const bool pt_c = pb.pt_const ? pb.pt_const[p] != 0 : false;
+    double t3[3] = {0, 0, 0};
+    // cached values of this lane's first observation (tracks longer than 64 recompute)
+    double c_r[2] = {0, 0}, c_fy[2] = {0, 0}, c_E[6] = {0, 0, 0, 0, 0, 0};
+    for (int o = o0 + lane; o < o1; o += 64) {
+      const int c = pb.obs_cam[o];
+      const int a = d.shared ? 0 : c;
+      double r[2], F[2 * BD], E[6];
+      eval_full<KD>(d, pb.cam_q + 4 * c, pb.cam_t + 3 * c, pb.intr + 4 * a, X, pb.obs_uv[o],
+                    pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
+      double fy0 = 0, fy1 = 0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { const double v = w.dy[6 * c + k]; fy0 += F[k] * v; fy1 += F[BD + k] * v; }
+#pragma unroll
+      for (int k = 0; k < KD; ++k) { const double v = w.dy[6 * d.C + KD * a + k]; fy0 += F[6 + k] * v; fy1 += F[BD + 6 + k] * v; }
+      t3[0] += E[0] * fy0 + E[3] * fy1; t3[1] += E[1] * fy0 + E[4] * fy1; t3[2] += E[2] * fy0 + E[5] * fy1;
+      if (o - o0 < 64) {
+        c_r[0] = r[0]; c_r[1] = r[1]; c_fy[0] = fy0; c_fy[1] = fy1;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c_E[k] = E[k];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t3[i] = wave_sum(t3[i]);
+    const double* Gp = w.G + 6 * (size_t)p;
+    const double G00 = Gp[0], G01 = Gp[1], G02 = Gp[2], G11 = Gp[3], G12 = Gp[4], G22 = Gp[5];
+    // ys = hs - G G^T t3
+    const double u0 = G00 * t3[0], u1 = G01 * t3[0] + G11 * t3[1], u2 = G02 * t3[0] + G12 * t3[1] + G22 * t3[2];
+    double ys[3];
+    ys[0] = w.hs[3 * p] - (G00 * u0 + G01 * u1 + G02 * u2);
+    ys[1] = w.hs[3 * p + 1] - (G11 * u1 + G12 * u2);
+    ys[2] = w.hs[3 * p + 2] - (G22 * u2);
+    const double Xn[3] = {X[0] - ys[0], X[1] - ys[1], X[2] - ys[2]};
+    if (lane == 0) {
+      w.cand_pts[3 * (size_t)p] = Xn[0]; w.cand_pts[3 * (size_t)p + 1] = Xn[1]; w.cand_pts[3 * (size_t)p + 2] = Xn[2];
+      s_step += ys[0] * ys[0] + ys[1] * ys[1] + ys[2] * ys[2];
+      s_xn += X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
+    }
+    for (int o = o0 + lane; o < o1; o += 64) {
+      const int c = pb.obs_cam[o];
+      const int a = d.shared ? 0 : c;
+      double r[2], fy[2], E[6];
+      if (o - o0 < 64) {
+        r[0] = c_r[0]; r[1] = c_r[1]; fy[0] = c_fy[0]; fy[1] = c_fy[1];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) E[k] = c_E[k];
+      } else {
+        double F[2 * BD];
+        eval_full<KD>(d, pb.cam_q + 4 * c, pb.cam_t + 3 * c, pb.intr + 4 * a, X, pb.obs_uv[o],
+                      pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
+        fy[0] = 0; fy[1] = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { const double v = w.dy[6 * c + k]; fy[0] += F[k] * v; fy[1] += F[BD + k] * v; }
+#pragma unroll
+        for (int k = 0; k < KD; ++k) { const double v = w.dy[6 * d.C + KD * a + k]; fy[0] += F[6 + k] * v; fy[1] += F[BD + 6 + k] * v; }
+      }
+      // model residual of the step s = -y:  m = -(F dy + E ys)
+      const double m0 = -(fy[0] + E[0] * ys[0] + E[1] * ys[1] + E[2] * ys[2]);
+      const double m1 = -(fy[1] + E[3] * ys[0] + E[4] * ys[1] + E[5] * ys[2]);
+      s_mcc += -(m0 * (r[0] + m0 / 2.0) + m1 * (r[1] + m1 / 2.0));
+      double rc[2];
+      const float2 uv = pb.obs_uv[o];
+      obs_residual(d.model, w.cand_q + 4 * c, w.cand_t + 3 * c, w.cand_intr + 4 * a, Xn, (double)uv.x, (double)uv.y, rc);
+      s_cost += loss_rho0(d, rc[0] * rc[0] + rc[1] * rc[1]);
+    }
+  }
+  s_cost = wave_sum(s_cost); s_mcc = wave_sum(s_mcc); s_step = wave_sum(s_step); s_xn = wave_sum(s_xn);
+  if (lane == 0) { red[wave][0] = s_cost; red[wave][1] = s_mcc; red[wave][2] = s_step; red[wave][3] = s_xn; }
+  __syncthreads();
+  if (threadIdx.x < 4) w.part_F[4 * blockIdx.x + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void reduce_step_kernel(Ws w, int nparts) {
+  __shared__ double red[4][256];
+  if (w.ctl->done) return;
+  double s[4] = {0, 0, 0, 0};
+  for (int i = threadIdx.x; i < nparts; i += 256)
+    for (int k = 0; k < 4; ++k) s[k] += w.part_F[4 * i + k];
+  for (int k = 0; k < 4; ++k) red[k][threadIdx.x] = s[k];
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) w.stepsum[threadIdx.x] = red[threadIdx.x][0];
+}
+
+// Ceres' trust-region decision (TrustRegionMinimizer::Minimize body + LevenbergMarquardtStrategy)
+__global__ void control_kernel(Ws w, vgg_ba_options opt, int C) {
+  Ctl* c = w.ctl;
+  if (c->done) return;
+  const int it = c->iteration;
+  vgg_ba_iteration li;
+  li.iteration = it; li.successful = 0; li.cost = c->x_cost; li.cost_change = 0; li.gradient_max_norm = c->gmax;
+  li.step_norm = 0; li.relative_decrease = 0; li.radius = c->radius;
+  c->accept = 0;
+  double step_c = 0, xn_c = 0;
+  for (int i = 0; i <= C; ++i) { step_c += w.cam_part[2 * i]; xn_c += w.cam_part[2 * i + 1]; }
+  const double cand_cost = 0.5 * w.stepsum[0];
+  const double mcc = w.stepsum[1];
+  const double step_norm = sqrt(w.stepsum[2] + step_c);
+  const double x_norm = sqrt(w.stepsum[3] + xn_c);
+  c->cand_cost = cand_cost; c->mcc = mcc; c->step_norm = step_norm;
+  const bool step_valid = !c->linear_fail && (mcc > 0.0);
+  c->linear_fail = 0;
+  if (!step_valid) {
+    if (++c->invalid_streak >= opt.max_num_consecutive_invalid_steps) { c->done = 1; c->termination = 5; }
+    c->radius /= c->decrease_factor; c->decrease_factor *= 2.0;
+    c->num_unsucc += 1;
+    li.radius = c->radius;
+    w.log[it] = li;
+    return;
+  }
+  c->invalid_streak = 0;
+  li.step_norm = step_norm;
+  li.cost_change = c->x_cost - cand_cost;
+  const double ptol = opt.parameter_tolerance * (x_norm + opt.parameter_tolerance);
+  if (!(step_norm > ptol)) { c->done = 1; c->termination = 3; w.log[it] = li; return; }
+  if (fabs(c->x_cost - cand_cost) <= opt.function_tolerance * c->x_cost) { c->done = 1; c->termination = 2; w.log[it] = li; return; }
+  const double rel = (c->x_cost - cand_cost) / mcc;
+  c->rel = rel;
+  li.relative_decrease = rel;
+  if (rel > opt.min_relative_decrease) {
+    c->accept = 1;
+    c->x_cost = cand_cost;
+    const double tmp = 2.0 * rel - 1.0;
+    c->radius = c->radius / fmax(1.0 / 3.0, 1.0 - tmp * tmp * tmp);
+    c->radius = fmin(opt.max_trust_region_radius, c->radius);
+    c->decrease_factor = 2.0;
+    c->need_lin = 1;
+    c->num_succ += 1;
+    li.successful = 1; li.cost = cand_cost;
+  } else {
+    c->radius /= c->decrease_factor; c->decrease_factor *= 2.0;
+    c->num_unsucc += 1;
+  }
+  li.radius = c->radius;
+  w.log[it] = li;
+}
+
+__global__ void commit_kernel(Ws w, double* cam_q, double* cam_t, double* intr, double* pts, int C, int NI, int P) {
+  if (!w.ctl->accept) return;     // accept is cleared by control_kernel on every live iteration
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)3 * P) pts[i] = w.cand_pts[i];
+  if (i < (size_t)4 * C) cam_q[i] = w.cand_q[i];
+  if (i < (size_t)3 * C) cam_t[i] = w.cand_t[i];
+  if (i < (size_t)4 * NI) intr[i] = w.cand_intr[i];
+}
+__global__ void clear_accept_kernel(Ws w) { if (w.ctl->done) w.ctl->accept = 0; }
+
+// ---------------------------------------------------------------------------------------------
+// host side
+struct Launch {
+  Dims d; DevProblem dp; Ws w; vgg_ba_options opt; hipStream_t st; int wgB;
+  const int32_t* chunk_desc; const int32_t* entries; int num_chunks;
+  double *cam_q, *cam_t, *intr, *pts;
+};
+
+template <int KD>
+static void phase_linearize(const Launch& L) {
+  cam_pass_kernel<KD, 0><<<L.d.C, 256, 0, L.st>>>(L.dp, L.w);
+}
+
+template <int KD>
+static void phase_schur(const Launch& L) {
+  const Dims& d = L.d;
+  prep_kernel<KD><<<1, 256, 0, L.st>>>(L.dp, L.w, L.opt);
+  damping_kernel<<<div_up(d.n_red, 256), 256, 0, L.st>>>(L.w, L.opt, d.n_red);
+  point_pass_kernel<KD><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w, L.opt);
+  reduce_gmax_kernel<<<1, 256, 0, L.st>>>(L.w, L.wgB);
+  cam_pass_kernel<KD, 1><<<d.C, 256, 0, L.st>>>(L.dp, L.w);
+  hipMemsetAsync(L.w.sys, 0, sizeof(double) * L.w.sys_count, L.st);
+  if (L.num_chunks > 0) {
+    if (d.shared || KD == 0) schur_tile_kernel<KD, 6><<<L.num_chunks, 256, 0, L.st>>>(L.dp, L.w, L.chunk_desc, L.entries);
+    else schur_tile_kernel<KD, 6 + KD><<<L.num_chunks, 256, 0, L.st>>>(L.dp, L.w, L.chunk_desc, L.entries);
+  }
+  assemble_kernel<KD><<<d.C + 1, 64, 0, L.st>>>(L.dp, L.w);
+}
+
+template <int KD>
+static int phase_step(const Launch& L) {
+  const Dims& d = L.d;
+  begin_iteration_kernel<<<1, 1, 0, L.st>>>(L.w, L.opt);
+  fix_constant_kernel<<<div_up(d.n_red, 256), 256, 0, L.st>>>(L.w, d.n_red);
+  int rc = cholesky_solve_enqueue(L.w.S, L.w.rhs, d.n_red, &L.w.ctl->linear_fail, &L.w.ctl->done, L.st);
+  if (rc != VGG_OK) return rc;
+  cam_update_kernel<KD><<<div_up(d.C + 1, 64), 64, 0, L.st>>>(L.dp, L.w);
+  point_step_kernel<KD><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w);
+  reduce_step_kernel<<<1, 256, 0, L.st>>>(L.w, L.wgB);
+  return VGG_OK;
+}
+
+static void phase_update(const Launch& L) {
+  const Dims& d = L.d;
+  control_kernel<<<1, 1, 0, L.st>>>(L.w, L.opt, d.C);
+  size_t nmax = (size_t)3 * d.P;
+  if ((size_t)4 * d.C > nmax) nmax = (size_t)4 * d.C;
+  if ((size_t)4 * d.NI > nmax) nmax = (size_t)4 * d.NI;
+  commit_kernel<<<div_up((long)nmax, 256), 256, 0, L.st>>>(L.w, L.cam_q, L.cam_t, L.intr, L.pts, d.C, d.NI, d.P);
+  clear_accept_kernel<<<1, 1, 0, L.st>>>(L.w);
+}
+
+static int make_launch(const vgg_ba_problem* pb, const vgg_ba_options* opt, void* workspace, hipStream_t st, Launch* L) {
+  if (!pb || !opt || !workspace) return VGG_ERR_INVALID_ARGUMENT;
+  if (pb->num_cams <= 0 || pb->num_pts < 0 || pb->num_obs < 0) return VGG_ERR_INVALID_ARGUMENT;
+  if (pb->num_intr != 1 && pb->num_intr != pb->num_cams) return VGG_ERR_UNSUPPORTED;
+  if (pb->camera_model != kPinhole && pb->camera_model != kSimpleRadial) return VGG_ERR_UNSUPPORTED;
+  L->d = make_dims(pb);
+  L->dp = dev_problem(pb, L->d);
+  L->w = carve(L->d, opt->max_num_iterations, workspace);
+  L->opt = *opt;
+  L->st = st;
+  L->wgB = min(max(div_up(L->d.P, 4), 1), kMaxWG);
+  L->chunk_desc = pb->chunk_desc; L->entries = pb->entries; L->num_chunks = pb->num_chunks;
+  L->cam_q = pb->cam_q; L->cam_t = pb->cam_t; L->intr = pb->intr; L->pts = pb->pts;
+  return VGG_OK;
+}
+
+template <typename Fn0, typename Fn1, typename Fn2>
+static int dispatch_kd(int kd, Fn0 f0, Fn1 f1, Fn2 f2) {
+  switch (kd) { case 0: return f0(); case 1: return f1(); default: return f2(); }
+}
+
+static int run_phase(const Launch& L, int phase) {
+  switch (phase) {
+    case 0:
+      return dispatch_kd(L.d.kd, [&] { phase_linearize<0>(L); return VGG_OK; }, [&] { phase_linearize<1>(L); return VGG_OK; },
+                         [&] { phase_linearize<2>(L); return VGG_OK; });
+    case 1:
+      return dispatch_kd(L.d.kd, [&] { phase_schur<0>(L); return VGG_OK; }, [&] { phase_schur<1>(L); return VGG_OK; },
+                         [&] { phase_schur<2>(L); return VGG_OK; });
+    case 2:
+      return dispatch_kd(L.d.kd, [&] { return phase_step<0>(L); }, [&] { return phase_step<1>(L); }, [&] { return phase_step<2>(L); });
+    case 3: phase_update(L); return VGG_OK;
+    default: return VGG_ERR_INVALID_ARGUMENT;
+  }
+}
+
+static int finish(const Launch& L, int max_iters, vgg_ba_summary* summary, vgg_ba_iteration* log, int log_cap) {
+  Ctl h;
+  if (hipMemcpyAsync(&h, L.w.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, L.st) != hipSuccess) return VGG_ERR_HIP;
+  int ncopy = 0;
+  if (log && log_cap > 0) {
+    ncopy = (max_iters + 1 < log_cap) ? max_iters + 1 : log_cap;
+    if (hipMemcpyAsync(log, L.w.log, sizeof(vgg_ba_iteration) * ncopy, hipMemcpyDeviceToHost, L.st) != hipSuccess) return VGG_ERR_HIP;
+  }
+  if (hipStreamSynchronize(L.st) != hipSuccess) return VGG_ERR_HIP;
+  if (summary) {
+    summary->initial_cost = h.initial_cost; summary->final_cost = h.x_cost;
+    summary->num_iterations = h.iteration; summary->num_successful_steps = h.num_succ;
+    summary->num_unsuccessful_steps = h.num_unsucc; summary->termination = h.termination;
+    summary->n_reduced = L.d.n_red;
+    summary->num_log = (h.iteration + 1 < ncopy) ? h.iteration + 1 : ncopy;
+  }
+  return VGG_OK;
+}
+
+}  // namespace vgg
+
+using namespace vgg;
+
+extern "C" {
+
+const char* vgg_build_arch(void) { return "gfx950"; }
+int vgg_abi_version(void) { return 1; }
+
+size_t vgg_ba_workspace_bytes(const vgg_ba_problem* problem, const vgg_ba_options* options) {
+  if (!problem || !options) return 0;
+  const Dims d = make_dims(problem);
+  return carve(d, options->max_num_iterations, nullptr).total_bytes + 256;
+}
+
+int vgg_ba_begin(const vgg_ba_problem* problem, const vgg_ba_options* options, void* workspace, size_t workspace_bytes,
+                 int rank, int world_size, void* stream) {
+  Launch L;
+  int rc = make_launch(problem, options, workspace, (hipStream_t)stream, &L);
+  if (rc != VGG_OK) return rc;
+  if (workspace_bytes < L.w.total_bytes) return VGG_ERR_WORKSPACE;
+  init_kernel<<<div_up(L.d.n_red > 0 ? L.d.n_red : 1, 256), 256, 0, L.st>>>(L.dp, L.w, L.opt, rank, world_size);
+  VGG_LAUNCH_CHECK();
+  return VGG_OK;
+}
+
+int vgg_ba_phase(const vgg_ba_problem* problem, const vgg_ba_options* options, void* workspace, int phase, void* stream) {
+  Launch L;
+  int rc = make_launch(problem, options, workspace, (hipStream_t)stream, &L);
+  if (rc != VGG_OK) return rc;
+  rc = run_phase(L, phase);
+  if (rc != VGG_OK) return rc;
+  VGG_LAUNCH_CHECK();
+  return VGG_OK;
+}
+
+int vgg_ba_reduce_buffer(const vgg_ba_problem* problem, const vgg_ba_options* options, void* workspace, int which,
+                         double** device_ptr, size_t* count) {
+  if (!problem || !options || !workspace || !device_ptr || !count) return VGG_ERR_INVALID_ARGUMENT;
+  const Dims d = make_dims(problem);
+  Ws w = carve(d, options->max_num_iterations, workspace);
+  switch (which) {
+    case 0: *device_ptr = w.lin; *count = w.lin_count; break;
+    case 1: *device_ptr = w.sys; *count = w.sys_count; break;
+    case 2: *device_ptr = w.gmax_pts; *count = 1; break;
+    case 3: *device_ptr = w.stepsum; *count = 4; break;
+    default: return VGG_ERR_INVALID_ARGUMENT;
+  }
+  return VGG_OK;
+}
+
+int vgg_ba_finish(const vgg_ba_problem* problem, const vgg_ba_options* options, void* workspace,
+                  vgg_ba_summary* summary, vgg_ba_iteration* log, int log_cap, void* stream) {
+  Launch L;
+  int rc = make_launch(problem, options, workspace, (hipStream_t)stream, &L);
+  if (rc != VGG_OK) return rc;
+  return finish(L, options->max_num_iterations, summary, log, log_cap);
+}
+
+int vgg_ba_solve(const vgg_ba_problem* problem, const vgg_ba_options* options, void* workspace,
+                 size_t workspace_bytes, vgg_ba_summary* summary, vgg_ba_iteration* log, int log_cap, void* stream) {
+  int rc = vgg_ba_begin(problem, options, workspace, workspace_bytes, 0, 1, stream);
+  if (rc != VGG_OK) return rc;
+  Launch L;
+  rc = make_launch(problem, options, workspace, (hipStream_t)stream, &L);
+  if (rc != VGG_OK) return rc;
+  // iteration max_num_iterations+1 only runs the start-of-iteration checks (gradient test after the last step)
+  for (int it = 0; it <= options->max_num_iterations; ++it) {
+    for (int phase = 0; phase < 4; ++phase) {
+      rc = run_phase(L, phase);
+      if (rc != VGG_OK) return rc;
+    }
+  }
+  VGG_LAUNCH_CHECK();
+  return finish(L, options->max_num_iterations, summary, log, log_cap);
+}
+
+}  // extern "C"

@@ -1,0 +1,53 @@
+// Shared device/host helpers for the gfx950 (CDNA4, wave64) kernels of the geometry hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#define VGG_OK 0
+#define VGG_ERR_INVALID_ARGUMENT (-1)
+#define VGG_ERR_HIP (-2)
+#define VGG_ERR_WORKSPACE (-3)
+#define VGG_ERR_UNSUPPORTED (-4)
+
+#define VGG_HIP_CHECK(expr)                                    \
+  do {                                                         \
+    hipError_t e_ = (expr);                                    \
+    if (e_ != hipSuccess) return VGG_ERR_HIP;                  \
+  } while (0)
+
+#define VGG_LAUNCH_CHECK()                                     \
+  do {                                                         \
+    if (hipGetLastError() != hipSuccess) return VGG_ERR_HIP;   \
+  } while (0)
+
+namespace vgg {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// full-wave (64 lanes) butterfly reductions; every lane ends with the total
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_bcast(double v, int src) { return __shfl(v, src, 64); }
+
+template <typename T>
+__device__ __forceinline__ double load_f64(const T* p) { return (double)(*p); }
+
+inline int div_up(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace vgg

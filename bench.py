@@ -1,0 +1,260 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path BASELINE.json names: Levenberg-Marquardt bundle-adjustment iterations/s.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A *step* is ONE LM iteration (linearise -> block-sparse Schur complement -> dense Cholesky of the
+reduced camera system -> back-substitution -> candidate cost -> trust-region decision) over the whole
+synthetic scene.  Workload at N=1 = BASELINE.json configs[2], the configuration the north-star target is
+quoted on: 200 frames x 100k tracks, SIMPLE_RADIAL, shared camera (SURVEY.md section 8d generator).
+N>1: the tracks are sharded by 3D point (every rank holds its own 100k-track shard, cameras
+replicated) and the per-camera blocks / reduced system are all-reduced over RCCL once per iteration;
+`value` counts shard-iterations (N x K) per second, i.e. "weak" scaling.
+Inputs are resident in HBM before the timed region; termination tests are disabled so that exactly K
+iterations run (a solve is restarted from the initial state every EPISODE iterations, like the
+reference's 50/100-iteration BA calls).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from vggsfm_amd import _lib  # noqa: E402
+from vggsfm_amd import ba as BA  # noqa: E402
+from vggsfm_amd.ba_options import BundleAdjustmentOptions  # noqa: E402
+from vggsfm_amd.scene import make_scene, perturb_for_ba  # noqa: E402
+
+EPISODE = 25
+FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector = FP64 matrix peak (datasheet; MI355X_MICROARCH.md has no fp64 row)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md chip table (6.29 TB/s measured copy)
+KERNELS = ["cam_pass<linearize>", "point_pass", "cam_pass<rhs>", "schur_tile", "cholesky", "point_step"]
+
+WORKLOADS = {
+    # name: (frames, tracks per GPU, camera, shared)
+    "c2": (50, 20000, "SIMPLE_PINHOLE", False),
+    "c3": (200, 100000, "SIMPLE_RADIAL", True),
+    "c4shard": (400, 37500, "SIMPLE_RADIAL", False),
+}
+
+
+def D(x, dev):
+    return None if x is None else torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def wrap(ws, addr, count):
+    off = addr - ws.data_ptr()
+    return ws[off:off + 8 * count].view(torch.float64)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    S, N, cam_type, shared = WORKLOADS[args.workload]
+    sc = make_scene(S, N, cam_type, shared_camera=shared, seed=0, track_seed=1000 + rank)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=rank)
+    ext0_c, K0_c, extra0_c, _ = perturb_for_ba(sc, seed=0)          # cameras identical on every rank
+    prob, valid_idx, deleted = BA.compile_problem(D(pts0, dev), D(ext0_c, dev), D(K0_c, dev), D(sc.tracks, dev),
+                                                  D(sc.mask, dev), D(extra0_c, dev), shared, cam_type)
+    init = [t.clone() for t in (prob.cam_q, prob.cam_t, prob.intr, prob.pts)]
+    L = _lib.lib()
+    opts = BundleAdjustmentOptions()
+    so = opts.solver_options
+    so.max_num_iterations = EPISODE
+    so.function_tolerance = so.gradient_tolerance = so.parameter_tolerance = -1.0   # run exactly K iterations
+    cp = prob.c_struct()
+    co = BA._c_options(opts)
+    nbytes = int(L.vgg_ba_workspace_bytes(ctypes.byref(cp), ctypes.byref(co)))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    st = _lib.stream_ptr()
+    bufs = []
+    for which in range(4):
+        p = ctypes.POINTER(ctypes.c_double)()
+        cnt = ctypes.c_size_t()
+        _lib.check(L.vgg_ba_reduce_buffer(ctypes.byref(cp), ctypes.byref(co), _lib.ptr(ws), which, ctypes.byref(p),
+                                          ctypes.byref(cnt)), "vgg_ba_reduce_buffer")
+        bufs.append(wrap(ws, ctypes.addressof(p.contents), cnt.value))
+
+    def begin():
+        for dst, src in zip((prob.cam_q, prob.cam_t, prob.intr, prob.pts), init):
+            dst.copy_(src)
+        _lib.check(L.vgg_ba_begin(ctypes.byref(cp), ctypes.byref(co), _lib.ptr(ws), ctypes.c_size_t(nbytes), rank, world,
+                                  st), "vgg_ba_begin")
+
+    def phase(i):
+        _lib.check(L.vgg_ba_phase(ctypes.byref(cp), ctypes.byref(co), _lib.ptr(ws), i, st), "vgg_ba_phase")
+
+    def iteration():
+        phase(0)
+        if dist:
+            dist.all_reduce(bufs[0])
+        phase(1)
+        if dist:
+            dist.all_reduce(bufs[1])
+            dist.all_reduce(bufs[2], op=dist.ReduceOp.MAX)
+        phase(2)
+        if dist:
+            dist.all_reduce(bufs[3])
+        phase(3)
+
+    def run(n, counter):
+        for _ in range(n):
+            if counter[0] % EPISODE == 0:
+                begin()
+            iteration()
+            counter[0] += 1
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    counter = [0]
+    run(args.warmup, counter)
+    barrier()
+    _lib.check(L.vgg_ba_profile(1, args.steps + 4), "vgg_ba_profile")
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps, counter)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # the last episode must have run all its iterations (no early termination => no skipped work)
+    summ = _lib.BASummary()
+    _lib.check(L.vgg_ba_finish(ctypes.byref(cp), ctypes.byref(co), _lib.ptr(ws), ctypes.byref(summ), None, 0, st),
+               "vgg_ba_finish")
+    expect = counter[0] % EPISODE or EPISODE
+    if summ.num_iterations != expect:
+        raise SystemExit(f"LM terminated early: {summ.num_iterations} of {expect} iterations (termination "
+                         f"{summ.termination}) -- timing invalid")
+
+    # ---- per-kernel HIP-event timings of the timed region (rank-local)
+    prof = {}
+    for kid, name in enumerate(KERNELS):
+        tot = ctypes.c_double()
+        n = ctypes.c_int()
+        _lib.check(L.vgg_ba_profile_read(kid, ctypes.byref(tot), ctypes.byref(n), 1), "vgg_ba_profile_read")
+        prof[name] = (tot.value, n.value)
+    L.vgg_ba_profile(0, 0)
+
+    if rank == 0:
+        counts = (prob.row_ptr[1:] - prob.row_ptr[:-1]).double()
+        n_obs = int(prob.num_obs)
+        P = int(prob.pts.shape[0])
+        n_red = int(summ.n_reduced)
+        bd = 6 if shared else 6 + (2 if cam_type == "SIMPLE_RADIAL" else 1)     # Schur block width
+        pair_blocks = float((counts * (counts + 1) / 2).sum().item())
+        # algorithmic work per launch (DESIGN.md "Kernels"): flops for the fp64-compute-bound kernels,
+        # bytes for the streaming kernels
+        work = {
+            "schur_tile": ("mfma", 2.0 * 3 * bd * bd * pair_blocks),
+            "cholesky": ("mfma", n_red ** 3 / 3.0 + 2.0 * n_red ** 2),
+            "point_pass": ("hbm", 12.0 * n_obs + P * (24 + 4 + 8 * (6 + 3 + 6))),
+            "point_step": ("hbm", 12.0 * n_obs + P * (24 + 4 + 8 * (6 + 3) + 24)),
+            "cam_pass<linearize>": ("hbm", 12.0 * n_obs + 24.0 * n_obs),
+            "cam_pass<rhs>": ("hbm", 12.0 * n_obs + (24.0 + 24 + 48) * n_obs),
+        }
+        # the roofline object describes the dominant SINGLE kernel; "cholesky" is a group of ~75 small
+        # launches (panel / update / solve) and is reported in kernel_ms only
+        dom = max((k for k in prof if k != "cholesky"), key=lambda k: prof[k][0])
+        tot_ms, launches = prof[dom]
+        avg_ms = tot_ms / max(launches, 1)
+        bound, amount = work[dom]
+        if bound == "mfma":
+            achieved = amount / (avg_ms * 1e-3) / 1e12
+            roof = dict(bound="mfma", achieved=achieved, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=achieved / FP64_PEAK_TFLOPS, traffic=None)
+        else:
+            achieved = amount / (avg_ms * 1e-3) / 1e9
+            roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                        traffic=None)
+        roof.update(kernel=dom, avg_launch_ms=avg_ms, launches=launches, algorithmic_per_launch=amount,
+                    note="fp64: the kernel runs on the FP64 VALU, whose peak equals the FP64 MFMA peak on MI355X"
+                    if dom == "schur_tile" else "")
+        kernel_ms = {k: (v[0] / max(v[1], 1)) for k, v in prof.items()}
+
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import ba as OB          # checker timed as the CPU baseline ("port"), never on the GPU path
+            vi, row_ptr, obs_cam, obs_uv, dele = OB.build_observations(pts0, ext0_c, sc.tracks, sc.mask)
+            cq = np.ascontiguousarray(OB.rotmat_to_quat(ext0_c[:, :, :3]))
+            ct = np.ascontiguousarray(ext0_c[:, :, 3])
+            ni = 1 if shared else S
+            intr = np.zeros((ni, 4))
+            src = slice(0, 1) if shared else slice(None)
+            intr[:, 0], intr[:, 1], intr[:, 2] = K0_c[src, 0, 0], K0_c[src, 0, 2], K0_c[src, 1, 2]
+            if extra0_c is not None:
+                intr[:, 3] = extra0_c[src, 0]
+            cam_intr = np.zeros(S, np.int32) if shared else np.arange(S, dtype=np.int32)
+            cam_const = np.zeros(S, np.uint8)
+            cam_const[0], cam_const[1] = 1, 2
+            o = OB.ceres_options(args.cpu_iters, -1.0, -1.0, -1.0)
+            pts_c = np.ascontiguousarray(pts0[vi])
+            tc = time.perf_counter()
+            s_cpu = OB.solve_csr(cq, ct, intr, pts_c, cam_intr, row_ptr, obs_cam, obs_uv, OB.MODEL[cam_type], o,
+                                 cam_const=cam_const)
+            tcpu = time.perf_counter() - tc
+            cpu = dict(value=s_cpu["num_iterations"] / tcpu, unit="LM-iterations/s", cores=int(OB.lib().bao_num_threads()),
+                       kind="port", sample=f"full {S}x{N} workload, {s_cpu['num_iterations']} LM iterations "
+                       f"(oracle/ba_oracle.c, OpenMP, includes the initial evaluation), {tcpu:.1f} s")
+        out = {
+            "metric": "BA LM-iterations/sec",
+            "value": args.steps * world / dt,
+            "unit": "LM-iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"synthetic {S} frames x {N} tracks per GPU, {cam_type}"
+                                   f"{' shared_camera' if shared else ''}, full LM (BASELINE configs[2] at N=1)",
+                       "frames": S, "tracks_per_gpu": N, "observations_per_gpu": n_obs, "reduced_system": n_red,
+                       "parallelism": f"points sharded x{world}, cameras replicated, RCCL all-reduce of the reduced system",
+                       "episode_iterations": EPISODE,
+                       "successful_steps_last_episode": int(summ.num_successful_steps),
+                       "kernel_ms": kernel_ms},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -64,7 +64,7 @@ int vgg_cam_from_img(const void* tracks, int tracks_are_f64, const double* intri
  * view pairs (the caller reproduces the reference's host-side torch.randperm draw, :804-813).
  * invalid_vis_conf (S,N) uint8 = (vis <= 0.05) | (score <= 0.5)  (:867-874).
  * Pass 1 writes per-hypothesis (inlier_num, mean inlier error) into workspace and the chunk-global
- * max of the mean errors; vgg_triangulate_select then applies calculate_residual_indicator
+ * max of the mean errors; pass 2 then applies calculate_residual_indicator
  * (vggsfm/two_view_geo/utils.py:63-87) with that chunk-global threshold and gathers the winner.
  * Outputs: points (N,3) f64, inlier_num (N) int64, inlier_mask (N,S) uint8. */
 size_t vgg_triangulate_workspace_bytes(int S, int N, int H, int lo_num);
@@ -108,7 +108,14 @@ typedef struct {
   /* Schur tile work list (device) */
   int32_t num_chunks;
   const int32_t* chunk_desc;  /* [num_chunks,4] = groupI, groupJ, entry_begin, entry_end */
-  const int32_t* entries;     /* [num_entries,4] = point, obs_begin_A, obs_begin_B, cntA | cntB<<8 */
+  const int32_t* entries;     /* [num_entries,4] = point, segment_A, segment_B, maskA | maskB<<16
+                                 (bit l of a mask: camera group*16+l observes the point) */
+  int32_t num_segments;       /* segments: runs of one point's observations inside one camera group */
+  const int32_t* obs_slot;    /* [num_obs] = segment*16 + (camera % 16): where the point-major observation's
+                                 Schur factor lives in the zero-padded segment buffer */
+  int32_t num_tiles;
+  const int32_t* tile_desc;   /* [num_tiles,4] = groupI, groupJ, chunk_begin, chunk_end (chunks of one tile
+                                 are consecutive; their partial sums are reduced in this order) */
 } vgg_ba_problem;
 
 typedef struct {
@@ -160,10 +167,19 @@ int vgg_ba_reduce_buffer(const vgg_ba_problem* problem, const vgg_ba_options* op
 int vgg_ba_finish(const vgg_ba_problem* problem, const vgg_ba_options* options, void* workspace,
                   vgg_ba_summary* summary, vgg_ba_iteration* log, int log_cap, void* stream);
 
+/* Optional per-kernel timing (HIP events recorded on the launch stream around the dominant kernels).
+ * kernel_id: 0 cam_pass<linearize> 1 point_pass 2 cam_pass<rhs> 3 schur_tile 4 cholesky (all launches of one
+ * solve) 5 point_step.  vgg_ba_profile_read synchronises on the recorded events. */
+int vgg_ba_profile(int enable, int max_launches_per_kernel);
+int vgg_ba_profile_read(int kernel_id, double* total_ms, int* launches, int reset);
+
 /* Dense symmetric positive-definite solve of the reduced camera system (exposed for tests):
- * A (n,n) row-major lower triangle is overwritten by its Cholesky factor, b by the solution.
+ * A (n,n) row-major lower triangle is overwritten by its Cholesky factor, b by the solution
+ * (if b == A + n*n the forward substitution is fused into the factorisation).
+ * workspace: vgg_cholesky_workspace_bytes(n) device bytes (inverse diagonal blocks).
  * *device_fail (int32, device) is set non-zero on a non-positive pivot. */
-int vgg_cholesky_solve(double* A, double* b, int n, int32_t* device_fail, void* stream);
+size_t vgg_cholesky_workspace_bytes(int n);
+int vgg_cholesky_solve(double* A, double* b, int n, void* workspace, int32_t* device_fail, void* stream);
 
 #ifdef __cplusplus
 }

@@ -277,20 +277,30 @@ static void mask_jac(const ctx_t* c, int cam, int p, double* Jp, double* Ji, dou
 static void grad_and_colnorm(const ctx_t* c, const double* cq, const double* ct, const double* intr,
                              const double* pts, double* grad, double* colsq) {
   const bao_problem_t* pb = c->pb;
+  const int nr = c->n_red;
   memset(grad, 0, sizeof(double) * c->n_cols);
   memset(colsq, 0, sizeof(double) * c->n_cols);
-  for (int p = 0; p < pb->num_pts; ++p)
-    for (int o = pb->row_ptr[p]; o < pb->row_ptr[p + 1]; ++o) {
-      const int cam = pb->obs_cam[o];
-      double r[2], Jp[12], Ji[4], Jx[6];
-      eval_corrected(c, cq, ct, intr, pts, p, o, r, Jp, Ji, Jx);
-      mask_jac(c, cam, p, Jp, Ji, Jx);
-      for (int k = 0; k < 6; ++k) { grad[6 * cam + k] += Jp[k] * r[0] + Jp[6 + k] * r[1]; colsq[6 * cam + k] += Jp[k] * Jp[k] + Jp[6 + k] * Jp[6 + k]; }
-      const int ic = intr_col(c, pb->cam_intr[cam]);
-      for (int k = 0; k < c->kd; ++k) { grad[ic + k] += Ji[k] * r[0] + Ji[c->kd + k] * r[1]; colsq[ic + k] += Ji[k] * Ji[k] + Ji[c->kd + k] * Ji[c->kd + k]; }
-      const int pc = pt_col(c, p);
-      for (int k = 0; k < 3; ++k) { grad[pc + k] += Jx[k] * r[0] + Jx[3 + k] * r[1]; colsq[pc + k] += Jx[k] * Jx[k] + Jx[3 + k] * Jx[3 + k]; }
-    }
+#pragma omp parallel
+  {
+    double* lg = (double*)calloc(2 * (size_t)nr, sizeof(double));   /* camera-side partials of this thread */
+    double* lc = lg + nr;
+#pragma omp for schedule(static)
+    for (int p = 0; p < pb->num_pts; ++p)
+      for (int o = pb->row_ptr[p]; o < pb->row_ptr[p + 1]; ++o) {
+        const int cam = pb->obs_cam[o];
+        double r[2], Jp[12], Ji[4], Jx[6];
+        eval_corrected(c, cq, ct, intr, pts, p, o, r, Jp, Ji, Jx);
+        mask_jac(c, cam, p, Jp, Ji, Jx);
+        for (int k = 0; k < 6; ++k) { lg[6 * cam + k] += Jp[k] * r[0] + Jp[6 + k] * r[1]; lc[6 * cam + k] += Jp[k] * Jp[k] + Jp[6 + k] * Jp[6 + k]; }
+        const int ic = intr_col(c, pb->cam_intr[cam]);
+        for (int k = 0; k < c->kd; ++k) { lg[ic + k] += Ji[k] * r[0] + Ji[c->kd + k] * r[1]; lc[ic + k] += Ji[k] * Ji[k] + Ji[c->kd + k] * Ji[c->kd + k]; }
+        const int pc = pt_col(c, p);
+        for (int k = 0; k < 3; ++k) { grad[pc + k] += Jx[k] * r[0] + Jx[3 + k] * r[1]; colsq[pc + k] += Jx[k] * Jx[k] + Jx[3 + k] * Jx[3 + k]; }
+      }
+#pragma omp critical
+    for (int i = 0; i < nr; ++i) { grad[i] += lg[i]; colsq[i] += lc[i]; }
+    free(lg);
+  }
 }
 
 /* x (+) delta for the whole state */
@@ -323,6 +333,12 @@ static double ambient_diff_norm(const ctx_t* c, const double* q0, const double* 
   if (maxabs) *maxabs = m;
   return sqrt(s);
 }
+
+/* test hook: when set, the first reduced system (after damping / constant-column handling, before the
+ * factorisation) is copied out: lhs n*n row-major (full symmetric), rhs n */
+static double* g_dump_lhs = NULL;
+static double* g_dump_rhs = NULL;
+void bao_debug_dump_system(double* lhs, double* rhs) { g_dump_lhs = lhs; g_dump_rhs = rhs; }
 
 /* Build and solve the damped normal equations by Schur elimination; y solves
  * (Js^T Js + D^2) y = Js^T r with Js = J diag(scale).  Also returns
@@ -425,6 +441,7 @@ static int schur_solve(const ctx_t* c, const double* cq, const double* ct, const
       if (c->active[i]) lhs[(size_t)i * n + i] += D[i] * D[i];
       else { for (int j = 0; j < n; ++j) { lhs[(size_t)i * n + j] = 0; lhs[(size_t)j * n + i] = 0; } lhs[(size_t)i * n + i] = 1.0; rhs[i] = 0; }
     }
+    if (g_dump_lhs) { memcpy(g_dump_lhs, lhs, sizeof(double) * (size_t)n * n); memcpy(g_dump_rhs, rhs, sizeof(double) * n); g_dump_lhs = NULL; g_dump_rhs = NULL; }
     memcpy(y, rhs, sizeof(double) * n);
     fail = dense_chol_solve(lhs, y, n);
   }

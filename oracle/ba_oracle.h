@@ -59,6 +59,8 @@ int bao_num_threads(void);
 void bao_obs_eval(int model, const double* q, const double* t, const double* intr, const double* X, double u, double v,
                   double* r, double* Jp, double* Ji, double* Jx);
 void bao_quat_plus(const double* x, const double* d, double* out);
+/* test hook: copy the first reduced camera system (lhs n*n full, rhs n) of the next bao_solve call */
+void bao_debug_dump_system(double* lhs, double* rhs);
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,48 @@
+// standalone timing harness for csrc/chol.hip (not product code)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+#include "../../vggsfm_amd/csrc/chol.hip"
+int main(int argc, char** argv) {
+  const int n = argc > 1 ? atoi(argv[1]) : 1202;
+  const int reps = 20;
+  std::vector<double> A((size_t)n * n + n), M((size_t)n * 8);
+  srand(1);
+  // SPD: banded-ish random + diagonal dominance
+  for (size_t i = 0; i < A.size(); ++i) A[i] = 0;
+  for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) { double v = (rand() / (double)RAND_MAX - 0.5) * 0.01; A[(size_t)i * n + j] = v; }
+  for (int i = 0; i < n; ++i) A[(size_t)i * n + i] = 1.0 + n * 0.01;
+  for (int i = 0; i < n; ++i) A[(size_t)n * n + i] = rand() / (double)RAND_MAX;
+  double *dA, *d0, *ws; int* fail;
+  hipMalloc(&dA, A.size() * 8); hipMalloc(&d0, A.size() * 8); hipMalloc(&ws, 1 << 20); hipMalloc(&fail, 4);
+  hipMemcpy(d0, A.data(), A.size() * 8, hipMemcpyHostToDevice);
+  hipMemset(fail, 0, 4);
+  hipStream_t st; hipStreamCreate(&st);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int mode = 0; mode < 2; ++mode) {
+    float tot = 0;
+    for (int r = 0; r < reps + 2; ++r) {
+      hipMemcpyAsync(dA, d0, A.size() * 8, hipMemcpyDeviceToDevice, st);
+      if (mode == 1) {  // keep the GPU busy before: a big memset pair
+        for (int k = 0; k < 4; ++k) hipMemsetAsync(ws, 0, 1 << 20, st);
+      }
+      hipEventRecord(e0, st);
+      vgg::cholesky_solve_enqueue(dA, dA + (size_t)n * n, n, ws, fail, nullptr, st);
+      hipEventRecord(e1, st);
+      hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      if (r >= 2) tot += ms;
+    }
+    int hf; hipMemcpy(&hf, fail, 4, hipMemcpyDeviceToHost);
+    printf("n=%d mode=%d: %.3f ms per solve (fail=%d)\n", n, mode, tot / reps, hf);
+  }
+  // residual check
+  std::vector<double> x(n);
+  hipMemcpy(x.data(), dA + (size_t)n * n, n * 8, hipMemcpyDeviceToHost);
+  double maxr = 0;
+  for (int i = 0; i < n; ++i) { double s = 0; for (int j = 0; j < n; ++j) s += (j <= i ? A[(size_t)i * n + j] : A[(size_t)j * n + i]) * x[j]; maxr = fmax(maxr, fabs(s - A[(size_t)n * n + i])); }
+  printf("max residual %.3e\n", maxr);
+  return 0;
+}

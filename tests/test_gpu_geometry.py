@@ -87,7 +87,9 @@ def test_filter_empty_and_property_at_scale():
 
 
 def test_undistortion_roundtrip_property():
-    # cam_from_img(radial) followed by re-distortion reproduces (u,v) to the Newton tolerance
+    # cam_from_img(radial) followed by re-distortion reproduces (u,v) to the tolerance the REFERENCE
+    # reaches: its Newton matrix carries an extra identity (distortion.py:66-90), so the iteration
+    # converges linearly and stops at a step of 1e-5 (max_step_norm 1e-10 on the squared step)
     sc = make_scene(20, 5000, "SIMPLE_RADIAL", shared_camera=True, seed=5)
     K, extra = D(sc.intrinsics), D(sc.extra_params)
     tn = H.cam_from_img(D(sc.tracks), K, extra)
@@ -96,6 +98,6 @@ def test_undistortion_roundtrip_property():
     k = extra[:, 0][:, None]
     ud, vd = u * (1 + k * r2), v * (1 + k * r2)
     ref = (D(sc.tracks).double() - 512.0) / K[:, 0, 0][:, None, None]
-    assert float((torch.stack([ud, vd], -1) - ref).abs().max()) < 1e-9
+    assert float((torch.stack([ud, vd], -1) - ref).abs().max()) < 2e-5
     tn_o = G.cam_from_img(sc.tracks.astype(np.float64), sc.intrinsics, sc.extra_params)
     np.testing.assert_allclose(tn.cpu().numpy(), tn_o, rtol=1e-12, atol=1e-14)

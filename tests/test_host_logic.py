@@ -89,6 +89,11 @@ def test_compile_problem_matches_oracle_construction(S, N):
     assert cm == pm
     # Schur work list covers every co-observing camera pair of every point exactly once
     desc, ent = prob.chunk_desc.numpy(), prob.entries.numpy()
+    slot = prob.obs_slot.numpy()
+    assert len(np.unique(slot)) == len(slot) and slot.max() < prob.num_segments * BA.GROUP
+    assert (slot % BA.GROUP == obs_cam % BA.GROUP).all()
+    seg_of = slot // BA.GROUP
+    seg_first = {int(sg): int(np.nonzero(seg_of == sg)[0][0]) for sg in np.unique(seg_of)}
     covered = {}
     seen_entries = np.zeros(len(ent), bool)
     for gI, gJ, b, e in desc:
@@ -96,10 +101,13 @@ def test_compile_problem_matches_oracle_construction(S, N):
         for k in range(b, e):
             assert not seen_entries[k]
             seen_entries[k] = True
-            p, oa, ob, cnt = ent[k]
-            ca, cb = cnt & 0xff, (cnt >> 8) & 0xff
+            p, sa, sb, msk = ent[k]
+            mA, mB = int(msk) & 0xffff, (int(msk) >> 16) & 0xffff
+            ca, cb = bin(mA).count("1"), bin(mB).count("1")
+            oa, ob = seg_first[sa], seg_first[sb]
             A = obs_cam[oa:oa + ca]
             B = obs_cam[ob:ob + cb]
+            assert mA == sum(1 << (int(c) % BA.GROUP) for c in A) and mB == sum(1 << (int(c) % BA.GROUP) for c in B)
             assert (A // BA.GROUP == gI).all() and (B // BA.GROUP == gJ).all()
             assert row_ptr[p] <= oa and oa + ca <= row_ptr[p + 1] and row_ptr[p] <= ob and ob + cb <= row_ptr[p + 1]
             for a in A:
@@ -108,6 +116,12 @@ def test_compile_problem_matches_oracle_construction(S, N):
                         continue
                     covered[(p, int(a), int(bb))] = covered.get((p, int(a), int(bb)), 0) + 1
     assert seen_entries.all()
+    # tiles: consecutive chunk ranges that cover all chunks exactly once, one tile per (gI, gJ)
+    td = prob.tile_desc.numpy()
+    assert td[0, 2] == 0 and td[-1, 3] == len(desc) and (td[1:, 2] == td[:-1, 3]).all()
+    assert len({(int(a), int(b)) for a, b, _, _ in td}) == len(td)
+    for gI, gJ, c0, c1 in td:
+        assert (desc[c0:c1, 0] == gI).all() and (desc[c0:c1, 1] == gJ).all()
     expect = set()
     for p in range(len(vi)):
         cams = obs_cam[row_ptr[p]:row_ptr[p + 1]]

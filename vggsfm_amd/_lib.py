@@ -26,7 +26,8 @@ class BAProblem(ctypes.Structure):
                 ("obs_uv", ctypes.c_void_p), ("col_ptr", ctypes.c_void_p), ("cobs_pt", ctypes.c_void_p),
                 ("cobs_uv", ctypes.c_void_p), ("cam_const", ctypes.c_void_p), ("intr_const", ctypes.c_void_p),
                 ("pt_const", ctypes.c_void_p), ("num_chunks", ctypes.c_int32), ("chunk_desc", ctypes.c_void_p),
-                ("entries", ctypes.c_void_p)]
+                ("entries", ctypes.c_void_p), ("num_segments", ctypes.c_int32), ("obs_slot", ctypes.c_void_p),
+                ("num_tiles", ctypes.c_int32), ("tile_desc", ctypes.c_void_p)]
 
 
 class BAOptions(ctypes.Structure):
@@ -55,7 +56,8 @@ class BASummary(ctypes.Structure):
 EXPORTED = ["vgg_build_arch", "vgg_abi_version", "vgg_project_points", "vgg_filter_points_workspace_bytes",
             "vgg_filter_points", "vgg_cam_from_img_workspace_bytes", "vgg_cam_from_img",
             "vgg_triangulate_workspace_bytes", "vgg_triangulate_tracks", "vgg_ba_workspace_bytes", "vgg_ba_solve",
-            "vgg_ba_begin", "vgg_ba_phase", "vgg_ba_reduce_buffer", "vgg_ba_finish", "vgg_cholesky_solve"]
+            "vgg_ba_begin", "vgg_ba_phase", "vgg_ba_reduce_buffer", "vgg_ba_finish", "vgg_cholesky_solve",
+            "vgg_ba_profile", "vgg_ba_profile_read", "vgg_cholesky_workspace_bytes"]
 
 _lib = None
 
@@ -76,7 +78,7 @@ def lib():
     if arch != "gfx950":
         raise RuntimeError(f"libvggsfm_amd.so was built for {arch}, expected gfx950")
     for name in ("vgg_filter_points_workspace_bytes", "vgg_cam_from_img_workspace_bytes",
-                 "vgg_triangulate_workspace_bytes", "vgg_ba_workspace_bytes"):
+                 "vgg_triangulate_workspace_bytes", "vgg_ba_workspace_bytes", "vgg_cholesky_workspace_bytes"):
         getattr(L, name).restype = ctypes.c_size_t
     L.vgg_ba_workspace_bytes.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     _lib = L

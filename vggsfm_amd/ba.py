@@ -24,7 +24,7 @@ from .ba_options import LOSS_ID, TERMINATION, BundleAdjustmentOptions
 
 MODEL_ID = {"SIMPLE_PINHOLE": 0, "SIMPLE_RADIAL": 1}
 GROUP = 16          # cameras per Schur tile side (must match kGroup in csrc/ba.hip)
-CHUNK = 256         # tile entries per workgroup
+CHUNK = 1024        # tile entries per workgroup
 
 
 # ------------------------------------------------------------------ rotations (Eigen conventions)
@@ -82,6 +82,9 @@ class DeviceProblem:
     cobs_uv: torch.Tensor
     chunk_desc: torch.Tensor
     entries: torch.Tensor
+    tile_desc: torch.Tensor
+    obs_slot: torch.Tensor
+    num_segments: int
     camera_model: int
     cam_const: Optional[torch.Tensor] = None
     intr_const: Optional[torch.Tensor] = None
@@ -102,10 +105,12 @@ class DeviceProblem:
         P.camera_model, P.refine_focal, P.refine_extra = self.camera_model, int(self.refine_focal), int(self.refine_extra)
         P.loss, P.loss_scale = self.loss, self.loss_scale
         for name in ("cam_q", "cam_t", "intr", "pts", "row_ptr", "obs_cam", "obs_uv", "col_ptr", "cobs_pt", "cobs_uv",
-                     "cam_const", "intr_const", "pt_const", "chunk_desc", "entries"):
+                     "cam_const", "intr_const", "pt_const", "chunk_desc", "entries", "tile_desc", "obs_slot"):
             t = getattr(self, name)
             setattr(P, name, None if t is None else t.data_ptr())
         P.num_chunks = self.chunk_desc.shape[0]
+        P.num_tiles = self.tile_desc.shape[0]
+        P.num_segments = self.num_segments
         return P
 
 
@@ -115,13 +120,15 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK):
     A *segment* is the run of one point's observations that falls into one group of `group`
     consecutive cameras; an *entry* pairs two segments (gI <= gJ) of the same point; entries are
     sorted by tile (gI, gJ) and cut into chunks of <= `chunk` entries, one workgroup each.
-    Returns (chunk_desc (n,4) int32 = gI,gJ,begin,end ; entries (E,4) int32 = point,obsA,obsB,cntA|cntB<<8)."""
+    Returns (chunk_desc (n,4) int32 = gI,gJ,begin,end ; entries (E,4) int32 = point,segA,segB,maskA|maskB<<16 ;
+    tile_desc (T,4) int32 = gI,gJ,chunk_begin,chunk_end ; obs_slot (O,) int32 = segment*16 + camera%16 ;
+    number of segments)."""
     dev = obs_cam.device
     O = obs_cam.shape[0]
     P = row_ptr.shape[0] - 1
     if O == 0:
         z = torch.zeros((0, 4), dtype=torch.int32, device=dev)
-        return z, z.clone()
+        return z, z.clone(), z.clone(), torch.zeros(0, dtype=torch.int32, device=dev), 0
     counts = (row_ptr[1:] - row_ptr[:-1]).long()
     obs_pt = torch.repeat_interleave(torch.arange(P, device=dev), counts)
     grp = (obs_cam // group).long()
@@ -129,7 +136,9 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK):
     is_start[1:] = (obs_pt[1:] != obs_pt[:-1]) | (grp[1:] != grp[:-1])
     seg_begin = torch.nonzero(is_start).squeeze(1)
     nseg = seg_begin.shape[0]
-    seg_cnt = torch.diff(seg_begin, append=torch.tensor([O], device=dev))
+    seg_id = torch.cumsum(is_start.long(), 0) - 1
+    # presence mask of the segment: bit l <=> camera group*16 + l observes the point
+    seg_mask = torch.zeros(nseg, dtype=torch.long, device=dev).index_add_(0, seg_id, 1 << (obs_cam.long() % group))
     seg_pt = obs_pt[seg_begin]
     seg_grp = grp[seg_begin]
     ngroups = int((obs_cam.max().item() // group) + 1)
@@ -144,7 +153,7 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK):
     key = seg_grp[A] * ngroups + seg_grp[B]
     order = torch.argsort(key, stable=True)
     A, B, key = A[order], B[order], key[order]
-    entries = torch.stack([seg_pt[A], seg_begin[A], seg_begin[B], seg_cnt[A] | (seg_cnt[B] << 8)], 1).to(torch.int32)
+    entries = torch.stack([seg_pt[A], A, B, seg_mask[A] | (seg_mask[B] << 16)], 1).to(torch.int32)
     ukeys, kcounts = torch.unique_consecutive(key, return_counts=True)
     tile_start = torch.cumsum(kcounts, 0) - kcounts
     nchunks = (kcounts + chunk - 1) // chunk
@@ -154,7 +163,9 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK):
     begin = tile_start[ctile] + local * chunk
     end = torch.minimum(begin + chunk, tile_start[ctile] + kcounts[ctile])
     chunk_desc = torch.stack([ukeys[ctile] // ngroups, ukeys[ctile] % ngroups, begin, end], 1).to(torch.int32)
-    return chunk_desc.contiguous(), entries.contiguous()
+    tile_desc = torch.stack([ukeys // ngroups, ukeys % ngroups, cfirst, cfirst + nchunks], 1).to(torch.int32)
+    obs_slot = (seg_id * group + obs_cam.long() % group).to(torch.int32)
+    return chunk_desc.contiguous(), entries.contiguous(), tile_desc.contiguous(), obs_slot.contiguous(), int(nseg)
 
 
 def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_params=None, shared_camera=False,
@@ -213,9 +224,9 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
         cam_const[0] = 1                            # SetConstantCamPose(first registered image)
         if S > 1:
             cam_const[1] = 2                        # SetConstantCamPositions(second image, {0})
-    chunk_desc, entries = build_schur_tiles(row_ptr, obs_cam)
+    chunk_desc, entries, tile_desc, obs_slot, nseg = build_schur_tiles(row_ptr, obs_cam)
     prob = DeviceProblem(cam_q, cam_t, intr, pts, row_ptr, obs_cam, obs_uv, col_ptr, cobs_pt, cobs_uv, chunk_desc,
-                         entries, MODEL_ID[camera_type], cam_const=cam_const)
+                         entries, tile_desc, obs_slot, nseg, MODEL_ID[camera_type], cam_const=cam_const)
     return prob, valid_idx, deleted
 
 

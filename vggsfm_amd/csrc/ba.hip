@@ -29,10 +29,11 @@
 
 namespace vgg {
 
-int cholesky_solve_enqueue(double* A, double* b, int n, int32_t* device_fail, const int32_t* skip_flag, hipStream_t st);
+int cholesky_solve_enqueue(double* A, double* b, int n, double* inv_blocks, int32_t* device_fail, const int32_t* skip_flag,
+                           hipStream_t st);
+size_t cholesky_workspace_bytes(int n);
 
 constexpr int kGroup = 16;       // cameras per Schur tile side
-constexpr int kBatch = 8;        // tile entries staged per barrier
 constexpr int kMaxWG = 2048;
 
 struct Ctl {
@@ -63,6 +64,10 @@ struct Ws {  // device workspace carve-up (pointers into the caller's buffer)
   double* part_B;             // [kMaxWG] per-workgroup gradient max
   double* part_F;             // [kMaxWG][4]
   double* cam_part;           // [C+1][2] step^2 / x^2 of camera-side parameters
+  double* Y;                  // [num_segments][16][BDt*3] zero-padded per-observation Schur factors s_c o (F^T E G_p)
+  size_t y_bytes;
+  double* chol_inv;           // inverse diagonal blocks of the Cholesky factor
+  double* tile_part;          // [num_chunks][R][R] partial Schur tiles, R = 16*BDt
   size_t lin_count, sys_count, total_bytes;
 };
 
@@ -82,7 +87,7 @@ static Dims make_dims(const vgg_ba_problem* pb) {
   return d;
 }
 
-static Ws carve(const Dims& d, int max_iters, void* base) {
+static Ws carve(const Dims& d, int max_iters, int num_chunks, int num_segments, void* base) {
   Ws w;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return (char*)base + o; };
@@ -108,6 +113,13 @@ static Ws carve(const Dims& d, int max_iters, void* base) {
   w.part_B = (double*)take(8ull * kMaxWG);
   w.part_F = (double*)take(8ull * kMaxWG * 4);
   w.cam_part = (double*)take(8ull * (d.C + 1) * 2);
+  w.y_bytes = 8ull * (size_t)(num_segments > 0 ? num_segments : 1) * kGroup * (d.shared ? 6 : d.BDp) * 3;
+  w.Y = (double*)take(w.y_bytes);
+  w.chol_inv = (double*)take(cholesky_workspace_bytes(d.n_red));
+  {
+    const size_t bdt = d.shared ? 6 : d.BDp;
+    w.tile_part = (double*)take(8ull * (size_t)(num_chunks > 0 ? num_chunks : 1) * bdt * bdt * 256);   // R*R, R = 16*bdt
+  }
   w.total_bytes = off;
   return w;
 }
@@ -115,7 +127,7 @@ static Ws carve(const Dims& d, int max_iters, void* base) {
 struct DevProblem {  // by-value kernel argument
   Dims d;
   const double *cam_q, *cam_t, *intr, *pts;
-  const int32_t *row_ptr, *obs_cam, *col_ptr, *cobs_pt;
+  const int32_t *row_ptr, *obs_cam, *col_ptr, *cobs_pt, *obs_slot;
   const float2 *obs_uv, *cobs_uv;
   const uint8_t *cam_const, *intr_const, *pt_const;
 };
@@ -124,6 +136,7 @@ static DevProblem dev_problem(const vgg_ba_problem* pb, const Dims& d) {
   DevProblem p;
   p.d = d; p.cam_q = pb->cam_q; p.cam_t = pb->cam_t; p.intr = pb->intr; p.pts = pb->pts;
   p.row_ptr = pb->row_ptr; p.obs_cam = pb->obs_cam; p.col_ptr = pb->col_ptr; p.cobs_pt = pb->cobs_pt;
+  p.obs_slot = pb->obs_slot;
   p.obs_uv = (const float2*)pb->obs_uv; p.cobs_uv = (const float2*)pb->cobs_uv;
   p.cam_const = pb->cam_const; p.intr_const = pb->intr_const; p.pt_const = pb->pt_const;
   return p;
@@ -336,16 +349,19 @@ __global__ __launch_bounds__(256) void prep_kernel(DevProblem pb, Ws w, vgg_ba_o
   for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]); __syncthreads(); }
   double gm = red[0]; __syncthreads();
   if (d.shared && KD > 0) {
-    // shared intrinsics: sum the per-camera parts in camera order (deterministic)
-    if (threadIdx.x < KD) {
-      const int k = threadIdx.x;
+    // shared intrinsics: column norm and gradient are sums over all cameras
+    for (int k = 0; k < KD; ++k) {
       double cs = 0, gs = 0;
-      for (int c = 0; c < d.C; ++c) { cs += w.U[(size_t)c * BD * BD + (6 + k) * BD + 6 + k]; gs += w.g[(size_t)c * BD + 6 + k]; }
-      w.colsq_c[6 * d.C + k] = cs;
-      red[k] = w.active[6 * d.C + k] ? fabs(gs) : 0.0;
+      for (int c = threadIdx.x; c < d.C; c += 256) { cs += w.U[(size_t)c * BD * BD + (6 + k) * BD + 6 + k]; gs += w.g[(size_t)c * BD + 6 + k]; }
+      red[threadIdx.x] = cs; __syncthreads();
+      for (int s2 = 128; s2 > 0; s2 >>= 1) { if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2]; __syncthreads(); }
+      cs = red[0]; __syncthreads();
+      red[threadIdx.x] = gs; __syncthreads();
+      for (int s2 = 128; s2 > 0; s2 >>= 1) { if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2]; __syncthreads(); }
+      gs = red[0]; __syncthreads();
+      if (threadIdx.x == 0) w.colsq_c[6 * d.C + k] = cs;
+      if (w.active[6 * d.C + k]) gm = fmax(gm, fabs(gs));
     }
-    __syncthreads();
-    for (int k = 0; k < KD; ++k) gm = fmax(gm, red[k]);
     __syncthreads();
   }
   if (first) {
@@ -391,12 +407,19 @@ __global__ __launch_bounds__(256) void point_pass_kernel(DevProblem pb, Ws w, vg
     double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0}, Wa[3 * (KD ? KD : 1)];
 #pragma unroll
     for (int i = 0; i < 3 * (KD ? KD : 1); ++i) Wa[i] = 0;
+    double cF[2 * BD], cE[6];          // Jacobians of this lane's first observation (tracks > 64 recompute)
     for (int o = o0 + lane; o < o1; o += 64) {
       const int c = pb.obs_cam[o];
       const int a = d.shared ? 0 : c;
       double r[2], F[2 * BD], E[6];
       eval_full<KD>(d, pb.cam_q + 4 * c, pb.cam_t + 3 * c, pb.intr + 4 * a, X, pb.obs_uv[o],
                     pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
+      if (o - o0 < 64) {
+#pragma unroll
+        for (int i = 0; i < 2 * BD; ++i) cF[i] = F[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) cE[i] = E[i];
+      }
       V[0] += E[0] * E[0] + E[3] * E[3]; V[1] += E[0] * E[1] + E[3] * E[4]; V[2] += E[0] * E[2] + E[3] * E[5];
       V[3] += E[1] * E[1] + E[4] * E[4]; V[4] += E[1] * E[2] + E[4] * E[5]; V[5] += E[2] * E[2] + E[5] * E[5];
       g[0] += E[0] * r[0] + E[3] * r[1]; g[1] += E[1] * r[0] + E[4] * r[1]; g[2] += E[2] * r[0] + E[5] * r[1];
@@ -469,6 +492,38 @@ __global__ __launch_bounds__(256) void point_pass_kernel(DevProblem pb, Ws w, vg
       }
       gmax = fmax(gmax, fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2]))));
     }
+    // per-observation Schur factors Y_i = s_c o ((F_i^T E_i) G) -> slot obs_slot[o] of the zero-padded
+    // segment buffer consumed by schur_tile_kernel
+    {
+      const int bdt = d.shared ? 6 : BD;          // rows of the tile block (intrinsics only when per camera)
+      for (int o = o0 + lane; o < o1; o += 64) {
+        const int c = pb.obs_cam[o];
+        double F[2 * BD], E[6];
+        if (o - o0 < 64) {                        // cached Jacobians of the first slice
+#pragma unroll
+          for (int i = 0; i < 2 * BD; ++i) F[i] = cF[i];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) E[i] = cE[i];
+        } else {
+          const int a = d.shared ? 0 : c;
+          double r[2];
+          eval_full<KD>(d, pb.cam_q + 4 * c, pb.cam_t + 3 * c, pb.intr + 4 * a, X, pb.obs_uv[o],
+                        pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
+        }
+        double* y = w.Y + (size_t)pb.obs_slot[o] * bdt * 3;
+#pragma unroll
+        for (int i = 0; i < BD; ++i) {
+          if (i < bdt) {
+            const double sc = (i < 6) ? w.scale_c[6 * c + i] : w.scale_c[6 * d.C + KD * c + (i - 6)];
+            const double w0 = F[i] * E[0] + F[BD + i] * E[3], w1 = F[i] * E[1] + F[BD + i] * E[4],
+                         w2 = F[i] * E[2] + F[BD + i] * E[5];
+            y[i * 3 + 0] = sc * (w0 * Gm[0]);
+            y[i * 3 + 1] = sc * (w0 * Gm[1] + w1 * Gm[3]);
+            y[i * 3 + 2] = sc * (w0 * Gm[2] + w1 * Gm[4] + w2 * Gm[5]);
+          }
+        }
+      }
+    }
     if (lane == 0) {
       if (first) { w.scale_p[3 * p] = s[0]; w.scale_p[3 * p + 1] = s[1]; w.scale_p[3 * p + 2] = s[2]; }
 #pragma unroll
@@ -519,128 +574,153 @@ __global__ void begin_iteration_kernel(Ws w, vgg_ba_options opt) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Block-sparse Schur complement:  S[(cI,a),(cJ,b)] -= sum_p Y_{p,a} Y_{p,b}^T over the entries of one chunk.
-// Thread (a,b) of the 16x16 workgroup owns the BDxBD block of cameras (gI*16+a, gJ*16+b).
-//   Y_i = s_c o ((F_i^T E_i) G_p)   (BD x 3), recomputed from the raw observation: 16 B of HBM per
-//   observation instead of a 144-192 B cached block.
-template <int KD, int BD>
-struct TileCam {  // camera staged in LDS
-  double q[4], t[3], in4[4], s[BD];
-  unsigned flag; int intr_c;
-};
+// Block-sparse Schur complement on the matrix cores.
+// Tile (gI,gJ) of the reduced system is the R x R matrix (R = 16 cameras x BD rows)
+//     C = sum over entries  YA_e (R x 3) * YB_e^T (3 x R),
+// where YA_e / YB_e are the two *segments* of the entry: the per-observation factors
+// Y_i = s_c o ((F_i^T E_i) G_p) of one point inside one camera group, stored by point_pass at the slot of
+// their camera in a zero-padded block of 16 slots (cameras of the group that do not see the point stay
+// zero for the whole solve).  A segment is therefore one contiguous, 16-byte aligned run of 16*BD*3 doubles:
+// staging is a pure linear copy global -> LDS (dwordx4, coalesced, no masks, no index arithmetic), double
+// buffered against the MFMAs.  Four entries are packed along K (4 x 3 = 12 = three K=4 steps of
+// v_mfma_f64_16x16x4_f64).  The 4 wavefronts form a 2x2 grid over the NT x NT sub-tiles, each keeps up to
+// NH x NH accumulators in registers for the whole chunk; all MFMAs are unconditional (scalar loop bounds).
+typedef double f64x4_t __attribute__((ext_vector_type(4)));
 
-template <int KD, int BD>
-__global__ __launch_bounds__(256) void schur_tile_kernel(DevProblem pb, Ws w, const int32_t* __restrict__ chunk_desc,
+template <int BD>
+__global__ __launch_bounds__(256) void schur_tile_kernel(Ws w, const int32_t* __restrict__ chunk_desc,
                                                          const int32_t* __restrict__ entries) {
   constexpr int YS = BD * 3;                      // doubles per Y block
-  __shared__ TileCam<KD, BD> cams[2][kGroup];
-  __shared__ __attribute__((aligned(16))) double Y[kBatch][2][kGroup][YS];
-  __shared__ unsigned present[kBatch][2];
+  constexpr int SEG = kGroup * YS;                // doubles per segment (16 slots)
+  constexpr int R = kGroup * BD;                  // rows / cols of the tile
+  constexpr int NT = R / 16;                      // 16x16 sub-tiles per side
+  constexpr int NH = (NT + 1) / 2;                // sub-tile rows (cols) of one wavefront
+  __shared__ __attribute__((aligned(16))) double Ops[2][2][4][SEG];   // [buffer][side][entry][slot][r][c]
   if (w.ctl->done) return;
-  const Dims& d = pb.d;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: MFMAs only behind scalar control flow
   const int gI = chunk_desc[4 * blockIdx.x], gJ = chunk_desc[4 * blockIdx.x + 1];
   const int e0 = chunk_desc[4 * blockIdx.x + 2], e1 = chunk_desc[4 * blockIdx.x + 3];
   const bool diag = (gI == gJ);
-  // stage the (up to) 32 cameras
-  if (tid < 2 * kGroup) {
-    const int side = tid >> 4, l = tid & 15;
-    const int c = (side ? gJ : gI) * kGroup + l;
-    TileCam<KD, BD>& tc = cams[side][l];
-    if (c < d.C) {
-      const int a = d.shared ? 0 : c;
-      for (int k = 0; k < 4; ++k) { tc.q[k] = pb.cam_q[4 * c + k]; tc.in4[k] = pb.intr[4 * a + k]; }
-      for (int k = 0; k < 3; ++k) tc.t[k] = pb.cam_t[3 * c + k];
-      for (int k = 0; k < 6; ++k) tc.s[k] = w.scale_c[6 * c + k];
-      for (int k = 0; k < BD - 6; ++k) tc.s[6 + k] = w.scale_c[6 * d.C + KD * c + k];
-      tc.flag = pb.cam_const ? pb.cam_const[c] : 0u;
-      tc.intr_c = (pb.intr_const && pb.intr_const[a]) ? 1 : 0;
-    }
-  }
-  if (tid < kBatch * 2) present[tid >> 1][tid & 1] = 0u;
-  const int a = tid >> 4, b = tid & 15;
-  double acc[BD * BD];
+  const int4* ent = reinterpret_cast<const int4*>(entries);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int rb0 = wr * NH, cb0 = wc * NH;
+  f64x4_t acc[NH][NH];
 #pragma unroll
-  for (int i = 0; i < BD * BD; ++i) acc[i] = 0.0;
-  bool touched = false;
+  for (int i = 0; i < NH; ++i)
+#pragma unroll
+    for (int j = 0; j < NH; ++j) acc[i][j] = (f64x4_t){0.0, 0.0, 0.0, 0.0};
+
+  // Staging of a batch = linear copy of its (up to) 8 segments, 32 threads per segment.  It is split so that
+  // no wavefront ever waits on a dependent global load: the segment index of batch n+2 is loaded while
+  // the segment data of batch n+1 is in flight, and that data is written to LDS only after the MFMAs of
+  // batch n (async-stage split).
+  constexpr int V = SEG / 2;                      // double2 per segment
+  constexpr int NV = (V + 31) / 32;               // double2 per thread per batch
+  const int sseg = tid >> 5, l32 = tid & 31;
+  const int se = sseg >> 1, sside = sseg & 1;
+  const bool sactive = !(diag && sside);
+  auto load_seg_index = [&](int eb) -> int {      // -1: no such entry (tail of the chunk)
+    if (!sactive || eb + se >= e1) return -1;
+    const int4 en = ent[eb + se];
+    return sside ? en.z : en.y;
+  };
+  double2 sv[NV];
+  auto issue_loads = [&](int seg_index) {
+    const double2* src = reinterpret_cast<const double2*>(w.Y) + (size_t)(seg_index < 0 ? 0 : seg_index) * V;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int off = l32 + 32 * i;
+      sv[i] = (seg_index >= 0 && off < V) ? src[off] : make_double2(0.0, 0.0);
+    }
+  };
+  auto write_lds = [&](int buf) {
+    if (!sactive) return;
+    double2* dst = reinterpret_cast<double2*>(&Ops[buf][sside][se][0]);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int off = l32 + 32 * i;
+      if (off < V) dst[off] = sv[i];
+    }
+  };
+  // operand addressing: tile row rr = 16 rb + (lane & 15) lives at slot*YS + r*3 inside a segment; the K
+  // index k = 4 ks + (lane >> 4) selects entry e = k / 3 and component c = k % 3
+  const int li = lane & 15, lk = lane >> 4;
+  int rowoffA[NH], rowoffB[NH];
+#pragma unroll
+  for (int i = 0; i < NH; ++i) {
+    const int ra = min(16 * (rb0 + i) + li, R - 1), rbb = min(16 * (cb0 + i) + li, R - 1);
+    rowoffA[i] = (ra / BD) * YS + (ra % BD) * 3;
+    rowoffB[i] = (rbb / BD) * YS + (rbb % BD) * 3;
+  }
+  int koff[3];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) { const int k = 4 * ks + lk; koff[ks] = (k / 3) * SEG + (k % 3); }
+
+  issue_loads(load_seg_index(e0));
+  int seg_next = load_seg_index(e0 + 4);
+  write_lds(0);
   __syncthreads();
-  for (int eb = e0; eb < e1; eb += kBatch) {
-    // ---- stage: one thread per (entry, side, slot) computes one Y block
-    {
-      const int be = tid >> 5, side = (tid >> 4) & 1, k = tid & 15;
-      const int e = eb + be;
-      if (e < e1 && !(diag && side)) {
-        const int4 en = reinterpret_cast<const int4*>(entries)[e];
-        const int cnt = side ? ((en.w >> 8) & 0xff) : (en.w & 0xff);
-        if (k < cnt) {
-          const int o = (side ? en.z : en.y) + k;
-          const int c = pb.obs_cam[o];
-          const int l = c - (side ? gJ : gI) * kGroup;
-          const TileCam<KD, BD>& tc = cams[side][l];
-          const int p = en.x;
-          const double X[3] = {pb.pts[3 * p], pb.pts[3 * p + 1], pb.pts[3 * p + 2]};
-          double r[2], F[2 * (6 + KD)], E[6];
-          // intrinsics columns only take part in the tile when they are per-camera (BD > 6)
-          eval_full<KD>(d, tc.q, tc.t, tc.in4, X, pb.obs_uv[o], tc.flag, tc.intr_c != 0,
-                        pb.pt_const ? pb.pt_const[p] != 0 : false, r, F, E);
-          const double* Gp = w.G + 6 * (size_t)p;
-          const double G00 = Gp[0], G01 = Gp[1], G02 = Gp[2], G11 = Gp[3], G12 = Gp[4], G22 = Gp[5];
-          double* y = &Y[be][side][l][0];
-          constexpr int FB = 6 + KD;
+  int buf = 0;
+  for (int eb = e0; eb < e1; eb += 4, buf ^= 1) {
+    issue_loads(seg_next);                        // batch eb+4 (zeros past the end of the chunk)
+    seg_next = load_seg_index(eb + 8);
+    const double* As = &Ops[buf][0][0][0];
+    const double* Bs = &Ops[buf][diag ? 0 : 1][0][0];
 #pragma unroll
-          for (int i = 0; i < BD; ++i) {
-            const double w0 = F[i] * E[0] + F[FB + i] * E[3], w1 = F[i] * E[1] + F[FB + i] * E[4],
-                         w2 = F[i] * E[2] + F[FB + i] * E[5];
-            const double sc = tc.s[i];
-            y[i * 3 + 0] = sc * (w0 * G00);
-            y[i * 3 + 1] = sc * (w0 * G01 + w1 * G11);
-            y[i * 3 + 2] = sc * (w0 * G02 + w1 * G12 + w2 * G22);
-          }
-          atomicOr(&present[be][side], 1u << l);
-        }
-      }
+    for (int ks = 0; ks < 3; ++ks) {
+      double a[NH], b[NH];
+#pragma unroll
+      for (int i = 0; i < NH; ++i) { a[i] = As[rowoffA[i] + koff[ks]]; b[i] = Bs[rowoffB[i] + koff[ks]]; }
+#pragma unroll
+      for (int i = 0; i < NH; ++i)
+#pragma unroll
+        for (int j = 0; j < NH; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();
-    // ---- accumulate
-#pragma unroll 1
-    for (int be = 0; be < kBatch; ++be) {
-      const unsigned mA = present[be][0], mB = diag ? mA : present[be][1];
-      if (((mA >> a) & 1u) && ((mB >> b) & 1u) && (!diag || a <= b)) {
-        touched = true;
-        const double* ya = &Y[be][0][a][0];
-        const double* yb = &Y[be][diag ? 0 : 1][b][0];
-        double A[YS];
-#pragma unroll
-        for (int i = 0; i < YS; ++i) A[i] = ya[i];
-#pragma unroll
-        for (int j = 0; j < BD; ++j) {
-          const double b0 = yb[j * 3], b1 = yb[j * 3 + 1], b2 = yb[j * 3 + 2];
-#pragma unroll
-          for (int i = 0; i < BD; ++i) acc[i * BD + j] += A[i * 3] * b0 + A[i * 3 + 1] * b1 + A[i * 3 + 2] * b2;
-        }
-      }
-    }
-    __syncthreads();
-    if (tid < kBatch * 2) present[tid >> 1][tid & 1] = 0u;
-    // (the next stage's atomicOr happens after the threads pass the zeroing in program order of the
-    //  same wave only; a barrier is needed because other waves write the masks)
+    write_lds(buf ^ 1);
     __syncthreads();
   }
-  if (!touched) return;
+  // partial tile of this chunk, row-major R x R (f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 reg);
+  // tile_reduce_kernel sums the chunks of a tile in a fixed order (deterministic, no atomics)
+  double* part = w.tile_part + (size_t)blockIdx.x * R * R;
+#pragma unroll
+  for (int i = 0; i < NH; ++i)
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      const int rb = rb0 + i, cb = cb0 + j;
+      if (rb < NT && cb < NT) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) part[(size_t)(16 * rb + lk + 4 * reg) * R + 16 * cb + li] = acc[i][j][reg];
+      }
+    }
+}
+
+// S[(cI,a,i),(cJ,b,j)] = - sum over the chunks of tile (gI,gJ) of the partial tiles (plain stores: every
+// element of S outside the per-camera diagonal terms belongs to exactly one (tile, element)).
+// grid = (R*R/256, num_tiles): one element per thread, chunks summed in order.
+template <int BD>
+__global__ __launch_bounds__(256) void tile_reduce_kernel(Ws w, int n_red, int C, int KD,
+                                                          const int32_t* __restrict__ tile_desc) {
+  constexpr int R = kGroup * BD;
+  if (w.ctl->done) return;
+  const int gI = tile_desc[4 * blockIdx.y], gJ = tile_desc[4 * blockIdx.y + 1];
+  const int c0 = tile_desc[4 * blockIdx.y + 2], c1 = tile_desc[4 * blockIdx.y + 3];
+  const int n = n_red;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= R * R) return;
+  const int row = e / R, col = e - row * R;
+  const int a = row / BD, i = row - a * BD, b = col / BD, j = col - b * BD;
   const int ca = gI * kGroup + a, cb = gJ * kGroup + b;
-  const int n = d.n_red;
-#pragma unroll
-  for (int i = 0; i < BD; ++i) {
-    const int ri = (i < 6) ? 6 * ca + i : 6 * d.C + KD * ca + (i - 6);
-#pragma unroll
-    for (int j = 0; j < BD; ++j) {
-      const int cj = (j < 6) ? 6 * cb + j : 6 * d.C + KD * cb + (j - 6);
-      if (ca == cb && cj > ri) continue;          // symmetric diagonal block: lower half only
-      const int hi = ri > cj ? ri : cj, lo = ri > cj ? cj : ri;
-      const double v = acc[i * BD + j];
-      if (v != 0.0) unsafeAtomicAdd(&w.S[(size_t)hi * n + lo], -v);
-    }
-  }
+  if (ca >= C || cb >= C) return;
+  if (gI == gJ && col > row) return;             // diagonal tile is symmetric: the lower half is the unique source
+  const int ri = (i < 6) ? 6 * ca + i : 6 * C + KD * ca + (i - 6);
+  const int cj = (j < 6) ? 6 * cb + j : 6 * C + KD * cb + (j - 6);
+  double s0 = 0.0, s1 = 0.0;
+  int ch = c0;
+  for (; ch + 1 < c1; ch += 2) { s0 += w.tile_part[(size_t)ch * R * R + e]; s1 += w.tile_part[(size_t)(ch + 1) * R * R + e]; }
+  if (ch < c1) s0 += w.tile_part[(size_t)ch * R * R + e];
+  const int hi = ri > cj ? ri : cj, lo = ri > cj ? cj : ri;
+  w.S[(size_t)hi * n + lo] = -(s0 + s1);
 }
 
 // diagonal blocks, camera/intrinsics coupling, damping, right-hand side.  One workgroup (64) per camera,
@@ -675,23 +755,37 @@ __global__ __launch_bounds__(64) void assemble_kernel(DevProblem pb, Ws w) {
     if (tid < 6) w.rhs[6 * c + tid] += w.scale_c[6 * c + tid] * T[tid * tw];
     if (!d.shared && tid >= 6 && tid < BD) w.rhs[ia + tid - 6] += w.scale_c[ia + tid - 6] * T[tid * tw];
   } else if (d.shared && KD > 0) {
+    // shared-intrinsics block: sum the per-camera parts (one wavefront, lanes stride over cameras)
     const int ia = 6 * d.C;
-    if (tid < KD * KD) {
-      const int i = tid / KD, j = tid - i * KD;
-      if (j <= i) {
-        double v = 0.0;
-        for (int cc = 0; cc < d.C; ++cc) {
+    constexpr int NS = (KD > 0) ? KD * KD + KD : 1;
+    double sums[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) sums[i] = 0.0;
+    for (int cc = tid; cc < d.C; cc += 64) {
+#pragma unroll
+      for (int i = 0; i < KD; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+          double v = w.scale_c[ia + i] * w.T[((size_t)cc * BD + 6 + i) * tw + 1 + j];
           if (global_terms) v += w.scale_c[ia + i] * w.scale_c[ia + j] * w.U[(size_t)cc * BD * BD + (6 + i) * BD + 6 + j];
-          v += w.scale_c[ia + i] * w.T[((size_t)cc * BD + 6 + i) * tw + 1 + j];
+          sums[i * KD + j] += v;
         }
-        if (global_terms && i == j) v += w.dsq_c[ia + i];
-        w.S[(size_t)(ia + i) * n + ia + j] += v;
+        sums[KD * KD + i] += w.T[((size_t)cc * BD + 6 + i) * tw];
       }
     }
-    if (tid < KD) {
-      double v = 0.0;
-      for (int cc = 0; cc < d.C; ++cc) v += w.T[((size_t)cc * BD + 6 + tid) * tw];
-      w.rhs[ia + tid] += w.scale_c[ia + tid] * v;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) sums[i] = wave_sum(sums[i]);
+    if (tid == 0) {
+#pragma unroll
+      for (int i = 0; i < KD; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+          double v = sums[i * KD + j];
+          if (global_terms && i == j) v += w.dsq_c[ia + i];
+          w.S[(size_t)(ia + i) * n + ia + j] += v;
+        }
+        w.rhs[ia + i] += w.scale_c[ia + i] * sums[KD * KD + i];
+      }
     }
   }
 }
@@ -847,16 +941,18 @@ __global__ __launch_bounds__(256) void reduce_step_kernel(Ws w, int nparts) {
 }
 
 // Ceres' trust-region decision (TrustRegionMinimizer::Minimize body + LevenbergMarquardtStrategy)
-__global__ void control_kernel(Ws w, vgg_ba_options opt, int C) {
+__global__ __launch_bounds__(64) void control_kernel(Ws w, vgg_ba_options opt, int C) {
   Ctl* c = w.ctl;
   if (c->done) return;
+  double step_c = 0, xn_c = 0;
+  for (int i = threadIdx.x; i <= C; i += 64) { step_c += w.cam_part[2 * i]; xn_c += w.cam_part[2 * i + 1]; }
+  step_c = wave_sum(step_c); xn_c = wave_sum(xn_c);
+  if (threadIdx.x != 0) return;
   const int it = c->iteration;
   vgg_ba_iteration li;
   li.iteration = it; li.successful = 0; li.cost = c->x_cost; li.cost_change = 0; li.gradient_max_norm = c->gmax;
   li.step_norm = 0; li.relative_decrease = 0; li.radius = c->radius;
   c->accept = 0;
-  double step_c = 0, xn_c = 0;
-  for (int i = 0; i <= C; ++i) { step_c += w.cam_part[2 * i]; xn_c += w.cam_part[2 * i + 1]; }
   const double cand_cost = 0.5 * w.stepsum[0];
   const double mcc = w.stepsum[1];
   const double step_norm = sqrt(w.stepsum[2] + step_c);
@@ -911,14 +1007,36 @@ __global__ void clear_accept_kernel(Ws w) { if (w.ctl->done) w.ctl->accept = 0; 
 
 // ---------------------------------------------------------------------------------------------
 // host side
+// Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
+enum { kProfLinearize = 0, kProfPointPass, kProfCamRhs, kProfSchurTile, kProfCholesky, kProfPointStep, kProfCount };
+struct Profiler {
+  bool on = false;
+  int cap = 0;
+  hipEvent_t* start[kProfCount] = {};
+  hipEvent_t* stop[kProfCount] = {};
+  int n[kProfCount] = {};
+};
+static Profiler g_prof;
+struct ProfScope {
+  int id; hipStream_t st; bool live;
+  ProfScope(int id_, hipStream_t st_) : id(id_), st(st_), live(g_prof.on && g_prof.n[id_] < g_prof.cap) {
+    if (live) (void)hipEventRecord(g_prof.start[id][g_prof.n[id]], st);
+  }
+  ~ProfScope() {
+    if (live) { (void)hipEventRecord(g_prof.stop[id][g_prof.n[id]], st); g_prof.n[id]++; }
+  }
+};
+
 struct Launch {
   Dims d; DevProblem dp; Ws w; vgg_ba_options opt; hipStream_t st; int wgB;
   const int32_t* chunk_desc; const int32_t* entries; int num_chunks;
+  const int32_t* tile_desc; int num_tiles;
   double *cam_q, *cam_t, *intr, *pts;
 };
 
 template <int KD>
 static void phase_linearize(const Launch& L) {
+  ProfScope ps(kProfLinearize, L.st);
   cam_pass_kernel<KD, 0><<<L.d.C, 256, 0, L.st>>>(L.dp, L.w);
 }
 
@@ -927,13 +1045,25 @@ static void phase_schur(const Launch& L) {
   const Dims& d = L.d;
   prep_kernel<KD><<<1, 256, 0, L.st>>>(L.dp, L.w, L.opt);
   damping_kernel<<<div_up(d.n_red, 256), 256, 0, L.st>>>(L.w, L.opt, d.n_red);
-  point_pass_kernel<KD><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w, L.opt);
+  {
+    ProfScope ps(kProfPointPass, L.st);
+    point_pass_kernel<KD><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w, L.opt);
+  }
   reduce_gmax_kernel<<<1, 256, 0, L.st>>>(L.w, L.wgB);
-  cam_pass_kernel<KD, 1><<<d.C, 256, 0, L.st>>>(L.dp, L.w);
-  hipMemsetAsync(L.w.sys, 0, sizeof(double) * L.w.sys_count, L.st);
+  {
+    ProfScope ps(kProfCamRhs, L.st);
+    cam_pass_kernel<KD, 1><<<d.C, 256, 0, L.st>>>(L.dp, L.w);
+  }
+  (void)hipMemsetAsync(L.w.sys, 0, sizeof(double) * L.w.sys_count, L.st);
   if (L.num_chunks > 0) {
-    if (d.shared || KD == 0) schur_tile_kernel<KD, 6><<<L.num_chunks, 256, 0, L.st>>>(L.dp, L.w, L.chunk_desc, L.entries);
-    else schur_tile_kernel<KD, 6 + KD><<<L.num_chunks, 256, 0, L.st>>>(L.dp, L.w, L.chunk_desc, L.entries);
+    ProfScope ps(kProfSchurTile, L.st);
+    if (d.shared || KD == 0) {
+      schur_tile_kernel<6><<<L.num_chunks, 256, 0, L.st>>>(L.w, L.chunk_desc, L.entries);
+      tile_reduce_kernel<6><<<dim3(96 * 96 / 256, L.num_tiles), 256, 0, L.st>>>(L.w, d.n_red, d.C, KD, L.tile_desc);
+    } else {
+      schur_tile_kernel<6 + KD><<<L.num_chunks, 256, 0, L.st>>>(L.w, L.chunk_desc, L.entries);
+      tile_reduce_kernel<6 + KD><<<dim3(div_up(16 * (6 + KD) * 16 * (6 + KD), 256), L.num_tiles), 256, 0, L.st>>>(L.w, d.n_red, d.C, KD, L.tile_desc);
+    }
   }
   assemble_kernel<KD><<<d.C + 1, 64, 0, L.st>>>(L.dp, L.w);
 }
@@ -943,17 +1073,24 @@ static int phase_step(const Launch& L) {
   const Dims& d = L.d;
   begin_iteration_kernel<<<1, 1, 0, L.st>>>(L.w, L.opt);
   fix_constant_kernel<<<div_up(d.n_red, 256), 256, 0, L.st>>>(L.w, d.n_red);
-  int rc = cholesky_solve_enqueue(L.w.S, L.w.rhs, d.n_red, &L.w.ctl->linear_fail, &L.w.ctl->done, L.st);
+  int rc;
+  {
+    ProfScope ps(kProfCholesky, L.st);
+    rc = cholesky_solve_enqueue(L.w.S, L.w.rhs, d.n_red, L.w.chol_inv, &L.w.ctl->linear_fail, &L.w.ctl->done, L.st);
+  }
   if (rc != VGG_OK) return rc;
   cam_update_kernel<KD><<<div_up(d.C + 1, 64), 64, 0, L.st>>>(L.dp, L.w);
-  point_step_kernel<KD><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w);
+  {
+    ProfScope ps(kProfPointStep, L.st);
+    point_step_kernel<KD><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w);
+  }
   reduce_step_kernel<<<1, 256, 0, L.st>>>(L.w, L.wgB);
   return VGG_OK;
 }
 
 static void phase_update(const Launch& L) {
   const Dims& d = L.d;
-  control_kernel<<<1, 1, 0, L.st>>>(L.w, L.opt, d.C);
+  control_kernel<<<1, 64, 0, L.st>>>(L.w, L.opt, d.C);
   size_t nmax = (size_t)3 * d.P;
   if ((size_t)4 * d.C > nmax) nmax = (size_t)4 * d.C;
   if ((size_t)4 * d.NI > nmax) nmax = (size_t)4 * d.NI;
@@ -968,11 +1105,12 @@ static int make_launch(const vgg_ba_problem* pb, const vgg_ba_options* opt, void
   if (pb->camera_model != kPinhole && pb->camera_model != kSimpleRadial) return VGG_ERR_UNSUPPORTED;
   L->d = make_dims(pb);
   L->dp = dev_problem(pb, L->d);
-  L->w = carve(L->d, opt->max_num_iterations, workspace);
+  L->w = carve(L->d, opt->max_num_iterations, pb->num_chunks, pb->num_segments, workspace);
   L->opt = *opt;
   L->st = st;
   L->wgB = min(max(div_up(L->d.P, 4), 1), kMaxWG);
   L->chunk_desc = pb->chunk_desc; L->entries = pb->entries; L->num_chunks = pb->num_chunks;
+  L->tile_desc = pb->tile_desc; L->num_tiles = pb->num_tiles;
   L->cam_q = pb->cam_q; L->cam_t = pb->cam_t; L->intr = pb->intr; L->pts = pb->pts;
   return VGG_OK;
 }
@@ -1022,13 +1160,48 @@ using namespace vgg;
 
 extern "C" {
 
+int vgg_ba_profile(int enable, int max_launches_per_kernel) {
+  for (int k = 0; k < kProfCount; ++k) {
+    for (int i = 0; i < g_prof.cap; ++i) { (void)hipEventDestroy(g_prof.start[k][i]); (void)hipEventDestroy(g_prof.stop[k][i]); }
+    delete[] g_prof.start[k]; delete[] g_prof.stop[k];
+    g_prof.start[k] = g_prof.stop[k] = nullptr; g_prof.n[k] = 0;
+  }
+  g_prof.cap = 0; g_prof.on = false;
+  if (!enable) return VGG_OK;
+  if (max_launches_per_kernel <= 0) return VGG_ERR_INVALID_ARGUMENT;
+  for (int k = 0; k < kProfCount; ++k) {
+    g_prof.start[k] = new hipEvent_t[max_launches_per_kernel];
+    g_prof.stop[k] = new hipEvent_t[max_launches_per_kernel];
+    for (int i = 0; i < max_launches_per_kernel; ++i) {
+      VGG_HIP_CHECK(hipEventCreate(&g_prof.start[k][i]));
+      VGG_HIP_CHECK(hipEventCreate(&g_prof.stop[k][i]));
+    }
+  }
+  g_prof.cap = max_launches_per_kernel; g_prof.on = true;
+  return VGG_OK;
+}
+
+int vgg_ba_profile_read(int kernel_id, double* total_ms, int* launches, int reset) {
+  if (kernel_id < 0 || kernel_id >= kProfCount || !total_ms || !launches) return VGG_ERR_INVALID_ARGUMENT;
+  double tot = 0;
+  for (int i = 0; i < g_prof.n[kernel_id]; ++i) {
+    VGG_HIP_CHECK(hipEventSynchronize(g_prof.stop[kernel_id][i]));
+    float ms = 0;
+    VGG_HIP_CHECK(hipEventElapsedTime(&ms, g_prof.start[kernel_id][i], g_prof.stop[kernel_id][i]));
+    tot += ms;
+  }
+  *total_ms = tot; *launches = g_prof.n[kernel_id];
+  if (reset) g_prof.n[kernel_id] = 0;
+  return VGG_OK;
+}
+
 const char* vgg_build_arch(void) { return "gfx950"; }
 int vgg_abi_version(void) { return 1; }
 
 size_t vgg_ba_workspace_bytes(const vgg_ba_problem* problem, const vgg_ba_options* options) {
   if (!problem || !options) return 0;
   const Dims d = make_dims(problem);
-  return carve(d, options->max_num_iterations, nullptr).total_bytes + 256;
+  return carve(d, options->max_num_iterations, problem->num_chunks, problem->num_segments, nullptr).total_bytes + 256;
 }
 
 int vgg_ba_begin(const vgg_ba_problem* problem, const vgg_ba_options* options, void* workspace, size_t workspace_bytes,
@@ -1037,6 +1210,7 @@ int vgg_ba_begin(const vgg_ba_problem* problem, const vgg_ba_options* options, v
   int rc = make_launch(problem, options, workspace, (hipStream_t)stream, &L);
   if (rc != VGG_OK) return rc;
   if (workspace_bytes < L.w.total_bytes) return VGG_ERR_WORKSPACE;
+  VGG_HIP_CHECK(hipMemsetAsync(L.w.Y, 0, L.w.y_bytes, L.st));   // absent slots stay zero for the whole solve
   init_kernel<<<div_up(L.d.n_red > 0 ? L.d.n_red : 1, 256), 256, 0, L.st>>>(L.dp, L.w, L.opt, rank, world_size);
   VGG_LAUNCH_CHECK();
   return VGG_OK;
@@ -1056,7 +1230,7 @@ int vgg_ba_reduce_buffer(const vgg_ba_problem* problem, const vgg_ba_options* op
                          double** device_ptr, size_t* count) {
   if (!problem || !options || !workspace || !device_ptr || !count) return VGG_ERR_INVALID_ARGUMENT;
   const Dims d = make_dims(problem);
-  Ws w = carve(d, options->max_num_iterations, workspace);
+  Ws w = carve(d, options->max_num_iterations, problem->num_chunks, problem->num_segments, workspace);
   switch (which) {
     case 0: *device_ptr = w.lin; *count = w.lin_count; break;
     case 1: *device_ptr = w.sys; *count = w.sys_count; break;

@@ -60,18 +60,22 @@ int vgg_cam_from_img(const void* tracks, int tracks_are_f64, const double* intri
 
 /* ------------------------------------------------------------------------------------------
  * triangulate_tracks_single_chunk         vggsfm/utils/triangulation.py:776-956
- * LO-RANSAC multi-view DLT for N tracks of one chunk.  `pairs` (H,2) int32 device: the hypothesis
- * view pairs (the caller reproduces the reference's host-side torch.randperm draw, :804-813).
- * invalid_vis_conf (S,N) uint8 = (vis <= 0.05) | (score <= 0.5)  (:867-874).
- * Pass 1 writes per-hypothesis (inlier_num, mean inlier error) into workspace and the chunk-global
- * max of the mean errors; pass 2 then applies calculate_residual_indicator
- * (vggsfm/two_view_geo/utils.py:63-87) with that chunk-global threshold and gathers the winner.
+ * LO-RANSAC multi-view DLT for the N tracks of one chunk, one wavefront per track.
+ *   tracks_t (N,S,2) f64: normalised rays, TRACK-major (the reference transposes too, :798)
+ *   invalid_vis_conf_t (N,S) uint8 = (vis <= 0.05) | (score <= 0.5)              (:867-874)
+ *   pairs (H,2) int32 device: hypothesis view pairs; the caller reproduces the reference's host-side
+ *   torch.randperm draw (:804-813).  H <= 256, lo_num <= 64 (second round: min(10, lo_num), :902-904).
+ * Hypotheses are ranked by inlier count in STABLE descending order (tie-break contract).
+ * *threshold_io (host, in/out): calculate_residual_indicator (vggsfm/two_view_geo/utils.py:63-87)
+ * normalises by the chunk-global max mean inlier error + 1e-6.  Pass 2*pi + 1e-6 (exact whenever some
+ * hypothesis of the chunk has no inlier); on return it holds the measured value -- if it differs,
+ * call again with the returned value.  Synchronises the stream once.
  * Outputs: points (N,3) f64, inlier_num (N) int64, inlier_mask (N,S) uint8. */
 size_t vgg_triangulate_workspace_bytes(int S, int N, int H, int lo_num);
-int vgg_triangulate_tracks(const double* extrinsics, const double* tracks_normalized, const uint8_t* invalid_vis_conf,
+int vgg_triangulate_tracks(const double* extrinsics, const double* tracks_t, const uint8_t* invalid_vis_conf_t,
                            const int32_t* pairs, int S, int N, int H, int lo_num, double max_angular_error_deg,
                            double min_tri_angle_deg, double* out_points, int64_t* out_inlier_num,
-                           uint8_t* out_inlier_mask, void* workspace, void* stream);
+                           uint8_t* out_inlier_mask, double* threshold_io, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Bundle adjustment / pose refinement = what the reference obtains from

@@ -171,6 +171,18 @@ int vgg_ba_reduce_buffer(const vgg_ba_problem* problem, const vgg_ba_options* op
 int vgg_ba_finish(const vgg_ba_problem* problem, const vgg_ba_options* options, void* workspace,
                   vgg_ba_summary* summary, vgg_ba_iteration* log, int log_cap, void* stream);
 
+/* pycolmap.pose_refinement for a batch of frames   vggsfm/utils/triangulation.py:387,590 (loops :341-441, :542-608)
+ * = COLMAP RefineAbsolutePose: points constant, robust loss (reference: Cauchy, scale 1), unknowns pose
+ * (+ focal if refine_flags bit0, + extra param if bit1).  One workgroup solves one frame; frames are
+ * independent.  frame_ids (F) int32 device: frames to refine; inlier_mask (S,P) uint8: observations used.
+ * cam_q (S,4) / cam_t (S,3) / intr (S,4 = f,cx,cy,k PER FRAME) are updated in place for those frames.
+ * options: Ceres defaults for this call site are max_num_iterations 100, function_tolerance 1e-6,
+ * gradient_tolerance 1.0, parameter_tolerance 1e-8.  summaries (F) device or NULL. */
+int vgg_pose_refine(const double* points3D, const void* tracks, int tracks_are_f64, const uint8_t* inlier_mask, int S,
+                    int P, const int32_t* frame_ids, int num_frames, double* cam_q, double* cam_t, double* intr,
+                    int camera_model, const uint8_t* refine_flags, const vgg_ba_options* options, int loss,
+                    double loss_scale, vgg_ba_summary* summaries, void* stream);
+
 /* Optional per-kernel timing (HIP events recorded on the launch stream around the dominant kernels).
  * kernel_id: 0 cam_pass<linearize> 1 point_pass 2 cam_pass<rhs> 3 schur_tile 4 cholesky (all launches of one
  * solve) 5 point_step.  vgg_ba_profile_read synchronises on the recorded events. */

@@ -596,11 +596,24 @@ int bao_solve(const bao_problem_t* pb, const bao_options_t* opt, double* cam_q, 
     li.cost_change = x_cost - cand_cost;
     /* ParameterToleranceReached */
     {
+      /* |x| over the parameter blocks Ceres keeps in the reduced program (constant blocks are removed) */
       double xs = 0;
-      for (int i = 0; i < 4 * C; ++i) xs += cam_q[i] * cam_q[i];
-      for (int i = 0; i < 3 * C; ++i) xs += cam_t[i] * cam_t[i];
-      for (int i = 0; i < 4 * NI; ++i) xs += intr[i] * intr[i];
-      for (int i = 0; i < 3 * P; ++i) xs += pts[i] * pts[i];
+      for (int cam = 0; cam < C; ++cam) {
+        if (pb->cam_const && (pb->cam_const[cam] & 1)) continue;
+        for (int k = 0; k < 4; ++k) xs += cam_q[4 * cam + k] * cam_q[4 * cam + k];
+        for (int k = 0; k < 3; ++k) xs += cam_t[3 * cam + k] * cam_t[3 * cam + k];
+      }
+      if (c.kd > 0) {
+        const int np = pb->camera_model == 1 ? 4 : 3;
+        for (int a = 0; a < NI; ++a) {
+          if (pb->intr_const && pb->intr_const[a]) continue;
+          for (int k = 0; k < np; ++k) xs += intr[4 * a + k] * intr[4 * a + k];
+        }
+      }
+      for (int p = 0; p < P; ++p) {
+        if (pb->pt_const && pb->pt_const[p]) continue;
+        for (int k = 0; k < 3; ++k) xs += pts[3 * p + k] * pts[3 * p + k];
+      }
       const double tol = opt->parameter_tolerance * (sqrt(xs) + opt->parameter_tolerance);
       if (!(step_norm > tol)) { sum->termination = BAO_CONVERGENCE_PARAMETER; if (log && it < log_cap) log[it] = li; sum->num_log = it + 1; break; }
     }

@@ -818,8 +818,10 @@ __global__ void cam_update_kernel(DevProblem pb, Ws w) {
     }
     double qn[4];
     quat_plus(pb.cam_q + 4 * c, dl, qn);
-    for (int k = 0; k < 4; ++k) { w.cand_q[4 * c + k] = qn[k]; const double df = qn[k] - pb.cam_q[4 * c + k]; step += df * df; xn += pb.cam_q[4 * c + k] * pb.cam_q[4 * c + k]; }
-    for (int k = 0; k < 3; ++k) { const double tn = pb.cam_t[3 * c + k] + dl[3 + k]; w.cand_t[3 * c + k] = tn; step += dl[3 + k] * dl[3 + k]; xn += pb.cam_t[3 * c + k] * pb.cam_t[3 * c + k]; }
+    // |x| counts only blocks Ceres keeps in the reduced program (a constant pose is removed from it)
+    const bool pose_var = !(pb.cam_const && (pb.cam_const[c] & 1u));
+    for (int k = 0; k < 4; ++k) { w.cand_q[4 * c + k] = qn[k]; const double df = qn[k] - pb.cam_q[4 * c + k]; step += df * df; if (pose_var) xn += pb.cam_q[4 * c + k] * pb.cam_q[4 * c + k]; }
+    for (int k = 0; k < 3; ++k) { const double tn = pb.cam_t[3 * c + k] + dl[3 + k]; w.cand_t[3 * c + k] = tn; step += dl[3 + k] * dl[3 + k]; if (pose_var) xn += pb.cam_t[3 * c + k] * pb.cam_t[3 * c + k]; }
   }
   // intrinsics block a == c (per camera) or block 0 handled by the extra thread c == C (shared)
   const int a = d.shared ? ((c == d.C) ? 0 : -1) : ((c < d.C) ? c : -1);
@@ -834,7 +836,9 @@ __global__ void cam_update_kernel(DevProblem pb, Ws w) {
       in4[slot] -= dyv;
       step += dyv * dyv;
     }
-    for (int k = 0; k < 4; ++k) { w.cand_intr[4 * a + k] = in4[k]; xn += pb.intr[4 * a + k] * pb.intr[4 * a + k]; }
+    const bool intr_var = KD > 0 && !(pb.intr_const && pb.intr_const[a]);
+    const int np = (d.model == kSimpleRadial) ? 4 : 3;
+    for (int k = 0; k < 4; ++k) { w.cand_intr[4 * a + k] = in4[k]; if (intr_var && k < np) xn += pb.intr[4 * a + k] * pb.intr[4 * a + k]; }
   }
   w.cam_part[2 * c] = step;
   w.cam_part[2 * c + 1] = xn;
@@ -889,7 +893,7 @@ __global__ __launch_bounds__(256) void point_step_kernel(DevProblem pb, Ws w) {
     if (lane == 0) {
       w.cand_pts[3 * (size_t)p] = Xn[0]; w.cand_pts[3 * (size_t)p + 1] = Xn[1]; w.cand_pts[3 * (size_t)p + 2] = Xn[2];
       s_step += ys[0] * ys[0] + ys[1] * ys[1] + ys[2] * ys[2];
-      s_xn += X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
+      if (!pt_c) s_xn += X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
     }
     for (int o = o0 + lane; o < o1; o += 64) {
       const int c = pb.obs_cam[o];

@@ -116,3 +116,229 @@ def triangulate_by_pair(extrinsics, tracks_normalized, eps=1e-12):
     ang = torch.abs(torch.acos(torch.clamp(nom / den, -1.0, 1.0)))
     ang = torch.min(ang, torch.pi - ang) * (180.0 / torch.pi)
     return pts, cheirality, ang
+
+
+# ==========================================================================================
+# BA / pose-refinement drivers (reference: triangulation.py:138-647, 1020-1242).  The reference marshals
+# tensors into pycolmap objects with O(S*P) Python loops and back; here everything stays on the device.
+# ==========================================================================================
+from .. import ba as _ba                                    # noqa: E402
+from ..ba_options import AbsolutePoseRefinementOptions, BundleAdjustmentOptions  # noqa: E402
+from ..pose import pose_refinement_batch                    # noqa: E402
+from .triangulation_helpers import cam_from_img, filter_all_points3D, prepare_ba_options  # noqa: E402
+
+
+def get_valid_frame_mask(intrinsics, extrinsics, extra_params, scale):
+    """Reference: triangulation.py:1222-1242."""
+    valid = torch.logical_and(intrinsics[:, 0, 0] >= 0.1 * scale, intrinsics[:, 0, 0] <= 30 * scale)
+    if extra_params is not None:
+        if extra_params.dim() == 1:
+            extra_params = extra_params[:, None]
+        valid = torch.logical_and(valid, (extra_params.abs() <= 1.0).all(dim=-1))
+    return torch.logical_and(valid, (extrinsics[:, :, 3].abs() <= 30).all(-1))
+
+
+def _intr_params(intrinsics, extra_params):
+    """(S,3,3) K [+ (S,1) k] -> (S,4) COLMAP parameter rows f,cx,cy,k."""
+    S = intrinsics.shape[0]
+    p = torch.zeros((S, 4), dtype=torch.float64, device=intrinsics.device)
+    p[:, 0] = intrinsics[:, 0, 0]
+    p[:, 1] = intrinsics[:, 0, 2]
+    p[:, 2] = intrinsics[:, 1, 2]
+    if extra_params is not None:
+        p[:, 3] = extra_params.to(torch.float64)[:, 0]
+    return p
+
+
+def _from_intr_params(p, camera_type):
+    S = p.shape[0]
+    K = torch.zeros((S, 3, 3), dtype=torch.float64, device=p.device)
+    K[:, 0, 0] = K[:, 1, 1] = p[:, 0]
+    K[:, 0, 2], K[:, 1, 2], K[:, 2, 2] = p[:, 1], p[:, 2], 1.0
+    extra = p[:, 3:4].clone() if camera_type == "SIMPLE_RADIAL" else None
+    return K, extra
+
+
+def _check_camera_type(camera_type):
+    if camera_type not in ("SIMPLE_PINHOLE", "SIMPLE_RADIAL"):
+        raise ValueError(f"Camera type {camera_type} is not supported yet")
+
+
+def _refine_frames(extrinsics, intrinsics, extra_params, tracks2D, points3D, inlier, refine_ids, shared_camera,
+                   camera_type, min_inliers, first_frame_refines_intrinsics):
+    """Common body of init_refine_pose / refine_pose: what the reference's per-frame loop computes.
+    Returns (extrinsics, intrinsics, extra_params, refined (S,) bool)."""
+    S = extrinsics.shape[0]
+    dev = tracks2D.device
+    counts = inlier.sum(dim=1)
+    enough = counts > min_inliers
+    want = torch.zeros(S, dtype=torch.bool, device=dev)
+    want[torch.as_tensor(refine_ids, dtype=torch.long, device=dev)] = True
+    todo = want & enough
+    params = _intr_params(intrinsics, extra_params)
+    ext = extrinsics.to(torch.float64).clone()
+    flags = torch.full((S,), 3, dtype=torch.uint8, device=dev)
+    if shared_camera:
+        # one pycolmap.Camera object serves every frame: frame 0 may refine it, later frames keep it fixed
+        # (reference :373-375) and see the refined values
+        flags[1:] = 0
+        if not first_frame_refines_intrinsics:
+            flags[0] = 0
+        if bool(todo[0]):
+            ext, params, _ = pose_refinement_batch(ext, params, tracks2D, points3D, inlier, [0], camera_type, flags)
+        params = params[0:1].expand(S, -1).contiguous()
+        rest = torch.nonzero(todo[1:]).squeeze(1) + 1
+        ext, params, _ = pose_refinement_batch(ext, params, tracks2D, points3D, inlier, rest, camera_type, flags)
+        params = params[0:1].expand(S, -1).contiguous()
+    else:
+        ids = torch.nonzero(todo).squeeze(1)
+        ext, params, _ = pose_refinement_batch(ext, params, tracks2D, points3D, inlier, ids, camera_type, flags)
+    K, extra = _from_intr_params(params, camera_type)
+    return ext, K, extra, todo
+
+
+def init_refine_pose(extrinsics, intrinsics, extra_params, inlier, points3D, tracks, valid_track_mask_init, image_size,
+                     init_idx, max_reproj_error=12, shared_camera=False, camera_type="SIMPLE_PINHOLE"):
+    """Reference: triangulation.py:482-647.  Refines every frame except the initial pair on the fixed
+    initial point cloud (frames with <= 50 inliers are left alone)."""
+    _check_camera_type(camera_type)
+    S = extrinsics.shape[0]
+    P = tracks.shape[1]
+    assert len(intrinsics) == S and inlier.shape[0] == S - 1 and inlier.shape[1] == P and len(valid_track_mask_init) == P
+    inl = torch.cat([torch.ones_like(inlier[0:1]), inlier], dim=0)[:, valid_track_mask_init]
+    tracks2D = tracks[:, valid_track_mask_init]
+    refine_ids = [r for r in range(S) if r != 0 and r != init_idx + 1]
+    few = torch.nonzero((inl.sum(1) <= 50)[torch.as_tensor(refine_ids, dtype=torch.long, device=inl.device)]).squeeze(1) \
+        if refine_ids else []
+    for k in (few.tolist() if len(refine_ids) else []):
+        print("This frame only has inliers:", int(inl[refine_ids[k]].sum()))
+    ext, K, extra, _ = _refine_frames(extrinsics, intrinsics, extra_params, tracks2D, points3D, inl, refine_ids, shared_camera,
+                                      camera_type, 50, first_frame_refines_intrinsics=False)
+    scale = image_size.max()
+    valid = get_valid_frame_mask(K, ext, extra, scale)
+    if (~valid).sum() > 0:
+        print("some frames are invalid after BA refinement")
+        ext[~valid] = extrinsics[~valid].to(ext.dtype)
+        K[~valid] = intrinsics[~valid].to(ext.dtype)
+        if extra_params is not None:
+            extra[~valid] = extra_params[~valid].to(ext.dtype)
+    return ext, K, extra, valid
+
+
+def refine_pose(extrinsics, intrinsics, extra_params, inlier, points3D, tracks, valid_track_mask, image_size,
+                shared_camera=False, max_reproj_error=12, camera_type="SIMPLE_PINHOLE", force_estimate=False):
+    """Reference: triangulation.py:260-479.  Inliers = given mask AND reprojection error <= 12 px with
+    positive depth; frames with > 100 such inliers are refined.  The reference's RANSAC fallback
+    (pycolmap.absolute_pose_estimation, P3P, random) is not reproduced: such frames keep their pose."""
+    _check_camera_type(camera_type)
+    S = extrinsics.shape[0]
+    P = tracks.shape[1]
+    assert len(intrinsics) == S and inlier.shape[0] == S and inlier.shape[1] == P and len(valid_track_mask) == P
+    empty = points3D.abs().sum(-1) <= 0
+    if empty.sum() > 0:
+        tmp = valid_track_mask.clone()
+        tmp[valid_track_mask] = ~empty
+        valid_track_mask = tmp
+        points3D = points3D[~empty]
+    tracks2D = tracks[:, valid_track_mask]
+    _, reproj_inlier = filter_all_points3D(points3D, tracks2D, extrinsics, intrinsics, extra_params,
+                                           max_reproj_error=max_reproj_error, check_triangle=False, return_detail=True,
+                                           hard_max=-1, behind_value=1e9)
+    inl = torch.logical_and(inlier[:, valid_track_mask], reproj_inlier)
+    counts = inl.sum(1)
+    for r in torch.nonzero(counts <= 100).squeeze(1).tolist():
+        print(f"Frame {r} only has {int(counts[r])} geo_vis inliers")
+        if force_estimate:
+            print(f"Warning! absolute pose estimation (P3P RANSAC) is not part of the device path; frame {r} keeps its pose")
+    ext, K, extra, _ = _refine_frames(extrinsics, intrinsics, extra_params, tracks2D, points3D, inl, list(range(S)),
+                                      shared_camera, camera_type, 100, first_frame_refines_intrinsics=True)
+    scale = image_size.max()
+    valid = get_valid_frame_mask(K, ext, extra, scale)
+    if (~valid).sum() > 0:
+        print("some frames are invalid after BA refinement")
+        ext[~valid] = extrinsics[~valid].to(ext.dtype)
+        K[~valid] = intrinsics[~valid].to(ext.dtype)
+        if extra_params is not None:
+            extra[~valid] = extra_params[~valid].to(ext.dtype)
+    return ext, K, extra, valid
+
+
+def init_BA(extrinsics, intrinsics, extra_params, tracks, points_3d_pair, inlier, image_size, shared_camera=False,
+            init_max_reproj_error=0.5, camera_type="SIMPLE_PINHOLE"):
+    """Reference: triangulation.py:138-257: two-view BA on the best initial pair, then reprojection filter."""
+    _check_camera_type(camera_type)
+    init_idx = torch.argmax(inlier.sum(dim=-1)).item()
+    init_indices = [0, init_idx + 1]
+    toBA_ext, toBA_K = extrinsics[init_indices], intrinsics[init_indices]
+    toBA_extra = extra_params[init_indices] if extra_params is not None else None
+    toBA_tracks = tracks[init_indices]
+    toBA_points3D = points_3d_pair[init_idx]
+    toBA_masks = inlier[init_idx].unsqueeze(0)
+    toBA_masks = torch.cat([torch.ones_like(toBA_masks), toBA_masks], dim=0)
+    toBA_valid = toBA_masks.sum(dim=0) >= 2
+    toBA_masks = toBA_masks[:, toBA_valid]
+    toBA_points3D = toBA_points3D[toBA_valid]
+    toBA_tracks = toBA_tracks[:, toBA_valid]
+    pts_opt, ext_opt, K_opt, extra_opt, summary = _ba.bundle_adjustment(
+        toBA_points3D, toBA_ext, toBA_K, toBA_tracks, toBA_masks, image_size, toBA_extra, shared_camera, camera_type,
+        prepare_ba_options())
+    valid3D, _ = filter_all_points3D(pts_opt, toBA_tracks, ext_opt, K_opt, extra_opt, check_triangle=False,
+                                     max_reproj_error=init_max_reproj_error)
+    pts_opt = pts_opt[valid3D]
+    filtered = toBA_valid.clone()
+    filtered[toBA_valid] = valid3D
+    extrinsics[init_indices] = ext_opt.to(extrinsics.dtype)          # in place, like the reference (:243-246)
+    intrinsics[init_indices] = K_opt.to(intrinsics.dtype)
+    if extra_params is not None:
+        extra_params[init_indices] = extra_opt.to(extra_params.dtype)
+    return pts_opt, extrinsics, intrinsics, extra_params, filtered, summary, init_idx
+
+
+def _revert_negative_focal(ext, K, extra, ext_old, K_old, extra_old):
+    bad = K[:, 0, 0] < 0
+    if bad.any():
+        ext[bad], K[bad] = ext_old[bad].to(ext.dtype), K_old[bad].to(K.dtype)
+        if extra is not None:
+            extra[bad] = extra_old[bad].to(extra.dtype)
+    return ext, K, extra
+
+
+def global_BA(triangulated_points, valid_tracks, pred_tracks, inlier_mask, extrinsics, intrinsics, extra_params, image_size,
+              shared_camera=False, camera_type="SIMPLE_PINHOLE"):
+    """Reference: triangulation.py:1020-1073 (prepare_ba_options, then normalize(5, 0.1, 0.9, True))."""
+    BA_points = triangulated_points[valid_tracks]
+    BA_tracks = pred_tracks[:, valid_tracks]
+    BA_masks = inlier_mask[valid_tracks].transpose(0, 1)
+    pts, ext, K, extra, summary = _ba.bundle_adjustment(BA_points, extrinsics, intrinsics, BA_tracks, BA_masks, image_size,
+                                                        extra_params, shared_camera, camera_type, prepare_ba_options(),
+                                                        normalize=True)
+    ext, K, extra = _revert_negative_focal(ext, K, extra, extrinsics, intrinsics, extra_params)
+    return pts, ext, K, extra, summary
+
+
+def iterative_global_BA(pred_tracks, intrinsics, extrinsics, pred_vis, pred_score, valid_tracks, points3D_opt, image_size,
+                        shared_camera=False, min_valid_track_length=2, max_reproj_error=1, ba_options=None, lastBA=False,
+                        camera_type="SIMPLE_PINHOLE", extra_params=None):
+    """Reference: triangulation.py:1076-1209: retriangulate (128 hypotheses) -> filter -> BA -> filter."""
+    tn = cam_from_img(pred_tracks, intrinsics, extra_params)
+    best_pts, _, _ = triangulate_tracks(extrinsics, tn, track_vis=pred_vis, track_score=pred_score, max_ransac_iters=128)
+    best_pts[valid_tracks] = points3D_opt
+    _, filt = filter_all_points3D(best_pts, pred_tracks, extrinsics, intrinsics, extra_params=extra_params,
+                                  max_reproj_error=max_reproj_error, return_detail=True)
+    valid_tracks = filt.sum(dim=0) >= min_valid_track_length
+    BA_points = best_pts[valid_tracks]
+    BA_tracks = pred_tracks[:, valid_tracks]
+    BA_masks = filt[:, valid_tracks]
+    if ba_options is None:
+        ba_options = BundleAdjustmentOptions()
+    pts, ext, K, extra, summary = _ba.bundle_adjustment(BA_points, extrinsics, intrinsics, BA_tracks, BA_masks, image_size,
+                                                        extra_params, shared_camera, camera_type, ba_options, normalize=True)
+    ext, K, extra = _revert_negative_focal(ext, K, extra, extrinsics, intrinsics, extra_params)
+    _, filt2 = filter_all_points3D(pts, pred_tracks[:, valid_tracks], ext, K, extra_params=extra,
+                                   max_reproj_error=max_reproj_error, return_detail=True)
+    after = filt2.sum(dim=0) >= min_valid_track_length
+    vt = valid_tracks.clone()
+    vt[valid_tracks] = after
+    pts = pts[after]
+    BA_inlier_masks = filt2[:, after]
+    return pts, ext, K, extra, vt, BA_inlier_masks, summary

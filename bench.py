@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 from vggsfm_amd import _lib  # noqa: E402
 from vggsfm_amd import ba as BA  # noqa: E402
 from vggsfm_amd.ba_options import BundleAdjustmentOptions  # noqa: E402
+from vggsfm_amd.dist import ShardedBA  # noqa: E402
 from vggsfm_amd.scene import make_scene, perturb_for_ba  # noqa: E402
 
 EPISODE = 25
@@ -92,40 +93,14 @@ def main():
     so = opts.solver_options
     so.max_num_iterations = EPISODE
     so.function_tolerance = so.gradient_tolerance = so.parameter_tolerance = -1.0   # run exactly K iterations
-    cp = prob.c_struct()
-    co = BA._c_options(opts)
-    nbytes = int(L.vgg_ba_workspace_bytes(ctypes.byref(cp), ctypes.byref(co)))
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    st = _lib.stream_ptr()
-    bufs = []
-    for which in range(4):
-        p = ctypes.POINTER(ctypes.c_double)()
-        cnt = ctypes.c_size_t()
-        _lib.check(L.vgg_ba_reduce_buffer(ctypes.byref(cp), ctypes.byref(co), _lib.ptr(ws), which, ctypes.byref(p),
-                                          ctypes.byref(cnt)), "vgg_ba_reduce_buffer")
-        bufs.append(wrap(ws, ctypes.addressof(p.contents), cnt.value))
+    solver = ShardedBA(prob, opts, rank, world)     # phases + RCCL all-reduces on the current stream
 
     def begin():
         for dst, src in zip((prob.cam_q, prob.cam_t, prob.intr, prob.pts), init):
             dst.copy_(src)
-        _lib.check(L.vgg_ba_begin(ctypes.byref(cp), ctypes.byref(co), _lib.ptr(ws), ctypes.c_size_t(nbytes), rank, world,
-                                  st), "vgg_ba_begin")
+        solver.begin()
 
-    def phase(i):
-        _lib.check(L.vgg_ba_phase(ctypes.byref(cp), ctypes.byref(co), _lib.ptr(ws), i, st), "vgg_ba_phase")
-
-    def iteration():
-        phase(0)
-        if dist:
-            dist.all_reduce(bufs[0])
-        phase(1)
-        if dist:
-            dist.all_reduce(bufs[1])
-            dist.all_reduce(bufs[2], op=dist.ReduceOp.MAX)
-        phase(2)
-        if dist:
-            dist.all_reduce(bufs[3])
-        phase(3)
+    iteration = solver.iteration
 
     def run(n, counter):
         for _ in range(n):
@@ -155,13 +130,11 @@ def main():
         dt = float(tmax.item())
 
     # the last episode must have run all its iterations (no early termination => no skipped work)
-    summ = _lib.BASummary()
-    _lib.check(L.vgg_ba_finish(ctypes.byref(cp), ctypes.byref(co), _lib.ptr(ws), ctypes.byref(summ), None, 0, st),
-               "vgg_ba_finish")
+    fin = solver.finish()
     expect = counter[0] % EPISODE or EPISODE
-    if summ.num_iterations != expect:
-        raise SystemExit(f"LM terminated early: {summ.num_iterations} of {expect} iterations (termination "
-                         f"{summ.termination}) -- timing invalid")
+    if fin["num_iterations"] != expect:
+        raise SystemExit(f"LM terminated early: {fin['num_iterations']} of {expect} iterations (termination "
+                         f"{fin['termination_str']}) -- timing invalid")
 
     # ---- per-kernel HIP-event timings of the timed region (rank-local)
     prof = {}
@@ -176,7 +149,7 @@ def main():
         counts = (prob.row_ptr[1:] - prob.row_ptr[:-1]).double()
         n_obs = int(prob.num_obs)
         P = int(prob.pts.shape[0])
-        n_red = int(summ.n_reduced)
+        n_red = int(fin["n_reduced"])
         bd = 6 if shared else 6 + (2 if cam_type == "SIMPLE_RADIAL" else 1)     # Schur block width
         pair_blocks = float((counts * (counts + 1) / 2).sum().item())
         # algorithmic work per launch (DESIGN.md "Kernels"): flops for the fp64-compute-bound kernels,
@@ -245,7 +218,7 @@ def main():
                        "frames": S, "tracks_per_gpu": N, "observations_per_gpu": n_obs, "reduced_system": n_red,
                        "parallelism": f"points sharded x{world}, cameras replicated, RCCL all-reduce of the reduced system",
                        "episode_iterations": EPISODE,
-                       "successful_steps_last_episode": int(summ.num_successful_steps),
+                       "successful_steps_last_episode": int(fin["num_successful_steps"]),
                        "kernel_ms": kernel_ms},
             "roofline": roof,
             "cpu_baseline": cpu,

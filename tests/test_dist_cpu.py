@@ -1,0 +1,109 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise the point sharding and the collective that the
+GPU path performs every LM iteration (SUM all-reduce of the camera-side blocks of each rank's shard)."""
+import ctypes
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ba as OB
+from vggsfm_amd import ba as BA
+from vggsfm_amd.dist import partition_points, shard_slice
+from vggsfm_amd.scene import make_scene, perturb_for_ba
+
+
+def test_partition_balanced_and_exhaustive():
+    torch.manual_seed(0)
+    counts = torch.randint(2, 80, (5000,))
+    for w in (1, 2, 3, 8):
+        b = partition_points(counts, w)
+        assert b[0] == 0 and b[-1] == 5000 and (b[1:] >= b[:-1]).all()
+        loads = torch.stack([counts[b[r]:b[r + 1]].sum() for r in range(w)]).double()
+        assert float(loads.max() / loads.mean()) < 1.02
+    # degenerate: fewer points than ranks
+    b = partition_points(torch.tensor([5, 5]), 4)
+    assert b[0] == 0 and b[-1] == 2 and (b[1:] >= b[:-1]).all()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _camera_side(sc, ext0, K0, extra0, pts0, tracks, masks, cam_type):
+    """camera-side gradient sum_i F_i^T r_i and cost of a (shard of a) problem, through the oracle's
+    per-observation residual / Jacobian -- the content of reduce buffer 0."""
+    L = OB.lib()
+    S = len(ext0)
+    q = np.ascontiguousarray(OB.rotmat_to_quat(ext0[:, :, :3]))
+    t = np.ascontiguousarray(ext0[:, :, 3])
+    g = np.zeros((S, 8))
+    cost = 0.0
+    c = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    for s in range(S):
+        intr = np.array([K0[s, 0, 0], K0[s, 0, 2], K0[s, 1, 2], 0.0 if extra0 is None else extra0[s, 0]])
+        for p in np.nonzero(masks[s])[0]:
+            r = np.zeros(2); Jp = np.zeros(12); Ji = np.zeros(4); Jx = np.zeros(6)
+            X = np.ascontiguousarray(pts0[p])
+            L.bao_obs_eval(ctypes.c_int(OB.MODEL[cam_type]), c(q[s]), c(t[s]), c(intr), c(X),
+                           ctypes.c_double(float(tracks[s, p, 0])), ctypes.c_double(float(tracks[s, p, 1])), c(r), c(Jp),
+                           c(Ji), c(Jx))
+            F = np.concatenate([Jp.reshape(2, 6), Ji.reshape(2, 2)], 1)
+            g[s] += F.T @ r
+            cost += float(r @ r)
+    return g, cost
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cam_type = "SIMPLE_RADIAL"
+    sc = make_scene(6, 90, cam_type, shared_camera=False, seed=5)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=5)
+    T = lambda x: torch.from_numpy(np.ascontiguousarray(x))
+    tr, mk, pt, (lo, hi) = shard_slice(T(sc.tracks), T(sc.mask), T(pts0), rank, world)
+    # the shard compiles into a well-formed device problem (host logic runs on CPU tensors too)
+    prob, valid_idx, deleted = BA.compile_problem(pt, T(ext0), T(K0), tr, mk, T(extra0), False, cam_type)
+    n_obs = torch.tensor([prob.num_obs], dtype=torch.int64)
+    cam_counts = (prob.col_ptr[1:] - prob.col_ptr[:-1]).to(torch.int64)
+    g, cost = _camera_side(sc, ext0, K0, extra0, pt.numpy(), tr.numpy(), mk.numpy(), cam_type)
+    buf = torch.from_numpy(np.concatenate([g.ravel(), [cost]]))
+    dist.all_reduce(n_obs)
+    dist.all_reduce(cam_counts)
+    dist.all_reduce(buf)                       # what ShardedBA does with reduce buffer 0 over RCCL
+    gmax = torch.tensor([float(np.abs(g).max())], dtype=torch.float64)
+    dist.all_reduce(gmax, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        out.put((int(n_obs), cam_counts.numpy(), buf.numpy(), float(gmax), (lo, hi)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_sharded_camera_blocks_sum_to_global():
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    n_obs, cam_counts, buf, gmax, _ = out.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sc = make_scene(6, 90, "SIMPLE_RADIAL", shared_camera=False, seed=5)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=5)
+    assert n_obs == int(sc.mask.sum())
+    assert np.array_equal(cam_counts, sc.mask.sum(1))
+    g, cost = _camera_side(sc, ext0, K0, extra0, pts0, sc.tracks, sc.mask, "SIMPLE_RADIAL")
+    np.testing.assert_allclose(buf[:-1].reshape(6, 8), g, rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(buf[-1], cost, rtol=1e-12)
+    assert gmax <= np.abs(g).max() * 1.0000001 + 1e-12

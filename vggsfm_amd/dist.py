@@ -1,0 +1,117 @@
+"""Multi-GPU bundle adjustment: tracks sharded by 3D point, cameras replicated, one all-reduce of the
+per-camera blocks / reduced camera system per LM iteration.
+
+The reference has no distributed code at all; its serial chunking over the track axis
+(vggsfm/utils/triangulation.py:712-758, triangulation_helpers.py:167-197) is the evidence that tracks are
+independent.  Every residual touches exactly one point, so V_p, g_p, the Schur contribution and the
+back-substitution of a point are rank-local; what couples the ranks is only the camera side:
+
+  phase 0 LINEARIZE  local U_c = sum F^T F, g_c = sum F^T r, cost        -> all-reduce SUM  (C*(BD^2+BD+1) doubles)
+  phase 1 SCHUR      local reduced system S, rhs of the rank's points     -> all-reduce SUM  (n^2 + n doubles)
+                     local max |g_p|                                       -> all-reduce MAX  (1 double)
+  phase 2 STEP       every rank factors S redundantly, back-substitutes its points,
+                     local candidate cost / model change / step norm       -> all-reduce SUM  (4 doubles)
+  phase 3 UPDATE     identical trust-region decision on every rank
+
+One process per GPU, ``torch.distributed`` backend "nccl" (= RCCL over xGMI on ROCm).  The collectives run
+on the same stream as the kernels, so the host never synchronises inside the loop.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from . import ba as BA
+from .ba_options import LOSS_ID, BundleAdjustmentOptions
+
+
+def partition_points(obs_per_point, world_size):
+    """Contiguous point ranges balanced by observation count (prefix sum of the CSR row lengths).
+    Returns a (world_size+1,) long tensor of boundaries, boundaries[0] = 0, boundaries[-1] = P."""
+    counts = obs_per_point.to(torch.int64)
+    P = counts.shape[0]
+    csum = torch.cumsum(counts, 0)
+    total = int(csum[-1].item()) if P > 0 else 0
+    bounds = [0]
+    for r in range(1, world_size):
+        target = total * r / world_size
+        idx = int(torch.searchsorted(csum, torch.tensor(target, dtype=csum.dtype, device=csum.device)).item())
+        bounds.append(max(bounds[-1], min(idx, P)))
+    bounds.append(P)
+    return torch.tensor(bounds, dtype=torch.long)
+
+
+def shard_slice(tracks, masks, points3d, rank, world_size):
+    """The rank's contiguous slice of the track axis, balanced by observation count."""
+    b = partition_points(masks.sum(0), world_size)
+    lo, hi = int(b[rank]), int(b[rank + 1])
+    return tracks[:, lo:hi], masks[:, lo:hi], points3d[lo:hi], (lo, hi)
+
+
+class ShardedBA:
+    """LM loop of one rank's DeviceProblem with the collectives interleaved (also used with world_size 1)."""
+
+    def __init__(self, problem, options=None, rank=0, world_size=1, all_reduce=None):
+        self.L = _lib.lib()
+        self.problem = problem
+        self.options = options or BundleAdjustmentOptions()
+        problem.refine_focal = self.options.refine_focal_length
+        problem.refine_extra = self.options.refine_extra_params
+        problem.loss = LOSS_ID[self.options.loss_function_type]
+        problem.loss_scale = self.options.loss_function_scale
+        self.rank, self.world = rank, world_size
+        self.cp = problem.c_struct()
+        self.co = BA._c_options(self.options)
+        nbytes = int(self.L.vgg_ba_workspace_bytes(ctypes.byref(self.cp), ctypes.byref(self.co)))
+        self.nbytes = nbytes
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=problem.pts.device)
+        self.bufs = []
+        for which in range(4):
+            p = ctypes.POINTER(ctypes.c_double)()
+            cnt = ctypes.c_size_t()
+            _lib.check(self.L.vgg_ba_reduce_buffer(ctypes.byref(self.cp), ctypes.byref(self.co), _lib.ptr(self.ws), which,
+                                                   ctypes.byref(p), ctypes.byref(cnt)), "vgg_ba_reduce_buffer")
+            off = ctypes.addressof(p.contents) - self.ws.data_ptr()
+            self.bufs.append(self.ws[off:off + 8 * cnt.value].view(torch.float64))
+        if all_reduce is None and world_size > 1:
+            import torch.distributed as dist
+
+            def all_reduce(t, op):
+                dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+        self._all_reduce = all_reduce
+
+    def begin(self):
+        _lib.check(self.L.vgg_ba_begin(ctypes.byref(self.cp), ctypes.byref(self.co), _lib.ptr(self.ws),
+                                       ctypes.c_size_t(self.nbytes), self.rank, self.world, _lib.stream_ptr()), "vgg_ba_begin")
+
+    def _phase(self, i):
+        _lib.check(self.L.vgg_ba_phase(ctypes.byref(self.cp), ctypes.byref(self.co), _lib.ptr(self.ws), i,
+                                       _lib.stream_ptr()), "vgg_ba_phase")
+
+    def iteration(self):
+        ar = self._all_reduce if self.world > 1 else None
+        self._phase(0)
+        if ar:
+            ar(self.bufs[0], "sum")
+        self._phase(1)
+        if ar:
+            ar(self.bufs[1], "sum")
+            ar(self.bufs[2], "max")
+        self._phase(2)
+        if ar:
+            ar(self.bufs[3], "sum")
+        self._phase(3)
+
+    def finish(self, log_cap=0):
+        summ = _lib.BASummary()
+        log = (_lib.BAIteration * max(log_cap, 1))()
+        _lib.check(self.L.vgg_ba_finish(ctypes.byref(self.cp), ctypes.byref(self.co), _lib.ptr(self.ws), ctypes.byref(summ),
+                                        log if log_cap else None, log_cap, _lib.stream_ptr()), "vgg_ba_finish")
+        return BA._summary_dict(summ, log, summ.num_log if log_cap else 0)
+
+    def solve(self):
+        """Whole solve: device-side termination makes the trailing iterations no-ops."""
+        self.begin()
+        for _ in range(self.options.solver_options.max_num_iterations + 1):
+            self.iteration()
+        return self.finish(self.options.solver_options.max_num_iterations + 2)

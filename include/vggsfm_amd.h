@@ -111,7 +111,8 @@ typedef struct {
   const uint8_t* pt_const;    /* [num_pts] or NULL */
   /* Schur tile work list (device) */
   int32_t num_chunks;
-  const int32_t* chunk_desc;  /* [num_chunks,4] = groupI, groupJ, entry_begin, entry_end */
+  const int32_t* chunk_desc;  /* [num_chunks,6] = groupI, groupJ, tile_entry_begin, tile_entry_end, j, J:
+                                 workgroup j of the J of its tile takes the 32-entry sub-chunks j, j+J, ... */
   const int32_t* entries;     /* [num_entries,4] = point, segment_A, segment_B, maskA | maskB<<16
                                  (bit l of a mask: camera group*16+l observes the point) */
   int32_t num_segments;       /* segments: runs of one point's observations inside one camera group */

@@ -96,9 +96,12 @@ def test_compile_problem_matches_oracle_construction(S, N):
     seg_first = {int(sg): int(np.nonzero(seg_of == sg)[0][0]) for sg in np.unique(seg_of)}
     covered = {}
     seen_entries = np.zeros(len(ent), bool)
-    for gI, gJ, b, e in desc:
-        assert gI <= gJ and 0 < e - b <= BA.CHUNK
-        for k in range(b, e):
+    for gI, gJ, tb, te, j, J in desc:
+        # workgroup j of J of the tile sweeps the strided sub-chunks j, j+J, ... of SUB entries
+        assert gI <= gJ and 0 <= j < J and J == -(-(te - tb) // BA.CHUNK)
+        own = [k for s0 in range(tb + j * BA.SUB, te, J * BA.SUB) for k in range(s0, min(s0 + BA.SUB, te))]
+        assert len(own) <= BA.CHUNK + BA.SUB
+        for k in own:
             assert not seen_entries[k]
             seen_entries[k] = True
             p, sa, sb, msk = ent[k]

@@ -25,6 +25,7 @@ from .ba_options import LOSS_ID, TERMINATION, BundleAdjustmentOptions
 MODEL_ID = {"SIMPLE_PINHOLE": 0, "SIMPLE_RADIAL": 1}
 GROUP = 16          # cameras per Schur tile side (must match kGroup in csrc/ba.hip)
 CHUNK = 1024        # tile entries per workgroup
+SUB = 32          # entries per strided sub-chunk (kSub in csrc/ba.hip)
 
 
 # ------------------------------------------------------------------ rotations (Eigen conventions)
@@ -119,8 +120,9 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK):
 
     A *segment* is the run of one point's observations that falls into one group of `group`
     consecutive cameras; an *entry* pairs two segments (gI <= gJ) of the same point; entries are
-    sorted by tile (gI, gJ) and cut into chunks of <= `chunk` entries, one workgroup each.
-    Returns (chunk_desc (n,4) int32 = gI,gJ,begin,end ; entries (E,4) int32 = point,segA,segB,maskA|maskB<<16 ;
+    sorted by tile (gI, gJ) and by point inside a tile; a tile with k entries gets J = ceil(k / `chunk`)
+    workgroups ("chunks"), workgroup j taking the sub-chunks j, j+J, ... of SUB entries (kSub in ba.hip).
+    Returns (chunk_desc (n,6) int32 = gI,gJ,tile_begin,tile_end,j,J ; entries (E,4) int32 = point,segA,segB,maskA|maskB<<16 ;
     tile_desc (T,4) int32 = gI,gJ,chunk_begin,chunk_end ; obs_slot (O,) int32 = segment*16 + camera%16 ;
     number of segments)."""
     dev = obs_cam.device
@@ -128,7 +130,7 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK):
     P = row_ptr.shape[0] - 1
     if O == 0:
         z = torch.zeros((0, 4), dtype=torch.int32, device=dev)
-        return z, z.clone(), z.clone(), torch.zeros(0, dtype=torch.int32, device=dev), 0
+        return torch.zeros((0, 6), dtype=torch.int32, device=dev), z, z.clone(), torch.zeros(0, dtype=torch.int32, device=dev), 0
     counts = (row_ptr[1:] - row_ptr[:-1]).long()
     obs_pt = torch.repeat_interleave(torch.arange(P, device=dev), counts)
     grp = (obs_cam // group).long()
@@ -160,9 +162,8 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK):
     ctile = torch.repeat_interleave(torch.arange(ukeys.shape[0], device=dev), nchunks)
     cfirst = torch.cumsum(nchunks, 0) - nchunks
     local = torch.arange(ctile.shape[0], device=dev) - cfirst[ctile]
-    begin = tile_start[ctile] + local * chunk
-    end = torch.minimum(begin + chunk, tile_start[ctile] + kcounts[ctile])
-    chunk_desc = torch.stack([ukeys[ctile] // ngroups, ukeys[ctile] % ngroups, begin, end], 1).to(torch.int32)
+    chunk_desc = torch.stack([ukeys[ctile] // ngroups, ukeys[ctile] % ngroups, tile_start[ctile],
+                              tile_start[ctile] + kcounts[ctile], local, nchunks[ctile]], 1).to(torch.int32)
     tile_desc = torch.stack([ukeys // ngroups, ukeys % ngroups, cfirst, cfirst + nchunks], 1).to(torch.int32)
     obs_slot = (seg_id * group + obs_cam.long() % group).to(torch.int32)
     return chunk_desc.contiguous(), entries.contiguous(), tile_desc.contiguous(), obs_slot.contiguous(), int(nseg)

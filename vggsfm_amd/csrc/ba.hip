@@ -34,6 +34,7 @@ int cholesky_solve_enqueue(double* A, double* b, int n, double* inv_blocks, int3
 size_t cholesky_workspace_bytes(int n);
 
 constexpr int kGroup = 16;       // cameras per Schur tile side
+constexpr int kSub = 32;         // entries per strided sub-chunk of a Schur workgroup (see schur_tile_kernel)
 constexpr int kMaxWG = 2048;
 
 struct Ctl {
@@ -599,8 +600,17 @@ __global__ __launch_bounds__(256) void schur_tile_kernel(Ws w, const int32_t* __
   if (w.ctl->done) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: MFMAs only behind scalar control flow
-  const int gI = chunk_desc[4 * blockIdx.x], gJ = chunk_desc[4 * blockIdx.x + 1];
-  const int e0 = chunk_desc[4 * blockIdx.x + 2], e1 = chunk_desc[4 * blockIdx.x + 3];
+  // chunk = the j-th of the J workgroups of tile (gI,gJ).  The tile's entry list [e0,e1) is sorted by point;
+  // workgroup j takes the sub-chunks j, j+J, j+2J, ... of kSub entries, so all workgroups of all tiles sweep
+  // the point range at the same relative rate and the (up to ~G) re-reads of one point's segments by
+  // different tiles fall close together in time (they hit the L2 / Infinity Cache instead of HBM).
+  const int gI = chunk_desc[6 * blockIdx.x], gJ = chunk_desc[6 * blockIdx.x + 1];
+  const int e0 = chunk_desc[6 * blockIdx.x + 2], e1 = chunk_desc[6 * blockIdx.x + 3];
+  const int cj = chunk_desc[6 * blockIdx.x + 4], cJ = chunk_desc[6 * blockIdx.x + 5];
+  constexpr int BPS = kSub / 4;                   // batches of 4 entries per sub-chunk
+  const int nsub = (e1 - e0 + kSub - 1) / kSub;
+  const int nb = ((nsub - cj + cJ - 1) / cJ) * BPS;             // batches of this workgroup
+  auto ebase = [&](int b) -> int { return e0 + ((b / BPS) * cJ + cj) * kSub + (b % BPS) * 4; };
   const bool diag = (gI == gJ);
   const int4* ent = reinterpret_cast<const int4*>(entries);
   const int wr = wave >> 1, wc = wave & 1;
@@ -657,14 +667,14 @@ __global__ __launch_bounds__(256) void schur_tile_kernel(Ws w, const int32_t* __
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks) { const int k = 4 * ks + lk; koff[ks] = (k / 3) * SEG + (k % 3); }
 
-  issue_loads(load_seg_index(e0));
-  int seg_next = load_seg_index(e0 + 4);
+  issue_loads(load_seg_index(ebase(0)));
+  int seg_next = load_seg_index(ebase(1));
   write_lds(0);
   __syncthreads();
   int buf = 0;
-  for (int eb = e0; eb < e1; eb += 4, buf ^= 1) {
-    issue_loads(seg_next);                        // batch eb+4 (zeros past the end of the chunk)
-    seg_next = load_seg_index(eb + 8);
+  for (int b = 0; b < nb; ++b, buf ^= 1) {
+    issue_loads(seg_next);                        // batch b+1 (zeros past the end of the tile's list)
+    seg_next = load_seg_index(ebase(b + 2));
     const double* As = &Ops[buf][0][0][0];
     const double* Bs = &Ops[buf][diag ? 0 : 1][0][0];
 #pragma unroll

@@ -111,6 +111,8 @@ typedef struct {
   const uint8_t* pt_const;    /* [num_pts] or NULL */
   /* Schur tile work list (device) */
   int32_t num_chunks;
+  int32_t num_offdiag_chunks; /* chunks [0, num_offdiag_chunks) belong to off-diagonal tiles (groupI < groupJ), the rest
+                                 to diagonal tiles; the two sets are separate launches */
   const int32_t* chunk_desc;  /* [num_chunks,6] = groupI, groupJ, tile_entry_begin, tile_entry_end, j, J:
                                  workgroup j of the J of its tile takes the 32-entry sub-chunks j, j+J, ... */
   const int32_t* entries;     /* [num_entries,4] = point, segment_A, segment_B, maskA | maskB<<16

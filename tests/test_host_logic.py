@@ -98,9 +98,8 @@ def test_compile_problem_matches_oracle_construction(S, N):
     seen_entries = np.zeros(len(ent), bool)
     for gI, gJ, tb, te, j, J in desc:
         # workgroup j of J of the tile sweeps the strided sub-chunks j, j+J, ... of SUB entries
-        assert gI <= gJ and 0 <= j < J and J == -(-(te - tb) // BA.CHUNK)
+        assert gI <= gJ and 0 <= j < J and J <= max(1, -(-(te - tb) // BA.MIN_CHUNK))
         own = [k for s0 in range(tb + j * BA.SUB, te, J * BA.SUB) for k in range(s0, min(s0 + BA.SUB, te))]
-        assert len(own) <= BA.CHUNK + BA.SUB
         for k in own:
             assert not seen_entries[k]
             seen_entries[k] = True
@@ -119,6 +118,7 @@ def test_compile_problem_matches_oracle_construction(S, N):
                         continue
                     covered[(p, int(a), int(bb))] = covered.get((p, int(a), int(bb)), 0) + 1
     assert seen_entries.all()
+    assert len(desc) <= max(2 * 256 * 4, len(prob.tile_desc))  # one resident round per launch (off-diag, diag)
     # tiles: consecutive chunk ranges that cover all chunks exactly once, one tile per (gI, gJ)
     td = prob.tile_desc.numpy()
     assert td[0, 2] == 0 and td[-1, 3] == len(desc) and (td[1:, 2] == td[:-1, 3]).all()
@@ -142,3 +142,26 @@ def test_normalize_matches_oracle():
     e2, p2 = OB.normalize_reconstruction(sc.extrinsics, sc.points3D, alive)
     np.testing.assert_allclose(e1.numpy(), e2, rtol=1e-13, atol=1e-13)
     np.testing.assert_allclose(p1.numpy(), p2, rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("max_chunks", [1, 7, 40, 100000])
+def test_schur_chunks_adaptive_cover(max_chunks):
+    """Adaptive chunk size: every entry belongs to exactly one workgroup's strided sub-chunks and the
+    workgroup count respects the device capacity (or is one per tile when there are more tiles than slots)."""
+    torch.manual_seed(0)
+    S, P = 40, 300
+    m = torch.rand(S, P) < 0.4
+    m[:2] = True
+    pm = torch.nonzero(m.t())
+    obs_cam = pm[:, 1].to(torch.int32)
+    row_ptr = torch.zeros(P + 1, dtype=torch.int32)
+    row_ptr[1:] = torch.cumsum(m.sum(0), 0).to(torch.int32)
+    desc, ent, tiles, slot, nseg = BA.build_schur_tiles(row_ptr, obs_cam, max_chunks=max_chunks)
+    seen = np.zeros(len(ent), int)
+    for gI, gJ, tb, te, j, J in desc.numpy():
+        for s0 in range(tb + j * BA.SUB, te, J * BA.SUB):
+            seen[s0:min(s0 + BA.SUB, te)] += 1
+    assert (seen == 1).all()
+    assert len(desc) <= max(2 * max_chunks, len(tiles))
+    td = tiles.numpy()
+    assert td[0, 2] == 0 and td[-1, 3] == len(desc) and (td[1:, 2] == td[:-1, 3]).all()

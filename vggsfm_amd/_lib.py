@@ -25,7 +25,8 @@ class BAProblem(ctypes.Structure):
                 ("pts", ctypes.c_void_p), ("row_ptr", ctypes.c_void_p), ("obs_cam", ctypes.c_void_p),
                 ("obs_uv", ctypes.c_void_p), ("col_ptr", ctypes.c_void_p), ("cobs_pt", ctypes.c_void_p),
                 ("cobs_uv", ctypes.c_void_p), ("cam_const", ctypes.c_void_p), ("intr_const", ctypes.c_void_p),
-                ("pt_const", ctypes.c_void_p), ("num_chunks", ctypes.c_int32), ("chunk_desc", ctypes.c_void_p),
+                ("pt_const", ctypes.c_void_p), ("num_chunks", ctypes.c_int32), ("num_offdiag_chunks", ctypes.c_int32),
+                ("chunk_desc", ctypes.c_void_p),
                 ("entries", ctypes.c_void_p), ("num_segments", ctypes.c_int32), ("obs_slot", ctypes.c_void_p),
                 ("num_tiles", ctypes.c_int32), ("tile_desc", ctypes.c_void_p)]
 

@@ -25,7 +25,8 @@ from .ba_options import LOSS_ID, TERMINATION, BundleAdjustmentOptions
 MODEL_ID = {"SIMPLE_PINHOLE": 0, "SIMPLE_RADIAL": 1}
 GROUP = 16          # cameras per Schur tile side (must match kGroup in csrc/ba.hip)
 CHUNK = 1024        # tile entries per workgroup
-SUB = 32          # entries per strided sub-chunk (kSub in csrc/ba.hip)
+SUB = 32            # entries per strided sub-chunk (kSub in csrc/ba.hip)
+MIN_CHUNK = 128     # lower bound of the adaptive chunk size
 
 
 # ------------------------------------------------------------------ rotations (Eigen conventions)
@@ -94,6 +95,7 @@ class DeviceProblem:
     refine_extra: bool = True
     loss: int = 0
     loss_scale: float = 1.0
+    num_offdiag_chunks: int = -1      # derived from chunk_desc on first use
 
     @property
     def num_obs(self):
@@ -110,18 +112,21 @@ class DeviceProblem:
             t = getattr(self, name)
             setattr(P, name, None if t is None else t.data_ptr())
         P.num_chunks = self.chunk_desc.shape[0]
+        if self.num_offdiag_chunks < 0:
+            self.num_offdiag_chunks = int((self.chunk_desc[:, 0] != self.chunk_desc[:, 1]).sum().item())
+        P.num_offdiag_chunks = self.num_offdiag_chunks
         P.num_tiles = self.tile_desc.shape[0]
         P.num_segments = self.num_segments
         return P
 
 
-def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK):
+def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=None):
     """Block-sparse Schur work list (device, torch ops; structure is fixed for the whole solve).
 
     A *segment* is the run of one point's observations that falls into one group of `group`
     consecutive cameras; an *entry* pairs two segments (gI <= gJ) of the same point; entries are
     sorted by tile (gI, gJ) and by point inside a tile; a tile with k entries gets J = ceil(k / `chunk`)
-    workgroups ("chunks"), workgroup j taking the sub-chunks j, j+J, ... of SUB entries (kSub in ba.hip).
+    workgroups ("chunks", off-diagonal tiles first), workgroup j taking the sub-chunks j, j+J, ... of SUB entries (kSub in ba.hip).
     Returns (chunk_desc (n,6) int32 = gI,gJ,tile_begin,tile_end,j,J ; entries (E,4) int32 = point,segA,segB,maskA|maskB<<16 ;
     tile_desc (T,4) int32 = gI,gJ,chunk_begin,chunk_end ; obs_slot (O,) int32 = segment*16 + camera%16 ;
     number of segments)."""
@@ -152,13 +157,32 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK):
     A = torch.repeat_interleave(idx, npair)
     pair_start = torch.cumsum(npair, 0) - npair
     B = A + (torch.arange(total, device=dev) - pair_start[A])
-    key = seg_grp[A] * ngroups + seg_grp[B]
+    # tile key: off-diagonal tiles first, then the diagonal ones (they are separate launches)
+    key = seg_grp[A] * ngroups + seg_grp[B] + (seg_grp[A] == seg_grp[B]).long() * (ngroups * ngroups)
     order = torch.argsort(key, stable=True)
     A, B, key = A[order], B[order], key[order]
     entries = torch.stack([seg_pt[A], A, B, seg_mask[A] | (seg_mask[B] << 16)], 1).to(torch.int32)
     ukeys, kcounts = torch.unique_consecutive(key, return_counts=True)
     tile_start = torch.cumsum(kcounts, 0) - kcounts
-    nchunks = (kcounts + chunk - 1) // chunk
+    is_diag = ukeys >= ngroups * ngroups
+    ukeys = ukeys % (ngroups * ngroups)
+    csize = torch.full_like(kcounts, chunk)
+    if max_chunks is not None:
+        # one resident round per launch: the smallest chunk size (multiple of SUB, >= MIN_CHUNK) whose workgroup
+        # count fits the device (CUs x workgroups per CU), so no workgroup starts late and runs alone on its CU
+        for sel in (~is_diag, is_diag):
+            if not bool(sel.any()):
+                continue
+            kc = kcounts[sel]
+            lo, hi = MIN_CHUNK // SUB, max(MIN_CHUNK // SUB, int(-(-int(kc.max().item()) // SUB)))
+            fits = lambda c: int(((kc + c * SUB - 1) // (c * SUB)).sum().item()) <= max_chunks
+            if not fits(hi):
+                lo = hi                             # more tiles than slots: one workgroup per tile
+            while lo < hi:
+                mid = (lo + hi) // 2
+                lo, hi = (lo, mid) if fits(mid) else (mid + 1, hi)
+            csize[sel] = lo * SUB
+    nchunks = (kcounts + csize - 1) // csize
     ctile = torch.repeat_interleave(torch.arange(ukeys.shape[0], device=dev), nchunks)
     cfirst = torch.cumsum(nchunks, 0) - nchunks
     local = torch.arange(ctile.shape[0], device=dev) - cfirst[ctile]
@@ -225,7 +249,9 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
         cam_const[0] = 1                            # SetConstantCamPose(first registered image)
         if S > 1:
             cam_const[1] = 2                        # SetConstantCamPositions(second image, {0})
-    chunk_desc, entries, tile_desc, obs_slot, nseg = build_schur_tiles(row_ptr, obs_cam)
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == "cuda" else 256
+    slots = cus * (4 if shared_camera else 2)       # resident schur_tile workgroups (occupancy of the BD variant)
+    chunk_desc, entries, tile_desc, obs_slot, nseg = build_schur_tiles(row_ptr, obs_cam, max_chunks=slots)
     prob = DeviceProblem(cam_q, cam_t, intr, pts, row_ptr, obs_cam, obs_uv, col_ptr, cobs_pt, cobs_uv, chunk_desc,
                          entries, tile_desc, obs_slot, nseg, MODEL_ID[camera_type], cam_const=cam_const)
     return prob, valid_idx, deleted

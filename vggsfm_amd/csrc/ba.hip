@@ -34,6 +34,9 @@ int cholesky_solve_enqueue(double* A, double* b, int n, double* inv_blocks, int3
 size_t cholesky_workspace_bytes(int n);
 
 constexpr int kGroup = 16;       // cameras per Schur tile side
+#ifndef VGG_ABLATE
+#define VGG_ABLATE 0
+#endif
 constexpr int kSub = 32;         // entries per strided sub-chunk of a Schur workgroup (see schur_tile_kernel)
 constexpr int kMaxWG = 2048;
 
@@ -511,16 +514,18 @@ __global__ __launch_bounds__(256) void point_pass_kernel(DevProblem pb, Ws w, vg
           eval_full<KD>(d, pb.cam_q + 4 * c, pb.cam_t + 3 * c, pb.intr + 4 * a, X, pb.obs_uv[o],
                         pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
         }
-        double* y = w.Y + (size_t)pb.obs_slot[o] * bdt * 3;
+        // segment layout: [component 0..2][slot 0..15][row 0..bdt-1]  (three rows of the K dimension)
+        const int slot = pb.obs_slot[o], rt = kGroup * bdt;
+        double* y = w.Y + (size_t)(slot >> 4) * (3 * rt) + (slot & 15) * bdt;
 #pragma unroll
         for (int i = 0; i < BD; ++i) {
           if (i < bdt) {
             const double sc = (i < 6) ? w.scale_c[6 * c + i] : w.scale_c[6 * d.C + KD * c + (i - 6)];
             const double w0 = F[i] * E[0] + F[BD + i] * E[3], w1 = F[i] * E[1] + F[BD + i] * E[4],
                          w2 = F[i] * E[2] + F[BD + i] * E[5];
-            y[i * 3 + 0] = sc * (w0 * Gm[0]);
-            y[i * 3 + 1] = sc * (w0 * Gm[1] + w1 * Gm[3]);
-            y[i * 3 + 2] = sc * (w0 * Gm[2] + w1 * Gm[4] + w2 * Gm[5]);
+            y[i] = sc * (w0 * Gm[0]);
+            y[rt + i] = sc * (w0 * Gm[1] + w1 * Gm[3]);
+            y[2 * rt + i] = sc * (w0 * Gm[2] + w1 * Gm[4] + w2 * Gm[5]);
           }
         }
       }
@@ -588,15 +593,21 @@ __global__ void begin_iteration_kernel(Ws w, vgg_ba_options opt) {
 // NH x NH accumulators in registers for the whole chunk; all MFMAs are unconditional (scalar loop bounds).
 typedef double f64x4_t __attribute__((ext_vector_type(4)));
 
-template <int BD>
-__global__ __launch_bounds__(256) void schur_tile_kernel(Ws w, const int32_t* __restrict__ chunk_desc,
-                                                         const int32_t* __restrict__ entries) {
+template <int BD, bool DIAG>
+__global__ __launch_bounds__(256, (BD == 6 ? 4 : 2)) void schur_tile_kernel(Ws w, const int32_t* __restrict__ chunk_desc,
+                                                         const int32_t* __restrict__ entries, int chunk0) {
   constexpr int YS = BD * 3;                      // doubles per Y block
   constexpr int SEG = kGroup * YS;                // doubles per segment (16 slots)
   constexpr int R = kGroup * BD;                  // rows / cols of the tile
   constexpr int NT = R / 16;                      // 16x16 sub-tiles per side
   constexpr int NH = (NT + 1) / 2;                // sub-tile rows (cols) of one wavefront
-  __shared__ __attribute__((aligned(16))) double Ops[2][2][4][SEG];   // [buffer][side][entry][slot][r][c]
+  // [buffer][side][entry of the batch][component c][tile row]: a staged segment is a linear copy of the global
+  // one, except that the tile rows of the odd entries are XOR-swizzled by 16 (double2 index ^ 8) when the entry
+  // stride is a multiple of 256 bytes.  K step ks of the MFMAs takes component c = ks of the four entries
+  // (lane group lk = entry), so the four 128-byte runs one operand fetch touches fall two and two into the
+  // two halves of the LDS banks (conflict-free ds_read_b64).
+  constexpr int SWZ = ((SEG * 8) % 256 == 0) ? 16 : 0;
+  __shared__ __attribute__((aligned(16))) double Ops[2][DIAG ? 1 : 2][4][SEG];
   if (w.ctl->done) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: MFMAs only behind scalar control flow
@@ -604,34 +615,32 @@ __global__ __launch_bounds__(256) void schur_tile_kernel(Ws w, const int32_t* __
   // workgroup j takes the sub-chunks j, j+J, j+2J, ... of kSub entries, so all workgroups of all tiles sweep
   // the point range at the same relative rate and the (up to ~G) re-reads of one point's segments by
   // different tiles fall close together in time (they hit the L2 / Infinity Cache instead of HBM).
-  const int gI = chunk_desc[6 * blockIdx.x], gJ = chunk_desc[6 * blockIdx.x + 1];
-  const int e0 = chunk_desc[6 * blockIdx.x + 2], e1 = chunk_desc[6 * blockIdx.x + 3];
-  const int cj = chunk_desc[6 * blockIdx.x + 4], cJ = chunk_desc[6 * blockIdx.x + 5];
+  const int chunk = chunk0 + blockIdx.x;
+  const int e0 = chunk_desc[6 * chunk + 2], e1 = chunk_desc[6 * chunk + 3];
+  const int cj = chunk_desc[6 * chunk + 4], cJ = chunk_desc[6 * chunk + 5];
   constexpr int BPS = kSub / 4;                   // batches of 4 entries per sub-chunk
   const int nsub = (e1 - e0 + kSub - 1) / kSub;
   const int nb = ((nsub - cj + cJ - 1) / cJ) * BPS;             // batches of this workgroup
   auto ebase = [&](int b) -> int { return e0 + ((b / BPS) * cJ + cj) * kSub + (b % BPS) * 4; };
-  const bool diag = (gI == gJ);
+  constexpr bool diag = DIAG;
   const int4* ent = reinterpret_cast<const int4*>(entries);
-  const int wr = wave >> 1, wc = wave & 1;
-  const int rb0 = wr * NH, cb0 = wc * NH;
   f64x4_t acc[NH][NH];
 #pragma unroll
   for (int i = 0; i < NH; ++i)
 #pragma unroll
     for (int j = 0; j < NH; ++j) acc[i][j] = (f64x4_t){0.0, 0.0, 0.0, 0.0};
 
-  // Staging of a batch = linear copy of its (up to) 8 segments, 32 threads per segment.  It is split so that
+  // Staging of a batch = linear copy of its 8 (diagonal tile: 4) segments, 32 (64) threads per segment.  It is split so that
   // no wavefront ever waits on a dependent global load: the segment index of batch n+2 is loaded while
   // the segment data of batch n+1 is in flight, and that data is written to LDS only after the MFMAs of
   // batch n (async-stage split).
   constexpr int V = SEG / 2;                      // double2 per segment
-  constexpr int NV = (V + 31) / 32;               // double2 per thread per batch
-  const int sseg = tid >> 5, l32 = tid & 31;
-  const int se = sseg >> 1, sside = sseg & 1;
-  const bool sactive = !(diag && sside);
+  constexpr int TPS = DIAG ? 64 : 32;             // threads per segment
+  constexpr int NV = (V + TPS - 1) / TPS;         // double2 per thread per batch
+  const int sseg = tid / TPS, l32 = tid % TPS;
+  const int se = DIAG ? sseg : (sseg >> 1), sside = DIAG ? 0 : (sseg & 1);
   auto load_seg_index = [&](int eb) -> int {      // -1: no such entry (tail of the chunk)
-    if (!sactive || eb + se >= e1) return -1;
+    if (eb + se >= e1) return -1;
     const int4 en = ent[eb + se];
     return sside ? en.z : en.y;
   };
@@ -640,69 +649,118 @@ __global__ __launch_bounds__(256) void schur_tile_kernel(Ws w, const int32_t* __
     const double2* src = reinterpret_cast<const double2*>(w.Y) + (size_t)(seg_index < 0 ? 0 : seg_index) * V;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int off = l32 + 32 * i;
+      const int off = l32 + TPS * i;
       sv[i] = (seg_index >= 0 && off < V) ? src[off] : make_double2(0.0, 0.0);
     }
   };
   auto write_lds = [&](int buf) {
-    if (!sactive) return;
     double2* dst = reinterpret_cast<double2*>(&Ops[buf][sside][se][0]);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int off = l32 + 32 * i;
-      if (off < V) dst[off] = sv[i];
+      const int off = l32 + TPS * i;
+      if (off < V) dst[off ^ ((se & 1) * (SWZ / 2))] = sv[i];
     }
   };
-  // operand addressing: tile row rr = 16 rb + (lane & 15) lives at slot*YS + r*3 inside a segment; the K
-  // index k = 4 ks + (lane >> 4) selects entry e = k / 3 and component c = k % 3
+  // operand addressing: entry e = lane >> 4 of the batch, component c = ks, tile row rr = 16 rb + (lane & 15)
   const int li = lane & 15, lk = lane >> 4;
-  int rowoffA[NH], rowoffB[NH];
-#pragma unroll
-  for (int i = 0; i < NH; ++i) {
-    const int ra = min(16 * (rb0 + i) + li, R - 1), rbb = min(16 * (cb0 + i) + li, R - 1);
-    rowoffA[i] = (ra / BD) * YS + (ra % BD) * 3;
-    rowoffB[i] = (rbb / BD) * YS + (rbb % BD) * 3;
-  }
-  int koff[3];
-#pragma unroll
-  for (int ks = 0; ks < 3; ++ks) { const int k = 4 * ks + lk; koff[ks] = (k / 3) * SEG + (k % 3); }
+  // (ks enters the address as a compile-time immediate: ks R doubles)
+  const int kbase = lk * SEG, swz = (lk & 1) * SWZ;
 
   issue_loads(load_seg_index(ebase(0)));
   int seg_next = load_seg_index(ebase(1));
   write_lds(0);
   __syncthreads();
-  int buf = 0;
-  for (int b = 0; b < nb; ++b, buf ^= 1) {
-    issue_loads(seg_next);                        // batch b+1 (zeros past the end of the tile's list)
-    seg_next = load_seg_index(ebase(b + 2));
-    const double* As = &Ops[buf][0][0][0];
-    const double* Bs = &Ops[buf][diag ? 0 : 1][0][0];
-#pragma unroll
-    for (int ks = 0; ks < 3; ++ks) {
-      double a[NH], b[NH];
-#pragma unroll
-      for (int i = 0; i < NH; ++i) { a[i] = As[rowoffA[i] + koff[ks]]; b[i] = Bs[rowoffB[i] + koff[ks]]; }
-#pragma unroll
-      for (int i = 0; i < NH; ++i)
-#pragma unroll
-        for (int j = 0; j < NH; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+#if VGG_ABLATE == 2
+  issue_loads(-1);
+  write_lds(0);
+  __syncthreads();
+#endif
+  // software pipeline shared by the two sub-tile assignments below
+  auto sweep = [&](auto&& mfma_batch) {
+    int buf = 0;
+    for (int b = 0; b < nb; ++b, buf ^= 1) {
+#if VGG_ABLATE != 2                               // (profiling builds only: 1 = no MFMA, 2 = no global loads)
+      issue_loads(seg_next);                      // batch b+1 (zeros past the end of the tile's list)
+      seg_next = load_seg_index(ebase(b + 2));
+#endif
+#if VGG_ABLATE != 1
+      mfma_batch(buf);
+#endif
+      write_lds(buf ^ 1);
+      __syncthreads();
     }
-    write_lds(buf ^ 1);
-    __syncthreads();
-  }
+  };
   // partial tile of this chunk, row-major R x R (f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 reg);
   // tile_reduce_kernel sums the chunks of a tile in a fixed order (deterministic, no atomics)
-  double* part = w.tile_part + (size_t)blockIdx.x * R * R;
+  double* part = w.tile_part + (size_t)chunk * R * R;
+  auto store_subtile = [&](int rb, int cb, const f64x4_t& v) {
 #pragma unroll
-  for (int i = 0; i < NH; ++i)
+    for (int reg = 0; reg < 4; ++reg) part[(size_t)(16 * rb + lk + 4 * reg) * R + 16 * cb + li] = v[reg];
+  };
+  if constexpr (!DIAG) {
+    // off-diagonal tile: 2x2 wave grid, wave (wr,wc) owns the NH x NH block of sub-tiles at (wr NH, wc NH)
+    const int wr = wave >> 1, wc = wave & 1;
+    const int rb0 = wr * NH, cb0 = wc * NH;
+    int rowoffA[NH], rowoffB[NH];
 #pragma unroll
-    for (int j = 0; j < NH; ++j) {
-      const int rb = rb0 + i, cb = cb0 + j;
-      if (rb < NT && cb < NT) {
+    for (int i = 0; i < NH; ++i) {
+      rowoffA[i] = kbase + ((16 * min(rb0 + i, NT - 1) + li) ^ swz);
+      rowoffB[i] = kbase + ((16 * min(cb0 + i, NT - 1) + li) ^ swz);
+    }
+    sweep([&](int buf) {
+      const double* As = &Ops[buf][0][0][0];
+      const double* Bs = &Ops[buf][1][0][0];
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) part[(size_t)(16 * rb + lk + 4 * reg) * R + 16 * cb + li] = acc[i][j][reg];
+      for (int ks = 0; ks < 3; ++ks) {
+        double a[NH], bq[NH];
+#pragma unroll
+        for (int i = 0; i < NH; ++i) { a[i] = As[rowoffA[i] + ks * R]; bq[i] = Bs[rowoffB[i] + ks * R]; }
+#pragma unroll
+        for (int i = 0; i < NH; ++i)
+#pragma unroll
+          for (int j = 0; j < NH; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bq[j], acc[i][j], 0, 0, 0);
+      }
+    });
+#pragma unroll
+    for (int i = 0; i < NH; ++i)
+#pragma unroll
+      for (int j = 0; j < NH; ++j)
+        if (rb0 + i < NT && cb0 + j < NT) store_subtile(rb0 + i, cb0 + j, acc[i][j]);
+  } else {
+    // diagonal tile (A == B, symmetric): only the NT (NT + 1) / 2 sub-tiles of the lower triangle are computed;
+    // they are enumerated row by row and dealt to the 4 waves in runs of PER (wave-uniform scalar tables)
+    constexpr int NL = NT * (NT + 1) / 2;
+    constexpr int PER = (NL + 3) / 4;
+    static_assert(PER <= NH * NH, "accumulators");
+    const int t0 = wave * PER;
+    const int nmine = __builtin_amdgcn_readfirstlane(max(0, min(PER, NL - t0)));
+    int rbs[PER], cbs[PER], offA[PER], offB[PER];
+    {
+      int rb = 0, cb = 0;                           // walk to sub-tile t0
+      for (int t = 0; t < t0; ++t) { if (cb == rb) { ++rb; cb = 0; } else ++cb; }
+#pragma unroll
+      for (int t = 0; t < PER; ++t) {
+        rbs[t] = min(rb, NT - 1); cbs[t] = min(cb, NT - 1);
+        offA[t] = kbase + ((16 * rbs[t] + li) ^ swz); offB[t] = kbase + ((16 * cbs[t] + li) ^ swz);
+        if (cb == rb) { ++rb; cb = 0; } else ++cb;
       }
     }
+    sweep([&](int buf) {
+      const double* As = &Ops[buf][0][0][0];
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        double a[PER], bq[PER];
+#pragma unroll
+        for (int t = 0; t < PER; ++t) { a[t] = As[offA[t] + ks * R]; bq[t] = As[offB[t] + ks * R]; }
+#pragma unroll
+        for (int t = 0; t < PER; ++t)   // unconditional: a wave with fewer sub-tiles recomputes its last one
+          acc[t / NH][t % NH] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], bq[t], acc[t / NH][t % NH], 0, 0, 0);
+      }
+    });
+#pragma unroll
+    for (int t = 0; t < PER; ++t)
+      if (t < nmine) store_subtile(rbs[t], cbs[t], acc[t / NH][t % NH]);
+  }
 }
 
 // S[(cI,a,i),(cJ,b,j)] = - sum over the chunks of tile (gI,gJ) of the partial tiles (plain stores: every
@@ -1043,7 +1101,7 @@ struct ProfScope {
 
 struct Launch {
   Dims d; DevProblem dp; Ws w; vgg_ba_options opt; hipStream_t st; int wgB;
-  const int32_t* chunk_desc; const int32_t* entries; int num_chunks;
+  const int32_t* chunk_desc; const int32_t* entries; int num_chunks, num_offdiag_chunks;
   const int32_t* tile_desc; int num_tiles;
   double *cam_q, *cam_t, *intr, *pts;
 };
@@ -1052,6 +1110,13 @@ template <int KD>
 static void phase_linearize(const Launch& L) {
   ProfScope ps(kProfLinearize, L.st);
   cam_pass_kernel<KD, 0><<<L.d.C, 256, 0, L.st>>>(L.dp, L.w);
+}
+
+template <int BD>
+static void launch_schur_tiles(const Launch& L) {
+  const int noff = L.num_offdiag_chunks, ndiag = L.num_chunks - noff;
+  if (noff > 0) schur_tile_kernel<BD, false><<<noff, 256, 0, L.st>>>(L.w, L.chunk_desc, L.entries, 0);
+  if (ndiag > 0) schur_tile_kernel<BD, true><<<ndiag, 256, 0, L.st>>>(L.w, L.chunk_desc, L.entries, noff);
 }
 
 template <int KD>
@@ -1072,10 +1137,10 @@ static void phase_schur(const Launch& L) {
   if (L.num_chunks > 0) {
     ProfScope ps(kProfSchurTile, L.st);
     if (d.shared || KD == 0) {
-      schur_tile_kernel<6><<<L.num_chunks, 256, 0, L.st>>>(L.w, L.chunk_desc, L.entries);
+      launch_schur_tiles<6>(L);
       tile_reduce_kernel<6><<<dim3(96 * 96 / 256, L.num_tiles), 256, 0, L.st>>>(L.w, d.n_red, d.C, KD, L.tile_desc);
     } else {
-      schur_tile_kernel<6 + KD><<<L.num_chunks, 256, 0, L.st>>>(L.w, L.chunk_desc, L.entries);
+      launch_schur_tiles<6 + KD>(L);
       tile_reduce_kernel<6 + KD><<<dim3(div_up(16 * (6 + KD) * 16 * (6 + KD), 256), L.num_tiles), 256, 0, L.st>>>(L.w, d.n_red, d.C, KD, L.tile_desc);
     }
   }
@@ -1124,6 +1189,8 @@ static int make_launch(const vgg_ba_problem* pb, const vgg_ba_options* opt, void
   L->st = st;
   L->wgB = min(max(div_up(L->d.P, 4), 1), kMaxWG);
   L->chunk_desc = pb->chunk_desc; L->entries = pb->entries; L->num_chunks = pb->num_chunks;
+  L->num_offdiag_chunks = pb->num_offdiag_chunks;
+  if (pb->num_offdiag_chunks < 0 || pb->num_offdiag_chunks > pb->num_chunks) return VGG_ERR_INVALID_ARGUMENT;
   L->tile_desc = pb->tile_desc; L->num_tiles = pb->num_tiles;
   L->cam_q = pb->cam_q; L->cam_t = pb->cam_t; L->intr = pb->intr; L->pts = pb->pts;
   return VGG_OK;

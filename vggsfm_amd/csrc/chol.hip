@@ -69,7 +69,8 @@ __device__ __forceinline__ void factor_diag_lds(double* D, double* rdiag, int32_
 }
 
 __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A, int n, int nrows, int k0,
-                                                         int32_t* fail, const int32_t* skip) {
+                                                         int32_t* fail, const int32_t* skip,
+                                                         double* __restrict__ inv_blocks) {
   __shared__ double D[kNB * kLD];
   __shared__ double rdiag[kNB];
   if (skip && *skip) return;
@@ -90,6 +91,25 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
   // Column-oriented substitution: once x_k is final it is eliminated from all later columns with
   // independent FMAs, so the dependent chain is one multiply + one FMA per column (an fp64 FMA has a
   // 32-cycle dependent latency on gfx950) instead of a 528-long chain.
+  if (inv_blocks && blockIdx.x == gridDim.x - 1) {
+    // extra workgroup: T = L_kk^-T (rows of the identity pushed through the same substitution), used by the
+    // backward solve as a plain 32x32 mat-vec instead of a 32-step dependent chain.  Row-major 32x32.
+    if (tid < kNB) {
+      double x[kNB];
+#pragma unroll
+      for (int c = 0; c < kNB; ++c) x[c] = (c == tid) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < kNB; ++k) {
+        x[k] *= rdiag[k];
+#pragma unroll
+        for (int c = k + 1; c < kNB; ++c) x[c] -= x[k] * D[c * kLD + k];
+      }
+      double* T = inv_blocks + (size_t)(k0 / kNB) * kNB * kNB + tid * kNB;
+#pragma unroll
+      for (int c = 0; c < kNB; ++c) T[c] = x[c];
+    }
+    return;
+  }
   const int row = k0 + nb + blockIdx.x * 256 + tid;
   if (row >= nrows) return;
   double* Arow = A + (size_t)row * n + k0;
@@ -201,7 +221,7 @@ __device__ __forceinline__ void tri_solve_block(const double* __restrict__ L, do
 }
 
 __global__ __launch_bounds__(256) void chol_solve_kernel(const double* __restrict__ L, double* __restrict__ b, int n,
-                                                         int do_forward, const int32_t* skip) {
+                                                         int do_forward, int do_backward, const int32_t* skip) {
   __shared__ double Dl[kNB * kLD];
   __shared__ double rd[kNB];
   __shared__ double z[kNB];
@@ -226,6 +246,7 @@ __global__ __launch_bounds__(256) void chol_solve_kernel(const double* __restric
       __syncthreads();
     }
   }
+  if (!do_backward) return;
   for (int blk = nblk - 1; blk >= 0; --blk) {
     const int k0 = blk * kNB, nb = min(kNB, n - k0);
     tri_solve_block<false>(L, b, n, k0, Dl, rd, z);
@@ -252,7 +273,82 @@ __global__ __launch_bounds__(256) void chol_solve_kernel(const double* __restric
   }
 }
 
-size_t cholesky_workspace_bytes(int n) { (void)n; return 256; }   // kept in the ABI; the kernels need none today
+// Backward substitution L^T x = y with the inverted diagonal blocks: one workgroup of 1024 threads, y in LDS.
+// Per block row (last to first): x_j = T_j y_j (T_j = L_jj^-T, 32x32 mat-vec by 32 lanes), then
+// y_i -= sum_k L[k0+k][i] x_k for all i < k0, one column per thread.  The 32 loads of a column and the next
+// T block are issued BEFORE the mat-vec, so their latency overlaps it; nothing in the loop waits on a
+// dependent global load.
+constexpr int kBackThreads = 1024;
+__global__ __launch_bounds__(kBackThreads) void chol_backward_kernel(const double* __restrict__ L, double* __restrict__ b,
+                                                                     int n, const double* __restrict__ inv_blocks,
+                                                                     const int32_t* skip) {
+  extern __shared__ double sh[];
+  if (skip && *skip) return;
+  const int tid = threadIdx.x;
+  const int nblk = (n + kNB - 1) / kNB;
+  double* y = sh;                                   // [nblk * 32]
+  double* T = y + nblk * kNB;                       // [32][33]
+  double* xj = T + kNB * kLD;                       // [32]
+  for (int i = tid; i < nblk * kNB; i += kBackThreads) y[i] = (i < n) ? b[i] : 0.0;
+  {
+    const double t = inv_blocks[(size_t)(nblk - 1) * kNB * kNB + tid];
+    T[(tid >> 5) * kLD + (tid & 31)] = t;
+  }
+  __syncthreads();
+  for (int blk = nblk - 1; blk >= 0; --blk) {
+    const int k0 = blk * kNB, nb = min(kNB, n - k0);
+    // issue the loads that do not depend on x_j
+    const double tnext = (blk > 0) ? inv_blocks[(size_t)(blk - 1) * kNB * kNB + tid] : 0.0;
+    double l[kNB];
+    const bool have = (tid < k0);
+    if (nb == kNB) {
+#pragma unroll
+      for (int k = 0; k < kNB; ++k) l[k] = have ? L[(size_t)(k0 + k) * n + tid] : 0.0;
+    }
+    if (tid < kNB) {
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int c = 0; c < kNB; c += 4) {
+        s0 += T[tid * kLD + c] * y[k0 + c];
+        s1 += T[tid * kLD + c + 1] * y[k0 + c + 1];
+        s2 += T[tid * kLD + c + 2] * y[k0 + c + 2];
+        s3 += T[tid * kLD + c + 3] * y[k0 + c + 3];
+      }
+      xj[tid] = (tid < nb) ? (s0 + s1) + (s2 + s3) : 0.0;
+    }
+    __syncthreads();
+    if (tid < kNB) y[k0 + tid] = xj[tid];
+    if (nb == kNB) {
+      if (have) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int k = 0; k < kNB; k += 4) { s0 += l[k] * xj[k]; s1 += l[k + 1] * xj[k + 1]; s2 += l[k + 2] * xj[k + 2]; s3 += l[k + 3] * xj[k + 3]; }
+        y[tid] -= (s0 + s1) + (s2 + s3);
+      }
+      for (int i = tid + kBackThreads; i < k0; i += kBackThreads) {     // columns beyond the first 1024
+#pragma unroll
+        for (int k = 0; k < kNB; ++k) l[k] = L[(size_t)(k0 + k) * n + i];
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int k = 0; k < kNB; k += 4) { s0 += l[k] * xj[k]; s1 += l[k + 1] * xj[k + 1]; s2 += l[k + 2] * xj[k + 2]; s3 += l[k + 3] * xj[k + 3]; }
+        y[i] -= (s0 + s1) + (s2 + s3);
+      }
+    } else {                                        // ragged last block (processed first)
+      for (int i = tid; i < k0; i += kBackThreads) {
+        double s0 = 0.0;
+        for (int k = 0; k < nb; ++k) s0 += L[(size_t)(k0 + k) * n + i] * xj[k];
+        y[i] -= s0;
+      }
+    }
+    __syncthreads();                                // all reads of T / xj are done
+    T[(tid >> 5) * kLD + (tid & 31)] = tnext;
+    __syncthreads();
+  }
+  for (int i = tid; i < n; i += kBackThreads) b[i] = y[i];
+}
+
+// workspace = the inverted diagonal blocks T_j = L_jj^-T, 32x32 doubles each
+size_t cholesky_workspace_bytes(int n) { return (size_t)div_up(n, kNB) * kNB * kNB * sizeof(double) + 256; }
 
 // If b is stored directly behind A (b == A + n*n, i.e. "row n" of an (n+1) x n matrix) the right-hand side
 // rides through the factorisation as one more panel row: the panel solve and the trailing update then
@@ -261,11 +357,15 @@ int cholesky_solve_enqueue(double* A, double* b, int n, double* inv_blocks, int3
                            hipStream_t st) {
   const bool fused_rhs = (b == A + (size_t)n * n);
   const int nrows = fused_rhs ? n + 1 : n;
+  // fast backward solve: y and one T block in LDS (64 KB dynamic LDS => n <= ~7000); larger systems use the
+  // single-workgroup substitution kernel
+  const size_t back_lds = ((size_t)div_up(n, kNB) * kNB + kNB * kLD + kNB) * sizeof(double);
+  const bool use_inv = (inv_blocks != nullptr) && back_lds <= 64 * 1024;
   for (int k0 = 0; k0 < n; k0 += kNB) {
     const int nb = (n - k0 < kNB) ? n - k0 : kNB;
     const int rows_panel = nrows - k0 - nb;
-    const int grid = rows_panel > 0 ? div_up(rows_panel, 256) : 1;
-    chol_panel_kernel<<<grid, 256, 0, st>>>(A, n, nrows, k0, device_fail, skip);
+    const int grid = (rows_panel > 0 ? div_up(rows_panel, 256) : 1) + (use_inv ? 1 : 0);
+    chol_panel_kernel<<<grid, 256, 0, st>>>(A, n, nrows, k0, device_fail, skip, use_inv ? inv_blocks : nullptr);
     const int rows_below = nrows - k0 - kNB;
     if (rows_below > 0 && k0 + kNB < n) {
       const int T = div_up(rows_below, 32);
@@ -273,8 +373,12 @@ int cholesky_solve_enqueue(double* A, double* b, int n, double* inv_blocks, int3
       chol_update_kernel<<<div_up(tiles, 4), 256, 0, st>>>(A, n, nrows, k0, tiles, skip);
     }
   }
-  (void)inv_blocks;
-  chol_solve_kernel<<<1, 256, 0, st>>>(A, b, n, fused_rhs ? 0 : 1, skip);
+  if (use_inv) {
+    if (!fused_rhs) chol_solve_kernel<<<1, 256, 0, st>>>(A, b, n, 1, 0, skip);
+    chol_backward_kernel<<<1, kBackThreads, back_lds, st>>>(A, b, n, inv_blocks, skip);
+  } else {
+    chol_solve_kernel<<<1, 256, 0, st>>>(A, b, n, fused_rhs ? 0 : 1, 1, skip);
+  }
   if (hipGetLastError() != hipSuccess) return VGG_ERR_HIP;
   return VGG_OK;
 }

@@ -37,7 +37,13 @@ from vggsfm_amd.scene import make_scene, perturb_for_ba  # noqa: E402
 EPISODE = 25
 FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector = FP64 matrix peak (datasheet; MI355X_MICROARCH.md has no fp64 row)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md chip table (6.29 TB/s measured copy)
-KERNELS = ["cam_pass<linearize>", "point_pass", "cam_pass<rhs>", "schur_tile", "cholesky", "point_step"]
+KERNELS = ["cam_pass<linearize>", "point_pass", "cam_pass<rhs>", "schur_tile<offdiag>", "cholesky", "point_step",
+           "schur_tile<diag>"]
+# rocprofv3 kernel-name fragments of the single-kernel entries (for the PMC traffic lookup)
+ROCPROF_NAME = {"schur_tile<offdiag>": "schur_tile_kernel<6, false>", "schur_tile<diag>": "schur_tile_kernel<6, true>",
+                "point_pass": "point_pass_kernel", "point_step": "point_step_kernel",
+                "cam_pass<linearize>": "cam_pass_kernel<2, 0>", "cam_pass<rhs>": "cam_pass_kernel<2, 1>"}
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic_c3.json")
 
 WORKLOADS = {
     # name: (frames, tracks per GPU, camera, shared)
@@ -51,9 +57,18 @@ def D(x, dev):
     return None if x is None else torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 
 
-def wrap(ws, addr, count):
-    off = addr - ws.data_ptr()
-    return ws[off:off + 8 * count].view(torch.float64)
+def pmc_traffic(kernel, workload):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (scripts/prof/pmc_traffic.sh):
+    FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE counts half of the bytes of streaming reads on gfx950
+    (MI355X_MICROARCH.md "HBM"; confirmed for 4/8/16 B per lane by scripts/ubench/fetch_calib.hip)."""
+    if workload != "c3" or not os.path.exists(PMC_FILE) or kernel not in ROCPROF_NAME:
+        return None
+    with open(PMC_FILE) as fh:
+        pmc = json.load(fh)
+    for name, ctr in pmc.items():
+        if ROCPROF_NAME[kernel] in name and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
+            return (2.0 * ctr["FETCH_SIZE"]["mean"] + ctr["WRITE_SIZE"]["mean"]) * 1024.0
+    return None
 
 
 def main():
@@ -151,11 +166,22 @@ def main():
         P = int(prob.pts.shape[0])
         n_red = int(fin["n_reduced"])
         bd = 6 if shared else 6 + (2 if cam_type == "SIMPLE_RADIAL" else 1)     # Schur block width
-        pair_blocks = float((counts * (counts + 1) / 2).sum().item())
+        # camera-pair blocks (a <= b) of the Schur complement, split by the launch that computes them
+        emask = prob.entries[:, 3].long()
+        na = torch.zeros_like(emask)
+        nb_ = torch.zeros_like(emask)
+        for bit in range(16):
+            na += (emask >> bit) & 1
+            nb_ += (emask >> (16 + bit)) & 1
+        ediag = prob.entries[:, 1] == prob.entries[:, 2]
+        pairs_off = float((na * nb_)[~ediag].sum().item())
+        pairs_diag = float((na * (na + 1) // 2)[ediag].sum().item())
+        assert abs(pairs_off + pairs_diag - float((counts * (counts + 1) / 2).sum().item())) < 0.5
         # algorithmic work per launch (DESIGN.md "Kernels"): flops for the fp64-compute-bound kernels,
         # bytes for the streaming kernels
         work = {
-            "schur_tile": ("mfma", 2.0 * 3 * bd * bd * pair_blocks),
+            "schur_tile<offdiag>": ("mfma", 2.0 * 3 * bd * bd * pairs_off),
+            "schur_tile<diag>": ("mfma", 2.0 * 3 * bd * bd * pairs_diag),
             "cholesky": ("mfma", n_red ** 3 / 3.0 + 2.0 * n_red ** 2),
             "point_pass": ("hbm", 12.0 * n_obs + P * (24 + 4 + 8 * (6 + 3 + 6))),
             "point_step": ("hbm", 12.0 * n_obs + P * (24 + 4 + 8 * (6 + 3) + 24)),
@@ -176,10 +202,22 @@ def main():
             achieved = amount / (avg_ms * 1e-3) / 1e9
             roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                         traffic=None)
+        roof["traffic"] = pmc_traffic(dom, args.workload)
         roof.update(kernel=dom, avg_launch_ms=avg_ms, launches=launches, algorithmic_per_launch=amount,
-                    note="fp64: the kernel runs on the FP64 VALU, whose peak equals the FP64 MFMA peak on MI355X"
-                    if dom == "schur_tile" else "")
+                    traffic_source="profiles/pmc_traffic_c3.json: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, "
+                                   "rocprofv3 --pmc, separate passes" if roof["traffic"] else None,
+                    note="v_mfma_f64_16x16x4_f64 on the off-diagonal Schur tiles; algorithmic flops = 2*3*BD^2 per "
+                         "co-observing camera pair of a point (padding of the 16-camera segments not counted); "
+                         "FP64 MFMA peak = FP64 vector peak = 78.6 TFLOP/s" if dom.startswith("schur_tile") else "")
         kernel_ms = {k: (v[0] / max(v[1], 1)) for k, v in prof.items()}
+        # whole-iteration view of SURVEY.md section 8(d): algorithmic bytes / flops of one LM iteration
+        t_iter = dt / args.steps
+        k_intr = n_red - 6 * S
+        b_iter = 32.0 * n_obs + 72.0 * P + 16.0 * n_red ** 2 + 16.0 * (7 * S + k_intr)
+        f_iter = 400.0 * n_obs + 108.0 * float((counts * counts + counts).sum().item()) + n_red ** 3 / 3.0
+        iteration = dict(algorithmic_bytes=b_iter, hbm_frac_of_8TBs=b_iter / t_iter / (HBM_PEAK_GBS * 1e9),
+                         hbm_frac_of_6p29TBs=b_iter / t_iter / 6.29e12, algorithmic_flops=f_iter,
+                         fp64_frac=f_iter / t_iter / (FP64_PEAK_TFLOPS * 1e12))
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -221,6 +259,7 @@ def main():
                        "successful_steps_last_episode": int(fin["num_successful_steps"]),
                        "kernel_ms": kernel_ms},
             "roofline": roof,
+            "iteration_roofline": iteration,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

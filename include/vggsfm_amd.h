@@ -187,8 +187,9 @@ int vgg_pose_refine(const double* points3D, const void* tracks, int tracks_are_f
                     double loss_scale, vgg_ba_summary* summaries, void* stream);
 
 /* Optional per-kernel timing (HIP events recorded on the launch stream around the dominant kernels).
- * kernel_id: 0 cam_pass<linearize> 1 point_pass 2 cam_pass<rhs> 3 schur_tile 4 cholesky (all launches of one
- * solve) 5 point_step.  vgg_ba_profile_read synchronises on the recorded events. */
+ * kernel_id: 0 cam_pass<linearize> 1 point_pass 2 cam_pass<rhs> 3 schur_tile<off-diagonal tiles> 4 cholesky (all
+ * launches of one solve) 5 point_step 6 schur_tile<diagonal tiles>.  vgg_ba_profile_read synchronises on the
+ * recorded events. */
 int vgg_ba_profile(int enable, int max_launches_per_kernel);
 int vgg_ba_profile_read(int kernel_id, double* total_ms, int* launches, int reset);
 

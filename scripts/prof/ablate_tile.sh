@@ -3,7 +3,7 @@
 # Results of these builds are wrong by construction; the product library is rebuilt at the end.
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT/vggsfm_amd/csrc
-for A in 1 2 0; do
+for A in ${ABLATES:-1 2 0}; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -DVGG_ABLATE=$A -c ba.hip -o _obj/ba.o 2>/dev/null
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libvggsfm_amd.so _obj/*.o
   echo "ABLATE=$A"

@@ -34,6 +34,15 @@ int cholesky_solve_enqueue(double* A, double* b, int n, double* inv_blocks, int3
 size_t cholesky_workspace_bytes(int n);
 
 constexpr int kGroup = 16;       // cameras per Schur tile side
+#ifndef VGG_PP_OCC
+#define VGG_PP_OCC 2
+#endif
+#ifndef VGG_PS_OCC
+#define VGG_PS_OCC 2
+#endif
+#ifndef VGG_CP_OCC
+#define VGG_CP_OCC 2
+#endif
 #ifndef VGG_ABLATE
 #define VGG_ABLATE 0
 #endif
@@ -242,7 +251,7 @@ __global__ void init_kernel(DevProblem pb, Ws w, vgg_ba_options opt, int rank, i
 // ---------------------------------------------------------------------------------------------
 // camera-major pass.  MODE 0: linearisation terms U_c, g_c, cost.  MODE 1: T_c = F^T [r - E hs | -E Ms].
 template <int KD, int MODE>
-__global__ __launch_bounds__(256) void cam_pass_kernel(DevProblem pb, Ws w) {
+__global__ __launch_bounds__(256, VGG_CP_OCC) void cam_pass_kernel(DevProblem pb, Ws w) {
   constexpr int BD = 6 + KD;
   constexpr int NU = BD * (BD + 1) / 2;
   constexpr int NV = (MODE == 0) ? (NU + BD + 1) : (BD * (1 + KD));
@@ -392,7 +401,7 @@ __global__ void damping_kernel(Ws w, vgg_ba_options opt, int n_red) {
 // ---------------------------------------------------------------------------------------------
 // point-major pass: one wavefront per point
 template <int KD>
-__global__ __launch_bounds__(256) void point_pass_kernel(DevProblem pb, Ws w, vgg_ba_options opt) {
+__global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem pb, Ws w, vgg_ba_options opt) {
   constexpr int BD = 6 + KD;
   __shared__ double wmax[4];
   Ctl* ctl = w.ctl;
@@ -686,8 +695,13 @@ __global__ __launch_bounds__(256, (BD == 6 ? 4 : 2)) void schur_tile_kernel(Ws w
 #if VGG_ABLATE != 1
       mfma_batch(buf);
 #endif
+#if VGG_ABLATE == 4
+      mfma_batch(buf);
+#endif
       write_lds(buf ^ 1);
+#if VGG_ABLATE != 3
       __syncthreads();
+#endif
     }
   };
   // partial tile of this chunk, row-major R x R (f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 reg);
@@ -914,7 +928,7 @@ __global__ void cam_update_kernel(DevProblem pb, Ws w) {
 
 // back-substitution, model cost change, candidate point and candidate cost: one wavefront per point
 template <int KD>
-__global__ __launch_bounds__(256) void point_step_kernel(DevProblem pb, Ws w) {
+__global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem pb, Ws w) {
   constexpr int BD = 6 + KD;
   __shared__ double red[4][4];
   if (w.ctl->done) return;
@@ -1080,7 +1094,8 @@ __global__ void clear_accept_kernel(Ws w) { if (w.ctl->done) w.ctl->accept = 0; 
 // ---------------------------------------------------------------------------------------------
 // host side
 // Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
-enum { kProfLinearize = 0, kProfPointPass, kProfCamRhs, kProfSchurTile, kProfCholesky, kProfPointStep, kProfCount };
+enum { kProfLinearize = 0, kProfPointPass, kProfCamRhs, kProfSchurTile, kProfCholesky, kProfPointStep,
+       kProfSchurTileDiag, kProfCount };   // kProfSchurTile = the off-diagonal launch
 struct Profiler {
   bool on = false;
   int cap = 0;
@@ -1115,8 +1130,14 @@ static void phase_linearize(const Launch& L) {
 template <int BD>
 static void launch_schur_tiles(const Launch& L) {
   const int noff = L.num_offdiag_chunks, ndiag = L.num_chunks - noff;
-  if (noff > 0) schur_tile_kernel<BD, false><<<noff, 256, 0, L.st>>>(L.w, L.chunk_desc, L.entries, 0);
-  if (ndiag > 0) schur_tile_kernel<BD, true><<<ndiag, 256, 0, L.st>>>(L.w, L.chunk_desc, L.entries, noff);
+  if (noff > 0) {
+    ProfScope ps(kProfSchurTile, L.st);
+    schur_tile_kernel<BD, false><<<noff, 256, 0, L.st>>>(L.w, L.chunk_desc, L.entries, 0);
+  }
+  if (ndiag > 0) {
+    ProfScope ps(kProfSchurTileDiag, L.st);
+    schur_tile_kernel<BD, true><<<ndiag, 256, 0, L.st>>>(L.w, L.chunk_desc, L.entries, noff);
+  }
 }
 
 template <int KD>
@@ -1135,7 +1156,6 @@ static void phase_schur(const Launch& L) {
   }
   (void)hipMemsetAsync(L.w.sys, 0, sizeof(double) * L.w.sys_count, L.st);
   if (L.num_chunks > 0) {
-    ProfScope ps(kProfSchurTile, L.st);
     if (d.shared || KD == 0) {
       launch_schur_tiles<6>(L);
       tile_reduce_kernel<6><<<dim3(96 * 96 / 256, L.num_tiles), 256, 0, L.st>>>(L.w, d.n_red, d.C, KD, L.tile_desc);

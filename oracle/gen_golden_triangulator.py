@@ -1,0 +1,88 @@
+"""Golden vectors for the END-TO-END drop-in: the reference's own ``vggsfm.models.Triangulator.forward`` run on
+the CPU, with ``oracle/pycolmap_shim.py`` standing in for pycolmap (cut line B2).
+
+Run in the build container only (needs /root/reference):
+    python -m oracle.gen_golden_triangulator
+Writes tests/golden/triangulator_<case>.npz = the inputs handed to ``forward`` and its outputs
+(extrinsics, intrinsics, extra_params, points3D, valid_frame_mask, valid_2D_mask, valid_tracks).
+What these vectors pin is the reference's DRIVER (mask bookkeeping, thresholds schedule, problem construction,
+normalisation, read-back); the solver behind the shim is the oracle restatement (parity with pycolmap 3.10
+itself stays unpinned, oracle/ba_oracle.h).  S < 24 so that ``triangulate_tracks`` enumerates all view pairs
+and draws nothing from the RNG; ``torch.sort`` is forced stable as in oracle/gen_golden.py.
+"""
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import pycolmap_shim, ref_harness  # noqa: E402
+from oracle.gen_golden import _StableSort  # noqa: E402
+from vggsfm_amd.scene import make_scene, perturb_for_ba  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+CASES = {
+    # name: (S, N, camera_type, shared_camera, seed, kwargs of forward)
+    "pinhole_s10": (10, 500, "SIMPLE_PINHOLE", False, 31, dict(BA_iters=2, robust_refine=2)),
+    "radial_shared_s12": (12, 600, "SIMPLE_RADIAL", True, 32, dict(BA_iters=2, robust_refine=2)),
+    "pinhole_shared_s8": (8, 400, "SIMPLE_PINHOLE", True, 33, dict(BA_iters=1, robust_refine=1)),
+}
+
+
+def inputs(S, N, cam, shared, seed, W=1024):
+    sc = make_scene(S, N, cam, shared_camera=shared, seed=seed, outlier_frac=0.03)
+    ext0, K0, _, _ = perturb_for_ba(sc, seed=seed, rot_deg=0.5, trans=0.02, focal_rel=0.02)
+    rng = np.random.default_rng(seed)
+    images = rng.random((1, S, 3, 32, 32), dtype=np.float32)      # colours only; resized to (W,W) by the consumer
+    return dict(R=ext0[:, :, :3].astype(np.float32), T=ext0[:, :, 3].astype(np.float32),
+                focal_ndc=(K0[:, 0, 0] / (W / 2.0)).astype(np.float32), tracks=sc.tracks.astype(np.float32),
+                vis=sc.vis.astype(np.float32), score=sc.score.astype(np.float32),
+                fmat_inlier=(sc.mask[1:] & sc.mask[0:1]), images_small=images, W=np.int64(W))
+
+
+def expand_images(images_small, W):
+    """(1,S,3,h,w) -> (1,S,3,W,W) by nearest-neighbour repetition (exactly reproducible on any device)."""
+    t = torch.from_numpy(images_small)
+    r = W // t.shape[-1]
+    return t.repeat_interleave(r, dim=-1).repeat_interleave(r, dim=-2)
+
+
+def main():
+    sys.modules["pycolmap"] = pycolmap_shim
+    ref_harness.install()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        from vggsfm.models.triangulator import Triangulator
+    os.makedirs(OUT, exist_ok=True)
+    for name, (S, N, cam, shared, seed, kw) in CASES.items():
+        inp = inputs(S, N, cam, shared, seed)
+        W = int(inp["W"])
+        cams = types.SimpleNamespace(R=torch.from_numpy(inp["R"]), T=torch.from_numpy(inp["T"]),
+                                     focal_length=torch.from_numpy(np.stack([inp["focal_ndc"]] * 2, -1)))
+        images = expand_images(inp["images_small"], W)
+        prelim = {"fmat_inlier_mask": torch.from_numpy(inp["fmat_inlier"])[None]}
+        pycolmap_shim.CALLS.clear()
+        torch.manual_seed(0)
+        with _StableSort(), warnings.catch_warnings(), torch.no_grad():
+            warnings.simplefilter("ignore")
+            out = Triangulator()(cams, torch.from_numpy(inp["tracks"])[None], torch.from_numpy(inp["vis"])[None], images,
+                                 prelim, pred_score=torch.from_numpy(inp["score"])[None], shared_camera=shared,
+                                 camera_type=cam, **kw)
+        ext, K, extra, pts, rgb, rec, vframes, v2d, vtracks = out
+        print(name, "valid tracks", int(vtracks.sum()), "of", N, "solver calls", len(pycolmap_shim.CALLS),
+              [c[1]["num_iterations"] for c in pycolmap_shim.CALLS if c[0] == "bundle_adjustment"])
+        np.savez_compressed(
+            os.path.join(OUT, f"triangulator_{name}.npz"), camera_type=cam, shared=shared,
+            kw_keys=np.array(list(kw.keys())), kw_vals=np.array(list(kw.values())), **inp,
+            out_extrinsics=ext.numpy(), out_intrinsics=K.numpy(),
+            out_extra=np.zeros((0,)) if extra is None else extra.numpy(), out_points3D=pts.numpy(),
+            out_rgb=rgb.numpy(), out_valid_frames=vframes.numpy(), out_valid_2D=v2d.numpy(),
+            out_valid_tracks=vtracks.numpy(), rec_num_points3D=np.int64(rec.num_points3D()))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,258 @@
+"""A `pycolmap`-shaped module backed by the CPU oracle (TEST INFRASTRUCTURE ONLY -- cut line B2 of SURVEY.md 8b).
+
+Registered as ``sys.modules["pycolmap"]`` by ``oracle/gen_golden_triangulator.py`` BEFORE the reference is
+imported, it lets the reference's own driver code run unmodified in the build container:
+``vggsfm.models.Triangulator.forward`` -> ``init_BA`` / ``init_refine_pose`` / ``global_BA`` /
+``iterative_global_BA`` (vggsfm/utils/triangulation.py) -> ``batch_matrix_to_pycolmap`` /
+``pycolmap_to_batch_matrix`` (vggsfm/utils/tensor_to_pycolmap.py) -> *this module*.
+
+Only the surface those files touch is provided (last table row):
+``Reconstruction, Track, Camera, Rotation3d, Rigid3d, Image, Point2D, ListPoint2D, BundleAdjustmentOptions,
+AbsolutePoseRefinementOptions, AbsolutePoseEstimationOptions, bundle_adjustment, pose_refinement,
+absolute_pose_estimation``.  The solvers are ``oracle/ba.py`` (the Ceres/COLMAP restatement, PARITY UNPINNED
+against the real pycolmap 3.10 -- see oracle/ba_oracle.h); what this harness pins is everything AROUND the
+solver: the reference's mask bookkeeping, thresholds schedule, problem construction and result read-back.
+``absolute_pose_estimation`` (P3P LO-RANSAC) is not restated: it returns None, which the reference handles
+(vggsfm/utils/triangulation.py:434) by keeping the pose.
+"""
+import types
+
+import numpy as np
+
+from . import ba as OB
+
+
+class Track:
+    def __init__(self):
+        self.elements = []
+
+    def add_element(self, image_id, point2D_idx):
+        self.elements.append(types.SimpleNamespace(image_id=int(image_id), point2D_idx=int(point2D_idx)))
+
+    def length(self):
+        return len(self.elements)
+
+
+class Point3D:
+    def __init__(self, xyz, track, color):
+        self.xyz = np.array(xyz, dtype=np.float64)
+        self.track = track
+        self.color = np.array(color)
+        self.error = -1.0
+
+
+class Rotation3d:
+    def __init__(self, R=None):
+        self._R = np.eye(3) if R is None else np.array(R, dtype=np.float64).reshape(3, 3)
+
+    def matrix(self):
+        return self._R.copy()
+
+
+class Rigid3d:
+    def __init__(self, rotation=None, translation=None):
+        self.rotation = rotation if rotation is not None else Rotation3d()
+        self.translation = np.zeros(3) if translation is None else np.array(translation, dtype=np.float64).reshape(3)
+
+    def matrix(self):
+        return np.concatenate([self.rotation.matrix(), self.translation[:, None]], axis=1)
+
+    def __mul__(self, xyz):
+        return self.rotation.matrix() @ np.asarray(xyz, dtype=np.float64) + self.translation
+
+
+class Camera:
+    def __init__(self, model="SIMPLE_PINHOLE", width=0, height=0, params=(), camera_id=0):
+        self.model = str(model)
+        self.width, self.height = int(width), int(height)
+        self.params = np.array([float(p) for p in params], dtype=np.float64)
+        self.camera_id = int(camera_id)
+
+    def calibration_matrix(self):
+        f, cx, cy = self.params[0], self.params[1], self.params[2]
+        return np.array([[f, 0.0, cx], [0.0, f, cy], [0.0, 0.0, 1.0]])
+
+
+class Point2D:
+    def __init__(self, xy, point3D_id=-1):
+        self.xy = np.array(xy, dtype=np.float64)       # pycolmap stores Eigen::Vector2d (float32 tracks widen exactly)
+        self.point3D_id = int(point3D_id)
+
+
+class ListPoint2D(list):
+    pass
+
+
+class Image:
+    def __init__(self, id=0, name="", camera_id=0, cam_from_world=None):
+        self.image_id = int(id)
+        self.name = name
+        self.camera_id = int(camera_id)
+        self.cam_from_world = cam_from_world if cam_from_world is not None else Rigid3d()
+        self.points2D = ListPoint2D()
+        self.registered = False
+
+
+class Reconstruction:
+    def __init__(self):
+        self.points3D, self.images, self.cameras = {}, {}, {}
+        self._next_point3D_id = 1
+
+    def add_point3D(self, xyz, track, color=np.zeros(3)):
+        pid = self._next_point3D_id
+        self._next_point3D_id += 1
+        self.points3D[pid] = Point3D(xyz, track, color)
+        return pid
+
+    def add_camera(self, camera):
+        self.cameras[camera.camera_id] = camera
+
+    def add_image(self, image):
+        self.images[image.image_id] = image
+
+    def point3D_ids(self):
+        return set(self.points3D.keys())
+
+    def reg_image_ids(self):
+        return sorted(i for i, im in self.images.items() if im.registered)
+
+    def num_points3D(self):
+        return len(self.points3D)
+
+    def num_images(self):
+        return len(self.images)
+
+    def normalize(self, extent=10.0, p0=0.1, p1=0.9, use_images=True):
+        assert use_images
+        ids = sorted(self.images)
+        ext = np.stack([self.images[i].cam_from_world.matrix() for i in ids])
+        pids = sorted(self.points3D)
+        pts = np.stack([self.points3D[p].xyz for p in pids]) if pids else np.zeros((0, 3))
+        ext, pts = OB.normalize_reconstruction(ext, pts, None, extent, p0, p1)
+        for k, i in enumerate(ids):
+            self.images[i].cam_from_world = Rigid3d(Rotation3d(ext[k, :, :3]), ext[k, :, 3])
+        for k, p in enumerate(pids):
+            self.points3D[p].xyz = pts[k]
+
+    # ---- dense view of the problem the reference built with batch_matrix_to_pycolmap
+    def _dense(self):
+        ids = sorted(self.images)
+        assert ids == list(range(len(ids))), "image ids are frame indices (tensor_to_pycolmap.py:118)"
+        S = len(ids)
+        P = max(self.points3D) if self.points3D else 0
+        pts = np.zeros((P, 3))
+        alive = np.zeros(P, bool)
+        for pid, p in self.points3D.items():
+            pts[pid - 1] = p.xyz
+            alive[pid - 1] = True
+        tracks = np.zeros((S, P, 2), np.float32)
+        masks = np.zeros((S, P), bool)
+        for i in ids:
+            if not self.images[i].registered:
+                continue
+            for p2 in self.images[i].points2D:
+                if p2.point3D_id >= 1 and alive[p2.point3D_id - 1]:
+                    tracks[i, p2.point3D_id - 1] = p2.xy
+                    masks[i, p2.point3D_id - 1] = True
+        ext = np.stack([self.images[i].cam_from_world.matrix() for i in ids])
+        cams = [self.cameras[self.images[i].camera_id] for i in ids]
+        shared = len(self.cameras) == 1 and S > 1
+        model = cams[0].model
+        K = np.stack([c.calibration_matrix() for c in cams])
+        extra = np.stack([c.params[3:4] for c in cams]) if model == "SIMPLE_RADIAL" else None
+        return pts, ext, K, tracks, masks, extra, shared, model
+
+
+class _SolverOptions:
+    def __init__(self):
+        # COLMAP 3.10 BundleAdjustmentOptions: ceres defaults overridden in bundle_adjustment.h
+        self.function_tolerance = 0.0
+        self.gradient_tolerance = 1e-4
+        self.parameter_tolerance = 0.0
+        self.max_num_iterations = 100
+        self.max_linear_solver_iterations = 200
+        self.minimizer_progress_to_stdout = False
+        self.num_threads = -1
+
+
+class BundleAdjustmentOptions:
+    def __init__(self):
+        self.solver_options = _SolverOptions()
+        self.refine_focal_length = True
+        self.refine_principal_point = False
+        self.refine_extra_params = True
+        self.refine_extrinsics = True
+        self.print_summary = True
+        self.loss_function_type = "TRIVIAL"
+        self.loss_function_scale = 1.0
+
+
+class AbsolutePoseRefinementOptions:
+    def __init__(self):
+        self.gradient_tolerance = 1.0
+        self.max_num_iterations = 100
+        self.loss_function_scale = 1.0
+        self.refine_focal_length = True
+        self.refine_extra_params = True
+        self.print_summary = False
+
+
+class _Ransac:
+    max_error = 12.0
+
+
+class AbsolutePoseEstimationOptions:
+    def __init__(self):
+        self.estimate_focal_length = False
+        self.ransac = _Ransac()
+
+
+CALLS = []      # (kind, summary) of every solver call, for the generator's log
+
+
+def bundle_adjustment(reconstruction, options=None):
+    """pycolmap.bundle_adjustment: all registered images, image 0 pose constant, image 1 t_x constant,
+    negative-depth observation filter, Ceres LM (oracle/ba.py::bundle_adjustment)."""
+    options = options or BundleAdjustmentOptions()
+    pts, ext, K, tracks, masks, extra, shared, model = reconstruction._dense()
+    so = options.solver_options
+    o = OB.ceres_options(so.max_num_iterations, so.function_tolerance, so.gradient_tolerance, so.parameter_tolerance)
+    assert options.refine_focal_length and options.refine_extra_params and not options.refine_principal_point
+    p_opt, ext_o, K_o, extra_o, summ = OB.bundle_adjustment(pts, ext, K, tracks, masks, extra, shared, model, options=o)
+    CALLS.append(("bundle_adjustment", {k: summ[k] for k in ("initial_cost", "final_cost", "num_iterations",
+                                                             "termination")}))
+    valid_idx, deleted = summ["valid_idx"], summ["deleted"]
+    for k, vi in enumerate(valid_idx):
+        pid = int(vi) + 1
+        if pid not in reconstruction.points3D:
+            continue
+        if deleted[k]:
+            del reconstruction.points3D[pid]          # ObservationManager deletes the whole point
+        else:
+            reconstruction.points3D[pid].xyz = p_opt[k].copy()
+    for i in sorted(reconstruction.images):
+        reconstruction.images[i].cam_from_world = Rigid3d(Rotation3d(ext_o[i, :, :3]), ext_o[i, :, 3])
+        cam = reconstruction.cameras[reconstruction.images[i].camera_id]
+        cam.params[0], cam.params[1], cam.params[2] = K_o[i, 0, 0], K_o[i, 0, 2], K_o[i, 1, 2]
+        if model == "SIMPLE_RADIAL":
+            cam.params[3] = extra_o[i, 0]
+    return summ
+
+
+def pose_refinement(cam_from_world, points2D, points3D, inlier_mask, camera, refinement_options=None):
+    """pycolmap.pose_refinement -> {"cam_from_world": Rigid3d}; `camera.params` are refined in place."""
+    ro = refinement_options or AbsolutePoseRefinementOptions()
+    params = np.zeros(4)
+    params[:len(camera.params)] = camera.params
+    ext, intr, summ = OB.pose_refinement(cam_from_world.matrix(), np.asarray(points2D), np.asarray(points3D),
+                                         np.asarray(inlier_mask, bool), params, camera.model,
+                                         refine_focal_length=bool(ro.refine_focal_length),
+                                         refine_extra_params=bool(ro.refine_extra_params))
+    CALLS.append(("pose_refinement", {k: summ[k] for k in ("initial_cost", "final_cost", "num_iterations",
+                                                           "termination")}))
+    camera.params[:] = intr[:len(camera.params)]
+    return {"cam_from_world": Rigid3d(Rotation3d(ext[:, :3]), ext[:, 3]), "num_inliers": int(np.sum(inlier_mask))}
+
+
+def absolute_pose_estimation(*args, **kwargs):
+    return None

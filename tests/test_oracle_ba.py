@@ -187,3 +187,43 @@ def test_pose_refinement_recovers_pose():
     # robust loss: the 5 % outliers do not pull the pose away from the ground truth
     assert np.abs(ext - sc.extrinsics[2]).max() < 5e-3
     assert abs(intr_out[0] - 1000.0) < 5.0
+
+
+def test_pycolmap_shim_round_trip_equals_dense_oracle():
+    """oracle/pycolmap_shim.py (the B2 harness behind tests/golden/triangulator_*.npz): a Reconstruction filled the
+    way vggsfm/utils/tensor_to_pycolmap.py:60-158 fills it must give the same BA result as the dense oracle entry."""
+    from oracle import pycolmap_shim as pc
+    from vggsfm_amd.scene import make_scene, perturb_for_ba
+
+    sc = make_scene(6, 80, "SIMPLE_RADIAL", shared_camera=True, seed=5)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=5)
+    valid = np.nonzero(sc.mask.sum(0) >= 2)[0]
+    rec = pc.Reconstruction()
+    for v in valid:
+        rec.add_point3D(pts0[v], pc.Track(), np.zeros(3))
+    cam = pc.Camera(model="SIMPLE_RADIAL", width=1024, height=1024,
+                    params=[K0[0, 0, 0], K0[0, 0, 2], K0[0, 1, 2], extra0[0, 0]], camera_id=0)
+    rec.add_camera(cam)
+    for f in range(6):
+        im = pc.Image(id=f, name=f"image_{f}", camera_id=0,
+                      cam_from_world=pc.Rigid3d(pc.Rotation3d(ext0[f, :, :3]), ext0[f, :, 3]))
+        p2 = []
+        for pid in range(1, len(valid) + 1):
+            if sc.mask[f, valid[pid - 1]]:
+                p2.append(pc.Point2D(sc.tracks[f, valid[pid - 1]], pid))
+                rec.points3D[pid].track.add_element(f, len(p2) - 1)
+        im.points2D = pc.ListPoint2D(p2)
+        im.registered = True
+        rec.add_image(im)
+    opts = pc.BundleAdjustmentOptions()
+    opts.solver_options.max_num_iterations = 20
+    pc.bundle_adjustment(rec, opts)
+    p_ref, e_ref, K_ref, x_ref, summ = OB.bundle_adjustment(pts0, ext0, K0, sc.tracks, sc.mask, extra0, True,
+                                                            "SIMPLE_RADIAL", options=OB.ceres_options(20))
+    e = np.stack([rec.images[f].cam_from_world.matrix() for f in range(6)])
+    # same CSR problem on both sides; the OpenMP reductions of the oracle are not run-to-run bit-stable
+    assert np.abs(e - e_ref).max() < 1e-6
+    assert abs(cam.params[0] / K_ref[0, 0, 0] - 1) < 1e-6 and abs(cam.params[3] - x_ref[0, 0]) < 1e-6
+    for k, pid in enumerate(range(1, len(valid) + 1)):
+        if not summ["deleted"][k]:
+            assert np.abs(rec.points3D[pid].xyz - p_ref[k]).max() < 1e-6

@@ -7,8 +7,8 @@ Writes tests/golden/triangulator_<case>.npz = the inputs handed to ``forward`` a
 (extrinsics, intrinsics, extra_params, points3D, valid_frame_mask, valid_2D_mask, valid_tracks).
 What these vectors pin is the reference's DRIVER (mask bookkeeping, thresholds schedule, problem construction,
 normalisation, read-back); the solver behind the shim is the oracle restatement (parity with pycolmap 3.10
-itself stays unpinned, oracle/ba_oracle.h).  S < 24 so that ``triangulate_tracks`` enumerates all view pairs
-and draws nothing from the RNG; ``torch.sort`` is forced stable as in oracle/gen_golden.py.
+itself stays unpinned, oracle/ba_oracle.h).  ``torch.manual_seed(0)`` right before ``forward``; ``torch.sort`` is
+forced stable as in oracle/gen_golden.py.
 """
 import os
 import sys
@@ -30,6 +30,9 @@ CASES = {
     "pinhole_s10": (10, 500, "SIMPLE_PINHOLE", False, 31, dict(BA_iters=2, robust_refine=2)),
     "radial_shared_s12": (12, 600, "SIMPLE_RADIAL", True, 32, dict(BA_iters=2, robust_refine=2)),
     "pinhole_shared_s8": (8, 400, "SIMPLE_PINHOLE", True, 33, dict(BA_iters=1, robust_refine=1)),
+    # S >= 24: C(S,2) > 256, so every triangulate_tracks call draws one torch.randperm from the global CPU RNG
+    # (vggsfm/utils/triangulation.py:804-813); the drop-in must consume the same draws in the same order
+    "radial_s26_randperm": (26, 400, "SIMPLE_RADIAL", False, 34, dict(BA_iters=2, robust_refine=1)),
 }
 
 
@@ -58,7 +61,10 @@ def main():
         warnings.simplefilter("ignore")
         from vggsfm.models.triangulator import Triangulator
     os.makedirs(OUT, exist_ok=True)
+    only = sys.argv[1:]
     for name, (S, N, cam, shared, seed, kw) in CASES.items():
+        if only and name not in only:
+            continue
         inp = inputs(S, N, cam, shared, seed)
         W = int(inp["W"])
         cams = types.SimpleNamespace(R=torch.from_numpy(inp["R"]), T=torch.from_numpy(inp["T"]),

@@ -158,7 +158,7 @@ def solve_csr(cam_q, cam_t, intr, pts, cam_intr, row_ptr, obs_cam, obs_uv, camer
                 termination=summ.termination, n_reduced=summ.n_reduced, iterations=its)
 
 
-def build_observations(points3d, extrinsics, tracks, masks, max_points3D_val=3000):
+def build_observations(points3d, extrinsics, tracks, masks, max_points3D_val=3000, filter_negative_depth=True):
     """Problem construction of batch_matrix_to_pycolmap + the controller's negative-depth filter.
     Returns (point_index (P',) into the input tracks, row_ptr, obs_cam, obs_uv, deleted (P_valid,) bool,
     valid_idx)."""
@@ -172,7 +172,7 @@ def build_observations(points3d, extrinsics, tracks, masks, max_points3D_val=300
     deleted = np.zeros(len(valid_idx), bool)
     length = m.sum(0)
     eps = np.finfo(np.float64).eps
-    for s in range(m.shape[0]):
+    for s in range(m.shape[0] if filter_negative_depth else 0):
         bad = np.nonzero(m[s] & ~(z[s] >= eps) & ~deleted)[0]
         for p in bad:
             if length[p] <= 2:
@@ -192,7 +192,8 @@ def build_observations(points3d, extrinsics, tracks, masks, max_points3D_val=300
 
 
 def bundle_adjustment(points3d, extrinsics, intrinsics, tracks, masks, extra_params=None, shared_camera=False,
-                      camera_type="SIMPLE_PINHOLE", options=None, normalize=False):
+                      camera_type="SIMPLE_PINHOLE", options=None, normalize=False, constant_points=None,
+                      constant_pose_frames=None, filter_negative_depth=True, refine_focal=True, refine_extra=True):
     """What `batch_matrix_to_pycolmap -> pycolmap.bundle_adjustment [-> normalize] ->
     pycolmap_to_batch_matrix` computes.  Returns (points3D_opt (P_valid,3) with zero rows for deleted
     points, extrinsics (S,3,4), intrinsics (S,3,3), extra_params (S,1)|None, summary)."""
@@ -202,7 +203,8 @@ def bundle_adjustment(points3d, extrinsics, intrinsics, tracks, masks, extra_par
     S = len(extrinsics)
     extrinsics = np.asarray(extrinsics, np.float64)
     intrinsics = np.asarray(intrinsics, np.float64)
-    valid_idx, row_ptr, obs_cam, obs_uv, deleted = build_observations(points3d, extrinsics, tracks, masks)
+    valid_idx, row_ptr, obs_cam, obs_uv, deleted = build_observations(points3d, extrinsics, tracks, masks,
+                                                                      filter_negative_depth=filter_negative_depth)
     pts = np.ascontiguousarray(np.asarray(points3d, np.float64)[valid_idx])
     cam_q = np.ascontiguousarray(rotmat_to_quat(extrinsics[:, :, :3]))
     cam_t = np.ascontiguousarray(extrinsics[:, :, 3])
@@ -216,11 +218,16 @@ def bundle_adjustment(points3d, extrinsics, intrinsics, tracks, masks, extra_par
         intr[:, 3] = np.asarray(extra_params, np.float64)[src, 0]
     cam_intr = (np.zeros(S, np.int32) if shared_camera else np.arange(S, dtype=np.int32))
     cam_const = np.zeros(S, np.uint8)
-    cam_const[0] = 1            # SetConstantCamPose(image 0)
-    if S > 1:
-        cam_const[1] = 2        # SetConstantCamPositions(image 1, {0})
+    if constant_pose_frames is None:
+        cam_const[0] = 1            # SetConstantCamPose(image 0)
+        if S > 1:
+            cam_const[1] = 2        # SetConstantCamPositions(image 1, {0})
+    else:                           # explicit BundleAdjustmentConfig (video_runner.py:813-829)
+        cam_const[list(constant_pose_frames)] = 1
+    pt_const = None if constant_points is None else np.ascontiguousarray(
+        np.asarray(constant_points, bool)[valid_idx].astype(np.uint8))
     summary = solve_csr(cam_q, cam_t, intr, pts, cam_intr, row_ptr, obs_cam, obs_uv, MODEL[camera_type], options,
-                        cam_const=cam_const)
+                        refine_focal=refine_focal, refine_extra=refine_extra, cam_const=cam_const, pt_const=pt_const)
     ext = np.concatenate([quat_to_rotmat(cam_q), cam_t[:, :, None]], -1)
     pts[deleted] = 0.0
     if normalize:

@@ -257,6 +257,23 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
     return prob, valid_idx, deleted
 
 
+def window_bundle_adjustment(points3d, extrinsics, intrinsics, tracks, masks, num_existing_points, extra_params=None,
+                             shared_camera=True, camera_type="SIMPLE_RADIAL", options=None):
+    """The local BA of one video window (vggsfm/runners/video_runner.py:800-838): frame 0 of the window (= the last
+    frame of the previous one) keeps its pose, the first `num_existing_points` VALID points (the ones carried
+    over from earlier windows) are constant, the newly triangulated ones are variable, focal length and
+    distortion are not refined (``ba_options.refine_focal_length = refine_extra_params = False``)."""
+    options = options or BundleAdjustmentOptions()
+    options.refine_focal_length = False
+    options.refine_extra_params = False
+    valid = masks.bool().sum(0) >= 2
+    order = torch.cumsum(valid.long(), 0) - 1                       # 0-based point3D id - 1 of every valid track
+    constant = valid & (order < num_existing_points)
+    return bundle_adjustment(points3d, extrinsics, intrinsics, tracks, masks, None, extra_params, shared_camera,
+                             camera_type, options, False, constant_points=constant, constant_pose_frames=[0],
+                             filter_negative_depth=False)
+
+
 def _c_options(options: BundleAdjustmentOptions):
     so = options.solver_options
     return _lib.BAOptions(so.max_num_iterations, so.max_num_consecutive_invalid_steps, int(so.jacobi_scaling),
@@ -327,13 +344,26 @@ def normalize_reconstruction(extrinsics, points3D, alive=None, extent=5.0, p0=0.
 
 
 def bundle_adjustment(points3d, extrinsics, intrinsics, tracks, masks, image_size=None, extra_params=None,
-                      shared_camera=False, camera_type="SIMPLE_PINHOLE", options=None, normalize=False):
-    """Tensor-in / tensor-out equivalent of the reference's three-call round trip.
+                      shared_camera=False, camera_type="SIMPLE_PINHOLE", options=None, normalize=False,
+                      constant_points=None, constant_pose_frames=None, filter_negative_depth=True):
+    """Tensor-in / tensor-out equivalent of the reference's three-call round trip
+    (batch_matrix_to_pycolmap -> pycolmap.bundle_adjustment -> pycolmap_to_batch_matrix).
     Returns (points3D_opt (P',3), extrinsics (S,3,4), intrinsics (S,3,3), extra_params (S,1)|None, summary);
-    P' = number of tracks with >= 2 masked observations, rows of deleted points are zero."""
+    P' = number of tracks with >= 2 masked observations, rows of deleted points are zero.
+
+    The two optional arguments express a ``pycolmap.BundleAdjustmentConfig`` (video_runner.py:813-829):
+    `constant_points` (P,) bool over the INPUT tracks = ``add_constant_point``; `constant_pose_frames` = the frames
+    of ``set_constant_cam_pose`` -- when given it REPLACES the default gauge of ``pycolmap.bundle_adjustment``
+    (frame 0 pose + frame 1 t_x constant).  `filter_negative_depth=False` for the BundleAdjuster-level entry
+    (``solve_bundle_adjustment``), which does not run the ObservationManager filter."""
     _lib.require_gpu(points3d, extrinsics, intrinsics, tracks, masks)
     prob, valid_idx, deleted = compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_params,
-                                               shared_camera, camera_type)
+                                               shared_camera, camera_type, filter_negative_depth=filter_negative_depth,
+                                               gauge="colmap" if constant_pose_frames is None else "config")
+    if constant_pose_frames is not None:
+        prob.cam_const[torch.as_tensor(list(constant_pose_frames), dtype=torch.long, device=prob.cam_const.device)] = 1
+    if constant_points is not None:
+        prob.pt_const = constant_points.to(device=prob.pts.device)[valid_idx].to(torch.uint8).contiguous()
     summary, _ = solve(prob, options)
     S = extrinsics.shape[0]
     ext = torch.cat([quat_to_rotmat(prob.cam_q), prob.cam_t[:, :, None]], -1)

@@ -26,7 +26,7 @@ def _chol_ws(n):
     return torch.empty(int(_lib.lib().vgg_cholesky_workspace_bytes(n)), dtype=torch.uint8, device="cuda")
 
 
-@pytest.mark.parametrize("n", [1, 5, 32, 33, 100, 350, 1202])
+@pytest.mark.parametrize("n", [1, 5, 32, 33, 100, 256, 257, 350, 384, 1202])
 def test_cholesky_solve(n):
     rng = np.random.default_rng(n)
     M = rng.normal(size=(n, n + 8))
@@ -46,7 +46,7 @@ def test_cholesky_solve(n):
     np.testing.assert_allclose(np.tril(At.cpu().numpy()), Lr, rtol=1e-9, atol=1e-11)
 
 
-@pytest.mark.parametrize("n", [7, 64, 350, 1202])
+@pytest.mark.parametrize("n", [7, 64, 257, 350, 384, 1202, 3200, 4500])
 def test_cholesky_solve_fused_rhs_row(n):
     # b stored directly behind A: the rhs rides through the factorisation as row n (the BA path)
     rng = np.random.default_rng(100 + n)

@@ -2,141 +2,156 @@
 //
 // In the reference this is the DENSE_SCHUR / SPARSE_SCHUR factorisation inside Ceres, reached through
 // pycolmap.bundle_adjustment (vggsfm/utils/triangulation.py:213,1050,1142).  Here: right-looking blocked
-// Cholesky, NB = 32, two launches per block column:
-//   panel  : every workgroup re-factors the 32x32 diagonal block in LDS (outer-product form, ONE barrier per
+// Cholesky, two launches per block column of NB columns:
+//   panel  : every workgroup re-factors the NB x NB diagonal block in LDS (outer-product form, ONE barrier per
 //            column, reciprocal instead of divide), then solves the panel rows below by forward
-//            substitution, one row per lane with the row in 32 registers;
+//            substitution, one row per lane with the row in NB registers; one extra workgroup pushes the
+//            identity through the same substitution: T_k = L_kk^-T for the backward solve;
 //   update : trailing SYRK on the matrix cores, one wavefront per 32x32 tile =
-//            2x2 v_mfma_f64_16x16x4_f64 accumulators x 8 k-steps.
+//            2x2 v_mfma_f64_16x16x4_f64 accumulators x NB/4 k-steps.
+// The whole thing is a chain of dependent launches, each with a floor of ~4.5 us plus two memory round trips, and
+// a ~250 ns pivot step per column.  The kernels are templates on NB; NB = 64 (half the launches) was measured
+// and lost: its panel kernel takes 84 us against 2 x 18 us (the 64 x 64 factor and the 2016 broadcast LDS reads
+// of the substitution are LDS-issue bound), so NB = 32 is what runs.
 // The right-hand side is stored as row n of the (n+1) x n array, so the factorisation performs the
-// forward substitution on the way; the backward substitution stages each diagonal block in LDS.
+// forward substitution on the way; the backward substitution is a sequence of NB x NB mat-vecs with T_k.
 // Only the lower triangle (row-major, ld = n) is read or written.
 #include "common.hpp"
 
 namespace vgg {
 
-constexpr int kNB = 32;
-constexpr int kLD = kNB + 1;
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ double fast_rcp(double x) {      // 1/x: hardware estimate + 2 Newton steps
+__device__ __forceinline__ double fast_rcp(double x) {      // 1/x: hardware estimate (4.6e-8) + 2 Newton steps
   double r = __builtin_amdgcn_rcp(x);
   r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
   r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
   return r;
 }
 
-// The 256 threads of a workgroup factor the 32x32 block D (LDS, ld = kLD, rows >= nb padded with the
+// The 256 threads of a workgroup factor the NB x NB block D (LDS, ld = NB + 1, rows >= nb padded with the
 // identity) in place.  Outer-product form WITHOUT normalising inside the loop (a_ic -= a_ij a_cj / d_j), so
 // a step needs a single barrier: the column it reads was finalised by the previous step, the elements it
 // writes are disjoint from it.  Columns are scaled by 1/sqrt(d_j) at the end; rdiag[j] = 1 / L_jj.
+template <int NB>
 __device__ __forceinline__ void factor_diag_lds(double* D, double* rdiag, int32_t* fail_flag) {
+  constexpr int LD = NB + 1, STRIDE = 256 / NB, CNT = NB / STRIDE;
   const int tid = threadIdx.x;
-  const int c = tid & 31, i0 = tid >> 5;        // thread owns elements (i0 + 8 m, c), m = 0..3
+  const int c = tid % NB, i0 = tid / NB;        // thread owns elements (i0 + STRIDE m, c), m = 0..CNT-1
   bool bad = false;
-  for (int j = 0; j < kNB - 1; ++j) {
+  for (int j = 0; j < NB - 1; ++j) {
     __syncthreads();
-    const double dj = D[j * kLD + j];
+    const double dj = D[j * LD + j];
     if (!(dj > 0.0) || !(dj < 1.7976931348623157e308)) bad = true;
     const double inv = fast_rcp((dj > 0.0) ? dj : 1.0);
     if (c > j) {
-      const double lcj = D[c * kLD + j] * inv;
+      const double lcj = D[c * LD + j] * inv;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int i = i0 + 8 * m;
-        if (i >= c) D[i * kLD + c] -= D[i * kLD + j] * lcj;
+      for (int m = 0; m < CNT; ++m) {
+        const int i = i0 + STRIDE * m;
+        if (i >= c) D[i * LD + c] -= D[i * LD + j] * lcj;
       }
     }
   }
   __syncthreads();
   {
-    const double dl = D[(kNB - 1) * kLD + kNB - 1];
+    const double dl = D[(NB - 1) * LD + NB - 1];
     if (!(dl > 0.0) || !(dl < 1.7976931348623157e308)) bad = true;
   }
   // scale column c by 1/sqrt(d_c)
-  const double dc = D[c * kLD + c];
+  const double dc = D[c * LD + c];
   const double sd = sqrt((dc > 0.0) ? dc : 1.0);
   const double rs = 1.0 / sd;
   __syncthreads();
 #pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const int i = i0 + 8 * m;
-    if (i > c) D[i * kLD + c] *= rs;
-    else if (i == c) { D[i * kLD + c] = sd; rdiag[c] = rs; }
+  for (int m = 0; m < CNT; ++m) {
+    const int i = i0 + STRIDE * m;
+    if (i > c) D[i * LD + c] *= rs;
+    else if (i == c) { D[i * LD + c] = sd; rdiag[c] = rs; }
   }
   if (bad && tid == 0 && fail_flag) *fail_flag = 1;
   __syncthreads();
 }
 
+// x <- x L_kk^-T for one row held in registers.  Column-oriented substitution: once x_k is final it is
+// eliminated from all later columns with independent FMAs, so the dependent chain is one multiply + one FMA
+// per column (an fp64 FMA has a 32-cycle dependent latency on gfx950) instead of an NB(NB+1)/2-long chain.
+template <int NB>
+__device__ __forceinline__ void substitute_row(double (&x)[NB], const double* D, const double* rdiag) {
+  constexpr int LD = NB + 1;
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    x[k] *= rdiag[k];
+#pragma unroll
+    for (int c = k + 1; c < NB; ++c) x[c] -= x[k] * D[c * LD + k];
+  }
+}
+
+template <int NB>
 __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A, int n, int nrows, int k0,
                                                          int32_t* fail, const int32_t* skip,
                                                          double* __restrict__ inv_blocks) {
-  __shared__ double D[kNB * kLD];
-  __shared__ double rdiag[kNB];
+  constexpr int LD = NB + 1;
+  __shared__ double D[NB * LD];
+  __shared__ double rdiag[NB];
   if (skip && *skip) return;
-  const int nb = min(kNB, n - k0);
+  const int nb = min(NB, n - k0);
   const int tid = threadIdx.x;
-  for (int e = tid; e < kNB * kNB; e += 256) {
-    const int i = e >> 5, c = e & 31;
-    D[i * kLD + c] = (i < nb && c <= i) ? A[(size_t)(k0 + i) * n + k0 + c] : ((i == c) ? 1.0 : 0.0);
+  // panel row of this lane: issue its loads before the factorisation so that their latency overlaps it
+  const bool extra_wg = inv_blocks && blockIdx.x == gridDim.x - 1;
+  const int row = k0 + nb + blockIdx.x * 256 + tid;
+  const bool has_row = !extra_wg && row < nrows && nb == NB;
+  double x[NB];
+  if (has_row) {
+    const double* Arow = A + (size_t)row * n + k0;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) x[c] = Arow[c];   // unconditional: all NB loads in flight at once
+  } else {
+#pragma unroll
+    for (int c = 0; c < NB; ++c) x[c] = (extra_wg && c == tid) ? 1.0 : 0.0;
   }
-  factor_diag_lds(D, rdiag, (blockIdx.x == 0) ? fail : nullptr);
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int i = e / NB, c = e % NB;
+    D[i * LD + c] = (i < nb && c <= i) ? A[(size_t)(k0 + i) * n + k0 + c] : ((i == c) ? 1.0 : 0.0);
+  }
+  factor_diag_lds<NB>(D, rdiag, (blockIdx.x == 0) ? fail : nullptr);
   if (blockIdx.x == 0) {
-    for (int e = tid; e < kNB * kNB; e += 256) {
-      const int i = e >> 5, c = e & 31;
-      if (i < nb && c <= i) A[(size_t)(k0 + i) * n + k0 + c] = D[i * kLD + c];
+    for (int e = tid; e < NB * NB; e += 256) {
+      const int i = e / NB, c = e % NB;
+      if (i < nb && c <= i) A[(size_t)(k0 + i) * n + k0 + c] = D[i * LD + c];
     }
   }
-  // panel rows below the diagonal block (and the appended rhs row): x L_kk^T = a, one row per lane.
-  // Column-oriented substitution: once x_k is final it is eliminated from all later columns with
-  // independent FMAs, so the dependent chain is one multiply + one FMA per column (an fp64 FMA has a
-  // 32-cycle dependent latency on gfx950) instead of a 528-long chain.
-  if (inv_blocks && blockIdx.x == gridDim.x - 1) {
+  if (extra_wg) {
     // extra workgroup: T = L_kk^-T (rows of the identity pushed through the same substitution), used by the
-    // backward solve as a plain 32x32 mat-vec instead of a 32-step dependent chain.  Row-major 32x32.
-    if (tid < kNB) {
-      double x[kNB];
+    // backward solve as a plain NB x NB mat-vec instead of an NB-step dependent chain.  Row-major NB x NB.
+    if (tid < NB) {
+      substitute_row<NB>(x, D, rdiag);
+      double* T = inv_blocks + (size_t)(k0 / NB) * NB * NB + tid * NB;
 #pragma unroll
-      for (int c = 0; c < kNB; ++c) x[c] = (c == tid) ? 1.0 : 0.0;
-#pragma unroll
-      for (int k = 0; k < kNB; ++k) {
-        x[k] *= rdiag[k];
-#pragma unroll
-        for (int c = k + 1; c < kNB; ++c) x[c] -= x[k] * D[c * kLD + k];
-      }
-      double* T = inv_blocks + (size_t)(k0 / kNB) * kNB * kNB + tid * kNB;
-#pragma unroll
-      for (int c = 0; c < kNB; ++c) T[c] = x[c];
+      for (int c = 0; c < NB; ++c) T[c] = x[c];
     }
     return;
   }
-  const int row = k0 + nb + blockIdx.x * 256 + tid;
   if (row >= nrows) return;
   double* Arow = A + (size_t)row * n + k0;
-  if (nb < kNB) {                               // ragged last block: only the appended rhs row sits below it
+  if (nb < NB) {                                // ragged last block: only the appended rhs row sits below it
     for (int c = 0; c < nb; ++c) {
       double sacc = Arow[c];
-      for (int k = 0; k < c; ++k) sacc -= Arow[k] * D[c * kLD + k];
+      for (int k = 0; k < c; ++k) sacc -= Arow[k] * D[c * LD + k];
       Arow[c] = sacc * rdiag[c];
     }
     return;
   }
-  double x[kNB];
+  substitute_row<NB>(x, D, rdiag);
 #pragma unroll
-  for (int c = 0; c < kNB; ++c) x[c] = Arow[c];   // unconditional: all 32 loads in flight at once
-#pragma unroll
-  for (int k = 0; k < kNB; ++k) {
-    x[k] *= rdiag[k];
-#pragma unroll
-    for (int c = k + 1; c < kNB; ++c) x[c] -= x[k] * D[c * kLD + k];
-  }
-#pragma unroll
-  for (int c = 0; c < kNB; ++c) Arow[c] = x[c];
+  for (int c = 0; c < NB; ++c) Arow[c] = x[c];
 }
 
-// trailing update A[i][j] -= sum_k L[i][k0+k] L[j][k0+k] for i >= j >= k0+32, tiles of 32x32
+// trailing update A[i][j] -= sum_k L[i][k0+k] L[j][k0+k] for i >= j >= k0+NB, tiles of 32x32, k < NB
+template <int NB>
 __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ A, int n, int nrows, int k0,
                                                           int num_tiles, const int32_t* skip) {
+  constexpr int KS = NB / 4;
   if (skip && *skip) return;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // scalar: MFMAs
   const int t = blockIdx.x * 4 + wave;                                                       // behind scalar branches
@@ -145,16 +160,16 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ A
   while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
   while (bi * (bi + 1) / 2 > t) --bi;
   const int bj = t - bi * (bi + 1) / 2;
-  const int base = k0 + kNB;
+  const int base = k0 + NB;
   const int r0 = base + bi * 32, c0 = base + bj * 32;
   const int li = lane & 15, lk = lane >> 4;
   // operands: a[m][kk] = L[r0 + 16 m + li][k0 + 4 kk + lk], b[m][kk] = L[c0 + 16 m + li][k0 + 4 kk + lk]
-  double a[2][8], b[2][8];
+  double a[2][KS], b[2][KS];
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
     const int ra = r0 + 16 * m + li, rb = c0 + 16 * m + li;
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
+    for (int kk = 0; kk < KS; ++kk) {
       a[m][kk] = (ra < nrows) ? A[(size_t)ra * n + k0 + 4 * kk + lk] : 0.0;
       b[m][kk] = (rb < nrows) ? A[(size_t)rb * n + k0 + 4 * kk + lk] : 0.0;
     }
@@ -165,7 +180,7 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ A
 #pragma unroll
     for (int q = 0; q < 2; ++q) acc[m][q] = (f64x4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int kk = 0; kk < 8; ++kk)
+  for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -183,19 +198,20 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ A
       }
 }
 
-// Substitutions, one workgroup.  Each 32x32 diagonal block is staged in LDS (with the reciprocals of its
-// diagonal) so that the 32 dependent steps never wait on L2/HBM.  FORWARD (L z = b) is only needed when b
-// is not stored as row n of the factored matrix (cholesky_solve_enqueue).
-template <bool FORWARD>
+// Substitutions by one workgroup: the slow, size-unlimited path.  FORWARD (L z = b) is only needed when b
+// is not stored as row n of the factored matrix; BACKWARD only when the system is too large for the LDS kernel.
+// Each diagonal block is staged in LDS so that the dependent steps never wait on L2/HBM.
+template <int NB, bool FORWARD>
 __device__ __forceinline__ void tri_solve_block(const double* __restrict__ L, double* __restrict__ b, int n, int k0,
                                                 double* Dl, double* rd, double* z) {
+  constexpr int LD = NB + 1;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int nb = min(kNB, n - k0);
-  for (int e = tid; e < kNB * kNB; e += 256) {
-    const int i = e >> 5, c = e & 31;
+  const int nb = min(NB, n - k0);
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int i = e / NB, c = e % NB;
     if (i < nb && c <= i) {
       const double v = L[(size_t)(k0 + i) * n + k0 + c];
-      Dl[i * kLD + c] = v;
+      Dl[i * LD + c] = v;
       if (i == c) rd[i] = fast_rcp(v);
     }
   }
@@ -206,13 +222,13 @@ __device__ __forceinline__ void tri_solve_block(const double* __restrict__ L, do
       for (int k = 0; k < nb; ++k) {
         const double zk = __shfl(v, k, 64) * rd[k];
         if (lane == k) v = zk;
-        if (lane > k && lane < nb) v -= Dl[lane * kLD + k] * zk;
+        if (lane > k && lane < nb) v -= Dl[lane * LD + k] * zk;
       }
     } else {
       for (int k = nb - 1; k >= 0; --k) {
         const double yk = __shfl(v, k, 64) * rd[k];
         if (lane == k) v = yk;
-        if (lane < k) v -= Dl[k * kLD + lane] * yk;
+        if (lane < k) v -= Dl[k * LD + lane] * yk;
       }
     }
     if (lane < nb) { z[lane] = v; b[k0 + lane] = v; }
@@ -220,118 +236,106 @@ __device__ __forceinline__ void tri_solve_block(const double* __restrict__ L, do
   __syncthreads();
 }
 
+template <int NB>
 __global__ __launch_bounds__(256) void chol_solve_kernel(const double* __restrict__ L, double* __restrict__ b, int n,
                                                          int do_forward, int do_backward, const int32_t* skip) {
-  __shared__ double Dl[kNB * kLD];
-  __shared__ double rd[kNB];
-  __shared__ double z[kNB];
+  __shared__ double Dl[NB * (NB + 1)];
+  __shared__ double rd[NB];
+  __shared__ double z[NB];
   if (skip && *skip) return;
   const int tid = threadIdx.x;
-  const int nblk = (n + kNB - 1) / kNB;
+  const int nblk = (n + NB - 1) / NB;
   if (do_forward) {
     for (int blk = 0; blk < nblk; ++blk) {
-      const int k0 = blk * kNB, nb = min(kNB, n - k0);
-      tri_solve_block<true>(L, b, n, k0, Dl, rd, z);
-      const int sub = tid & 7, rloc = tid >> 3;       // 8 lanes per row, 4 consecutive columns each
-      for (int i0 = k0 + nb; i0 < n; i0 += 32) {
-        const int i = i0 + rloc;
+      const int k0 = blk * NB, nb = min(NB, n - k0);
+      tri_solve_block<NB, true>(L, b, n, k0, Dl, rd, z);
+      for (int i = k0 + nb + tid; i < n; i += 256) {
+        const double* Li = L + (size_t)i * n + k0;
         double s = 0.0;
-        if (i < n) {
-          const double* Li = L + (size_t)i * n + k0;
-          for (int k = sub * 4; k < min(sub * 4 + 4, nb); ++k) s += Li[k] * z[k];
-        }
-        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-        if (i < n && sub == 0) b[i] -= s;
+        for (int k = 0; k < nb; ++k) s += Li[k] * z[k];
+        b[i] -= s;
       }
       __syncthreads();
     }
   }
   if (!do_backward) return;
   for (int blk = nblk - 1; blk >= 0; --blk) {
-    const int k0 = blk * kNB, nb = min(kNB, n - k0);
-    tri_solve_block<false>(L, b, n, k0, Dl, rd, z);
-    // earlier rows: b_i -= sum_k L[k0+k][i] y_k.  A single workgroup is latency bound on these reads, so
-    // every thread keeps all 32 loads of a column in flight and uses four partial sums.
-    if (nb == kNB) {
-      for (int i = tid; i < k0; i += 256) {
-        double l[kNB];
-#pragma unroll
-        for (int k = 0; k < kNB; ++k) l[k] = L[(size_t)(k0 + k) * n + i];
-        double s0 = b[i], s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-        for (int k = 0; k < kNB; k += 4) { s0 -= l[k] * z[k]; s1 -= l[k + 1] * z[k + 1]; s2 -= l[k + 2] * z[k + 2]; s3 -= l[k + 3] * z[k + 3]; }
-        b[i] = (s0 + s1) + (s2 + s3);
-      }
-    } else {
-      for (int i = tid; i < k0; i += 256) {
-        double s0 = b[i];
-        for (int k = 0; k < nb; ++k) s0 -= L[(size_t)(k0 + k) * n + i] * z[k];
-        b[i] = s0;
-      }
+    const int k0 = blk * NB, nb = min(NB, n - k0);
+    tri_solve_block<NB, false>(L, b, n, k0, Dl, rd, z);
+    for (int i = tid; i < k0; i += 256) {
+      double s0 = b[i];
+      for (int k = 0; k < nb; ++k) s0 -= L[(size_t)(k0 + k) * n + i] * z[k];
+      b[i] = s0;
     }
     __syncthreads();
   }
 }
 
 // Backward substitution L^T x = y with the inverted diagonal blocks: one workgroup of 1024 threads, y in LDS.
-// Per block row (last to first): x_j = T_j y_j (T_j = L_jj^-T, 32x32 mat-vec by 32 lanes), then
-// y_i -= sum_k L[k0+k][i] x_k for all i < k0, one column per thread.  The 32 loads of a column and the next
-// T block are issued BEFORE the mat-vec, so their latency overlaps it; nothing in the loop waits on a
-// dependent global load.
+// Per block row (last to first): x_j = T_j y_j (T_j = L_jj^-T, NB x NB mat-vec by NB lanes), then
+// y_i -= sum_k L[k0+k][i] x_k for all i < k0, one column per thread, 32 rows at a time.  The first 32 loads of
+// a column and the next T block are issued BEFORE the mat-vec, so their latency overlaps it.
 constexpr int kBackThreads = 1024;
+template <int NB>
 __global__ __launch_bounds__(kBackThreads) void chol_backward_kernel(const double* __restrict__ L, double* __restrict__ b,
                                                                      int n, const double* __restrict__ inv_blocks,
                                                                      const int32_t* skip) {
+  constexpr int LD = NB + 1, TPT = NB * NB / kBackThreads;     // T elements per thread (1 or 4)
   extern __shared__ double sh[];
   if (skip && *skip) return;
   const int tid = threadIdx.x;
-  const int nblk = (n + kNB - 1) / kNB;
-  double* y = sh;                                   // [nblk * 32]
-  double* T = y + nblk * kNB;                       // [32][33]
-  double* xj = T + kNB * kLD;                       // [32]
-  for (int i = tid; i < nblk * kNB; i += kBackThreads) y[i] = (i < n) ? b[i] : 0.0;
-  {
-    const double t = inv_blocks[(size_t)(nblk - 1) * kNB * kNB + tid];
-    T[(tid >> 5) * kLD + (tid & 31)] = t;
+  const int nblk = (n + NB - 1) / NB;
+  double* y = sh;                                   // [nblk * NB]
+  double* T = y + nblk * NB;                        // [NB][NB + 1]
+  double* xj = T + NB * LD;                         // [NB]
+  for (int i = tid; i < nblk * NB; i += kBackThreads) y[i] = (i < n) ? b[i] : 0.0;
+#pragma unroll
+  for (int q = 0; q < TPT; ++q) {
+    const int e = tid + q * kBackThreads;
+    T[(e / NB) * LD + (e % NB)] = inv_blocks[(size_t)(nblk - 1) * NB * NB + e];
   }
   __syncthreads();
   for (int blk = nblk - 1; blk >= 0; --blk) {
-    const int k0 = blk * kNB, nb = min(kNB, n - k0);
+    const int k0 = blk * NB, nb = min(NB, n - k0);
     // issue the loads that do not depend on x_j
-    const double tnext = (blk > 0) ? inv_blocks[(size_t)(blk - 1) * kNB * kNB + tid] : 0.0;
-    double l[kNB];
-    const bool have = (tid < k0);
-    if (nb == kNB) {
+    double tnext[TPT];
 #pragma unroll
-      for (int k = 0; k < kNB; ++k) l[k] = have ? L[(size_t)(k0 + k) * n + tid] : 0.0;
-    }
-    if (tid < kNB) {
+    for (int q = 0; q < TPT; ++q)
+      tnext[q] = (blk > 0) ? inv_blocks[(size_t)(blk - 1) * NB * NB + tid + q * kBackThreads] : 0.0;
+    double l[32];
+    const bool have = (tid < k0) && nb == NB;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) l[k] = have ? L[(size_t)(k0 + k) * n + tid] : 0.0;
+    if (tid < NB) {
       double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-      for (int c = 0; c < kNB; c += 4) {
-        s0 += T[tid * kLD + c] * y[k0 + c];
-        s1 += T[tid * kLD + c + 1] * y[k0 + c + 1];
-        s2 += T[tid * kLD + c + 2] * y[k0 + c + 2];
-        s3 += T[tid * kLD + c + 3] * y[k0 + c + 3];
+      for (int c = 0; c < NB; c += 4) {
+        s0 += T[tid * LD + c] * y[k0 + c];
+        s1 += T[tid * LD + c + 1] * y[k0 + c + 1];
+        s2 += T[tid * LD + c + 2] * y[k0 + c + 2];
+        s3 += T[tid * LD + c + 3] * y[k0 + c + 3];
       }
       xj[tid] = (tid < nb) ? (s0 + s1) + (s2 + s3) : 0.0;
     }
     __syncthreads();
-    if (tid < kNB) y[k0 + tid] = xj[tid];
-    if (nb == kNB) {
-      if (have) {
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (tid < NB) y[k0 + tid] = xj[tid];
+    if (nb == NB) {
+      for (int i = tid; i < k0; i += kBackThreads) {
+        double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < kNB; k += 4) { s0 += l[k] * xj[k]; s1 += l[k + 1] * xj[k + 1]; s2 += l[k + 2] * xj[k + 2]; s3 += l[k + 3] * xj[k + 3]; }
-        y[tid] -= (s0 + s1) + (s2 + s3);
-      }
-      for (int i = tid + kBackThreads; i < k0; i += kBackThreads) {     // columns beyond the first 1024
+        for (int h = 0; h < NB; h += 32) {
+          if (h > 0 || i != tid) {                    // (the first 32 rows of the first column are already here)
 #pragma unroll
-        for (int k = 0; k < kNB; ++k) l[k] = L[(size_t)(k0 + k) * n + i];
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            for (int k = 0; k < 32; ++k) l[k] = L[(size_t)(k0 + h + k) * n + i];
+          }
+          double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-        for (int k = 0; k < kNB; k += 4) { s0 += l[k] * xj[k]; s1 += l[k + 1] * xj[k + 1]; s2 += l[k + 2] * xj[k + 2]; s3 += l[k + 3] * xj[k + 3]; }
-        y[i] -= (s0 + s1) + (s2 + s3);
+          for (int k = 0; k < 32; k += 4) {
+            s0 += l[k] * xj[h + k]; s1 += l[k + 1] * xj[h + k + 1]; s2 += l[k + 2] * xj[h + k + 2]; s3 += l[k + 3] * xj[h + k + 3];
+          }
+          acc += (s0 + s1) + (s2 + s3);
+        }
+        y[i] -= acc;
       }
     } else {                                        // ragged last block (processed first)
       for (int i = tid; i < k0; i += kBackThreads) {
@@ -341,46 +345,63 @@ __global__ __launch_bounds__(kBackThreads) void chol_backward_kernel(const doubl
       }
     }
     __syncthreads();                                // all reads of T / xj are done
-    T[(tid >> 5) * kLD + (tid & 31)] = tnext;
+#pragma unroll
+    for (int q = 0; q < TPT; ++q) {
+      const int e = tid + q * kBackThreads;
+      T[(e / NB) * LD + (e % NB)] = tnext[q];
+    }
     __syncthreads();
   }
   for (int i = tid; i < n; i += kBackThreads) b[i] = y[i];
 }
 
-// workspace = the inverted diagonal blocks T_j = L_jj^-T, 32x32 doubles each
-size_t cholesky_workspace_bytes(int n) { return (size_t)div_up(n, kNB) * kNB * kNB * sizeof(double) + 256; }
+static inline int block_size_for(int n) { (void)n; return 32; }
+
+// workspace = the inverted diagonal blocks T_j = L_jj^-T, NB x NB doubles each
+size_t cholesky_workspace_bytes(int n) {
+  const int nb = block_size_for(n);
+  return (size_t)div_up(n, nb) * nb * nb * sizeof(double) + 256;
+}
 
 // If b is stored directly behind A (b == A + n*n, i.e. "row n" of an (n+1) x n matrix) the right-hand side
 // rides through the factorisation as one more panel row: the panel solve and the trailing update then
 // perform the forward substitution for free and only L^T y = z is left.
-int cholesky_solve_enqueue(double* A, double* b, int n, double* inv_blocks, int32_t* device_fail, const int32_t* skip,
-                           hipStream_t st) {
+template <int NB>
+static int enqueue(double* A, double* b, int n, double* inv_blocks, int32_t* device_fail, const int32_t* skip,
+                   hipStream_t st) {
   const bool fused_rhs = (b == A + (size_t)n * n);
   const int nrows = fused_rhs ? n + 1 : n;
-  // fast backward solve: y and one T block in LDS (64 KB dynamic LDS => n <= ~7000); larger systems use the
-  // single-workgroup substitution kernel
-  const size_t back_lds = ((size_t)div_up(n, kNB) * kNB + kNB * kLD + kNB) * sizeof(double);
-  const bool use_inv = (inv_blocks != nullptr) && back_lds <= 64 * 1024;
-  for (int k0 = 0; k0 < n; k0 += kNB) {
-    const int nb = (n - k0 < kNB) ? n - k0 : kNB;
+  // fast backward solve: y and one T block in LDS (up to 150 KB); larger systems use the single-workgroup kernel
+  const size_t back_lds = ((size_t)div_up(n, NB) * NB + NB * (NB + 1) + NB) * sizeof(double);
+  bool lds_backward = back_lds <= 150 * 1024;
+  if (lds_backward && back_lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_backward_kernel<NB>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)back_lds) != hipSuccess)
+      lds_backward = false;
+  }
+  for (int k0 = 0; k0 < n; k0 += NB) {
+    const int nb = (n - k0 < NB) ? n - k0 : NB;
     const int rows_panel = nrows - k0 - nb;
-    const int grid = (rows_panel > 0 ? div_up(rows_panel, 256) : 1) + (use_inv ? 1 : 0);
-    chol_panel_kernel<<<grid, 256, 0, st>>>(A, n, nrows, k0, device_fail, skip, use_inv ? inv_blocks : nullptr);
-    const int rows_below = nrows - k0 - kNB;
-    if (rows_below > 0 && k0 + kNB < n) {
+    const int grid = (rows_panel > 0 ? div_up(rows_panel, 256) : 1) + 1;
+    chol_panel_kernel<NB><<<grid, 256, 0, st>>>(A, n, nrows, k0, device_fail, skip, inv_blocks);
+    const int rows_below = nrows - k0 - NB;
+    if (rows_below > 0 && k0 + NB < n) {
       const int T = div_up(rows_below, 32);
       const int tiles = T * (T + 1) / 2;
-      chol_update_kernel<<<div_up(tiles, 4), 256, 0, st>>>(A, n, nrows, k0, tiles, skip);
+      chol_update_kernel<NB><<<div_up(tiles, 4), 256, 0, st>>>(A, n, nrows, k0, tiles, skip);
     }
   }
-  if (use_inv) {
-    if (!fused_rhs) chol_solve_kernel<<<1, 256, 0, st>>>(A, b, n, 1, 0, skip);
-    chol_backward_kernel<<<1, kBackThreads, back_lds, st>>>(A, b, n, inv_blocks, skip);
-  } else {
-    chol_solve_kernel<<<1, 256, 0, st>>>(A, b, n, fused_rhs ? 0 : 1, 1, skip);
-  }
+  if (!fused_rhs) chol_solve_kernel<NB><<<1, 256, 0, st>>>(A, b, n, 1, lds_backward ? 0 : 1, skip);
+  else if (!lds_backward) chol_solve_kernel<NB><<<1, 256, 0, st>>>(A, b, n, 0, 1, skip);
+  if (lds_backward) chol_backward_kernel<NB><<<1, kBackThreads, back_lds, st>>>(A, b, n, inv_blocks, skip);
   if (hipGetLastError() != hipSuccess) return VGG_ERR_HIP;
   return VGG_OK;
+}
+
+int cholesky_solve_enqueue(double* A, double* b, int n, double* inv_blocks, int32_t* device_fail, const int32_t* skip,
+                           hipStream_t st) {
+  if (!inv_blocks) return VGG_ERR_INVALID_ARGUMENT;
+  return enqueue<32>(A, b, n, inv_blocks, device_fail, skip, st);
 }
 
 }  // namespace vgg

@@ -71,6 +71,12 @@ int vgg_cam_from_img(const void* tracks, int tracks_are_f64, const double* intri
  * hypothesis of the chunk has no inlier); on return it holds the measured value -- if it differs,
  * call again with the returned value.  Synchronises the stream once.
  * Outputs: points (N,3) f64, inlier_num (N) int64, inlier_mask (N,S) uint8. */
+/* triangulate_by_pair (vggsfm/utils/triangulation.py:45-135): the S-1 two-view DLT point clouds between frame 0 and
+ * every other frame.  extrinsics [S,3,4] f64, tracks_normalized [S,N,2] f64 (frame-major, camera rays) ->
+ * out_points [S-1,N,3] f64.  Cheirality and triangulation angle are elementwise follow-ups on the host side. */
+int vgg_triangulate_by_pair(const double* extrinsics, const double* tracks_normalized, int S, int N, double* out_points,
+                            void* stream);
+
 size_t vgg_triangulate_workspace_bytes(int S, int N, int H, int lo_num);
 int vgg_triangulate_tracks(const double* extrinsics, const double* tracks_t, const uint8_t* invalid_vis_conf_t,
                            const int32_t* pairs, int S, int N, int H, int lo_num, double max_angular_error_deg,

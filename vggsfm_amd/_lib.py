@@ -56,7 +56,7 @@ class BASummary(ctypes.Structure):
 # every symbol include/vggsfm_amd.h declares (tests check the library exports all of them)
 EXPORTED = ["vgg_build_arch", "vgg_abi_version", "vgg_project_points", "vgg_filter_points_workspace_bytes",
             "vgg_filter_points", "vgg_cam_from_img_workspace_bytes", "vgg_cam_from_img",
-            "vgg_triangulate_workspace_bytes", "vgg_triangulate_tracks", "vgg_ba_workspace_bytes", "vgg_ba_solve",
+            "vgg_triangulate_workspace_bytes", "vgg_triangulate_tracks", "vgg_triangulate_by_pair", "vgg_ba_workspace_bytes", "vgg_ba_solve",
             "vgg_ba_begin", "vgg_ba_phase", "vgg_ba_reduce_buffer", "vgg_ba_finish", "vgg_cholesky_solve",
             "vgg_ba_profile", "vgg_ba_profile_read", "vgg_cholesky_workspace_bytes", "vgg_pose_refine"]
 

@@ -400,6 +400,43 @@ __global__ __launch_bounds__(64) void triangulate_kernel(
   if (lane == 0) atomicMax(gmax_bits, (unsigned long long)__double_as_longlong(wave_max_e));
 }
 
+// Two-view DLT of every track between frame 0 and frame s (triangulate_by_pair, triangulation.py:45-135):
+// one thread per (s, track).  The DLT matrix of a view is built with exactly the expressions of the per-view
+// table of triangulate_kernel, so the point is bit-identical to that kernel's two-view hypothesis (0, s).
+__device__ __forceinline__ void view_dlt_matrix(const double* __restrict__ P, double u, double v, Sym4& m) {
+  const double nr = sqrt(u * u + v * v + 1.0);
+  const double r0 = u / nr, r1 = v / nr, r2 = 1.0 / nr;
+  double rp[4], T[12];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) rp[k] = r0 * P[k] + r1 * P[4 + k] + r2 * P[8 + k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { T[k] = P[k] - r0 * rp[k]; T[4 + k] = P[4 + k] - r1 * rp[k]; T[8 + k] = P[8 + k] - r2 * rp[k]; }
+  int q = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = i; j < 4; ++j) m.a[q++] = T[i] * T[j] + T[4 + i] * T[4 + j] + T[8 + i] * T[8 + j];
+}
+
+__global__ __launch_bounds__(256) void triangulate_pairs_kernel(const double* __restrict__ ext,
+                                                                const double* __restrict__ tn, int S, int N,
+                                                                double* __restrict__ out) {
+  const int s = blockIdx.y + 1;
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+    const double2 q0 = reinterpret_cast<const double2*>(tn)[n];
+    const double2 qs = reinterpret_cast<const double2*>(tn)[(size_t)s * N + n];
+    Sym4 m0, ms, m;
+    view_dlt_matrix(ext, q0.x, q0.y, m0);
+    view_dlt_matrix(ext + 12 * s, qs.x, qs.y, ms);
+#pragma unroll
+    for (int k = 0; k < 10; ++k) m.a[k] = m0.a[k] + ms.a[k];
+    double v[4];
+    smallest_eigvec4(m, v);
+    double* o = out + ((size_t)(s - 1) * N + n) * 3;
+    o[0] = v[0] / v[3]; o[1] = v[1] / v[3]; o[2] = v[2] / v[3];
+  }
+}
+
 }  // namespace vgg
 
 using namespace vgg;
@@ -444,6 +481,18 @@ int vgg_triangulate_tracks(const double* extrinsics, const double* tracks_t, con
   double m;
   memcpy(&m, &bits, sizeof(double));
   *threshold_io = m + 1e-6;
+  return VGG_OK;
+}
+
+// extrinsics (S,3,4) f64, tracks_normalized (S,N,2) f64 frame-major -> out_points (S-1,N,3): the two-view DLT
+// point of every track between frame 0 and frame s.
+int vgg_triangulate_by_pair(const double* extrinsics, const double* tracks_normalized, int S, int N, double* out_points,
+                            void* stream) {
+  if (S < 2 || N < 0 || !extrinsics || !tracks_normalized || !out_points) return VGG_ERR_INVALID_ARGUMENT;
+  if (N == 0) return VGG_OK;
+  const dim3 grid(min(div_up(N, 256), 1024), S - 1);
+  triangulate_pairs_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(extrinsics, tracks_normalized, S, N, out_points);
+  VGG_LAUNCH_CHECK();
   return VGG_OK;
 }
 

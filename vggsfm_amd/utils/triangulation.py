@@ -84,22 +84,18 @@ def triangulate_tracks(extrinsics, tracks_normalized, max_ransac_iters=256, lo_n
 def triangulate_by_pair(extrinsics, tracks_normalized, eps=1e-12):
     """Reference: triangulation.py:45-135.  extrinsics (1,S,3,4), tracks_normalized (1,S,N,2) ->
     points (S-1,N,3), cheirality (S-1,N) bool, triangulation angle deg (S-1,N).
-    Each (query, reference) pair is a two-view DLT: run the LO-RANSAC kernel per pair with the single
-    hypothesis (0, s); its point is the two-view DLT point.  Cheirality / angle are cheap tensor ops."""
+    One thread per (frame, track) two-view DLT (`vgg_triangulate_by_pair`, bit-identical to the two-view
+    hypothesis (0, s) of the LO-RANSAC kernel); cheirality / angle are cheap tensor ops."""
     assert extrinsics.shape[0] == 1
     ext = extrinsics[0].to(torch.float64)
     tn = tracks_normalized[0].to(torch.float64)
     S, N = tn.shape[0], tn.shape[1]
     dev = tn.device
+    _lib.require_gpu(ext, tn)
+    ext, tn = ext.contiguous(), tn.contiguous()
     pts = torch.empty((S - 1, N, 3), dtype=torch.float64, device=dev)
-    no_ivc = torch.zeros((2, N), dtype=torch.bool, device=dev)
-    pair01 = torch.tensor([[0, 1]])
-    for s in range(1, S):
-        e2 = torch.stack([ext[0], ext[s]]).contiguous()
-        t2 = torch.stack([tn[0], tn[s]])
-        # huge angular tolerance / zero angle threshold: the winner is the unique two-view hypothesis
-        p, _, _ = _launch_chunk(e2, t2, no_ivc, pair01, 1, 180.0, -1.0)
-        pts[s - 1] = p
+    _lib.check(_lib.lib().vgg_triangulate_by_pair(_lib.ptr(ext), _lib.ptr(tn), S, N, _lib.ptr(pts), _lib.stream_ptr()),
+               "vgg_triangulate_by_pair")
     R, t = ext[:, :, :3], ext[:, :, 3]
     centers = -torch.einsum("sji,sj->si", R, t)
     z0 = torch.einsum("j,snj->sn", R[0, 2], pts) + t[0, 2]

@@ -87,6 +87,5 @@ def test_triangulation_recovers_ground_truth_at_scale():
     # 0.5 px noise + 5 % outliers, windows of 5-20 views: the tail belongs to the short, narrow-baseline tracks
     # (values for this seed: median 6.5e-3, q90 0.11, q99 0.66); parity with the oracle is tested above
     assert float(err.median()) < 2e-2 and float(err.quantile(0.9)) < 0.25 and float(err.quantile(0.99)) < 1.5
-    # outlier observations are (almost) never inliers
-    out_inl = (msk & D(sc.outlier).t()).sum().item()
-    assert out_inl <= 0.01 * sc.outlier.sum()
+    # (the synthetic outliers are +-50 px, i.e. mostly INSIDE the reference's 2 degree = 35 px inlier cone at
+    #  f = 1000 px, so no statement about them is made here)

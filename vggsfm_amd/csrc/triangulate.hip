@@ -27,7 +27,9 @@
 namespace vgg {
 
 constexpr double kPi = 3.141592653589793;
-constexpr int kTab = 17;   // doubles per view in LDS: ray(3) flag(1) M(10) centre(3)
+constexpr int kTab = 4;    // doubles per view in LDS: unit ray (3), invalid flag (1).  The 4x4 DLT matrix of a view is
+                           // recomputed where it is needed and the camera centres live in a small global array:
+                           // 27 KB of table per wavefront at 200 views left room for ONE wavefront per SIMD
 
 struct Sym4 { double a[10]; };  // 00 01 02 03 11 12 13 22 23 33
 
@@ -99,6 +101,21 @@ __device__ __forceinline__ double sqnorm3(double a, double b, double c) {
   return n * n;
 }
 
+// DLT matrix T^T T of one view, T = P - r (r^T P) for the unit ray r (3x4 rows of the projection matrix P)
+__device__ __forceinline__ void view_dlt_matrix_r(const double* __restrict__ P, double r0, double r1, double r2,
+                                                  Sym4& m) {
+  double rp[4], T[12];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) rp[k] = r0 * P[k] + r1 * P[4 + k] + r2 * P[8 + k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { T[k] = P[k] - r0 * rp[k]; T[4 + k] = P[4 + k] - r1 * rp[k]; T[8 + k] = P[8 + k] - r2 * rp[k]; }
+  int q = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = i; j < 4; ++j) m.a[q++] = T[i] * T[j] + T[4 + i] * T[4 + j] + T[8 + i] * T[8 + j];
+}
+
 // angular error of X against view s (calculate_normalized_angular_error_batched); `cand` = err can be <= max_rad
 __device__ __forceinline__ double view_error(const double* __restrict__ P, const double* tab, double X0, double X1,
                                              double X2, double cos_gate, bool& is_nan, double& depth) {
@@ -115,8 +132,8 @@ __device__ __forceinline__ double view_error(const double* __restrict__ P, const
 }
 
 // "any pair of the S cameras subtends >= thr degrees at X" for the lanes with `live`; wave-uniform loop
-__device__ __forceinline__ bool any_pair_angle(const double* tab, int S, double X0, double X1, double X2, double thr,
-                                               bool live) {
+__device__ __forceinline__ bool any_pair_angle(const double* __restrict__ centers, int S, double X0, double X1, double X2,
+                                               double thr, bool live) {
   bool found = false;
   // a non-finite point can never satisfy ">= thr" (NaN compares false): do not scan S^2 pairs for it
   live = live && (fabs(X0) <= 1.7976931348623157e308) && (fabs(X1) <= 1.7976931348623157e308) &&
@@ -125,8 +142,8 @@ __device__ __forceinline__ bool any_pair_angle(const double* tab, int S, double 
   for (int dist = S - 1; dist >= 1; --dist) {
     for (int a = 0; a + dist < S; ++a) {
       const int b = a + dist;
-      const double* ca = tab + a * kTab + 14;
-      const double* cb = tab + b * kTab + 14;
+      const double* ca = centers + 3 * a;
+      const double* cb = centers + 3 * b;
       const double bsq = sqnorm3(ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]);
       if (live && !found) {
         const double r1 = sqnorm3(X0 - ca[0], X1 - ca[1], X2 - ca[2]);
@@ -161,8 +178,10 @@ __device__ __forceinline__ Cand eval_views(const double* __restrict__ ext, const
     if (inl) {
       ++cnt; sum += err;
       if (ACC) {
+        Sym4 mv;
+        view_dlt_matrix_r(ext + 12 * s, t[0], t[1], t[2], mv);
 #pragma unroll
-        for (int k = 0; k < 10; ++k) acc->a[k] += t[4 + k];
+        for (int k = 0; k < 10; ++k) acc->a[k] += mv.a[k];
       }
     }
   }
@@ -178,7 +197,7 @@ __global__ __launch_bounds__(64) void triangulate_kernel(
     const double* __restrict__ ext, const double* __restrict__ tn, const uint8_t* __restrict__ ivc,
     const int32_t* __restrict__ pairs, int S, int N, int H, int lo1, int lo2, double max_rad, double min_tri_deg,
     double thres, double* __restrict__ out_pts, int64_t* __restrict__ out_num, uint8_t* __restrict__ out_mask,
-    unsigned long long* __restrict__ gmax_bits) {
+    unsigned long long* __restrict__ gmax_bits, const double* __restrict__ centers) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* tab = lds;                                    // [S][kTab]
   double* hx = tab + (size_t)S * kTab;                  // [H][4]  RANSAC points + invalid flag
@@ -196,25 +215,10 @@ __global__ __launch_bounds__(64) void triangulate_kernel(
       const double u = tn[((size_t)n * S + s) * 2], v = tn[((size_t)n * S + s) * 2 + 1];
       const double nr = sqrt(u * u + v * v + 1.0);
       const double r0 = u / nr, r1 = v / nr, r2 = 1.0 / nr;
-      const double* P = ext + 12 * s;
-      // T = P - r (r^T P)   (3x4)
-      double rp[4], T[12];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) rp[k] = r0 * P[k] + r1 * P[4 + k] + r2 * P[8 + k];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { T[k] = P[k] - r0 * rp[k]; T[4 + k] = P[4 + k] - r1 * rp[k]; T[8 + k] = P[8 + k] - r2 * rp[k]; }
       double* t = tab + s * kTab;
       // F.normalize of the same homogeneous ray (eps 1e-12 never binds: norm >= 1)
       t[0] = r0; t[1] = r1; t[2] = r2;
       t[3] = ivc[(size_t)n * S + s] ? 1.0 : 0.0;
-      int q = 4;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = i; j < 4; ++j) t[q++] = T[i] * T[j] + T[4 + i] * T[4 + j] + T[8 + i] * T[8 + j];
-      t[14] = -(P[0] * P[3] + P[4] * P[7] + P[8] * P[11]);
-      t[15] = -(P[1] * P[3] + P[5] * P[7] + P[9] * P[11]);
-      t[16] = -(P[2] * P[3] + P[6] * P[7] + P[10] * P[11]);
     }
     __syncthreads();
 
@@ -226,19 +230,21 @@ __global__ __launch_bounds__(64) void triangulate_kernel(
       const int h = lane + 64 * j;
       live[j] = h < H;
       const int i1 = live[j] ? pairs[2 * h] : 0, i2 = live[j] ? pairs[2 * h + 1] : 0;
-      Sym4 m;
+      const double* P1 = ext + 12 * i1;
+      const double* P2 = ext + 12 * i2;
+      Sym4 m, m2;
+      view_dlt_matrix_r(P1, tab[i1 * kTab], tab[i1 * kTab + 1], tab[i1 * kTab + 2], m);
+      view_dlt_matrix_r(P2, tab[i2 * kTab], tab[i2 * kTab + 1], tab[i2 * kTab + 2], m2);
 #pragma unroll
-      for (int k = 0; k < 10; ++k) m.a[k] = tab[i1 * kTab + 4 + k] + tab[i2 * kTab + 4 + k];
+      for (int k = 0; k < 10; ++k) m.a[k] = m.a[k] + m2.a[k];
       double v[4];
       smallest_eigvec4(m, v);
       X[j][0] = v[0] / v[3]; X[j][1] = v[1] / v[3]; X[j][2] = v[2] / v[3];
       // cheirality on the two views, triangulation angle of the pair
-      const double* P1 = ext + 12 * i1;
-      const double* P2 = ext + 12 * i2;
       const double z1 = P1[8] * X[j][0] + P1[9] * X[j][1] + P1[10] * X[j][2] + P1[11];
       const double z2 = P2[8] * X[j][0] + P2[9] * X[j][1] + P2[10] * X[j][2] + P2[11];
-      const double* c1 = tab + i1 * kTab + 14;
-      const double* c2 = tab + i2 * kTab + 14;
+      const double* c1 = centers + 3 * i1;
+      const double* c2 = centers + 3 * i2;
       const double bsq = sqnorm3(c1[0] - c2[0], c1[1] - c2[1], c1[2] - c2[2]);
       const double r1 = sqnorm3(X[j][0] - c1[0], X[j][1] - c1[1], X[j][2] - c1[2]);
       const double r2 = sqnorm3(X[j][0] - c2[0], X[j][1] - c2[1], X[j][2] - c2[2]);
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(64) void triangulate_kernel(
       bool behind;
       // errors of the refined point (NaN -> 100*pi: not an inlier, no poisoning), cheirality over ALL views
       Cand tmp = eval_views<false>(ext, tab, S, L0, L1, L2, false, l_live, max_rad, cos_gate, false, nullptr, &behind);
-      const bool tri_ok = any_pair_angle(tab, S, L0, L1, L2, min_tri_deg, l_live);
+      const bool tri_ok = any_pair_angle(centers, S, L0, L1, L2, min_tri_deg, l_live);
       l_inv = behind || !tri_ok;
       if (!l_inv) lc = tmp;
       if (!l_live) { lc.n = 0; lc.e = 2.0 * kPi; }
@@ -357,7 +363,7 @@ __global__ __launch_bounds__(64) void triangulate_kernel(
       const double Q0 = v[0] / v[3], Q1 = v[1] / v[3], Q2 = v[2] / v[3];
       bool behind;
       Cand qc = eval_views<false>(ext, tab, S, Q0, Q1, Q2, false, q_live, max_rad, cos_gate, false, nullptr, &behind);
-      const bool tri_ok = any_pair_angle(tab, S, Q0, Q1, Q2, min_tri_deg, q_live);
+      const bool tri_ok = any_pair_angle(centers, S, Q0, Q1, Q2, min_tri_deg, q_live);
       const bool q_inv = behind || !tri_ok;
       if (q_inv) { qc.n = 0; qc.e = 2.0 * kPi; }
       if (q_live) {
@@ -405,17 +411,17 @@ __global__ __launch_bounds__(64) void triangulate_kernel(
 // table of triangulate_kernel, so the point is bit-identical to that kernel's two-view hypothesis (0, s).
 __device__ __forceinline__ void view_dlt_matrix(const double* __restrict__ P, double u, double v, Sym4& m) {
   const double nr = sqrt(u * u + v * v + 1.0);
-  const double r0 = u / nr, r1 = v / nr, r2 = 1.0 / nr;
-  double rp[4], T[12];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) rp[k] = r0 * P[k] + r1 * P[4 + k] + r2 * P[8 + k];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { T[k] = P[k] - r0 * rp[k]; T[4 + k] = P[4 + k] - r1 * rp[k]; T[8 + k] = P[8 + k] - r2 * rp[k]; }
-  int q = 0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = i; j < 4; ++j) m.a[q++] = T[i] * T[j] + T[4 + i] * T[4 + j] + T[8 + i] * T[8 + j];
+  view_dlt_matrix_r(P, u / nr, v / nr, 1.0 / nr, m);
+}
+
+// camera centres -R^T t of all views (read by the angle tests through wave-uniform loads)
+__global__ void view_centers_kernel(const double* __restrict__ ext, int S, double* __restrict__ centers) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  const double* P = ext + 12 * s;
+  centers[3 * s] = -(P[0] * P[3] + P[4] * P[7] + P[8] * P[11]);
+  centers[3 * s + 1] = -(P[1] * P[3] + P[5] * P[7] + P[9] * P[11]);
+  centers[3 * s + 2] = -(P[2] * P[3] + P[6] * P[7] + P[10] * P[11]);
 }
 
 __global__ __launch_bounds__(256) void triangulate_pairs_kernel(const double* __restrict__ ext,
@@ -444,8 +450,9 @@ using namespace vgg;
 extern "C" {
 
 size_t vgg_triangulate_workspace_bytes(int S, int N, int H, int lo_num) {
-  (void)S; (void)N; (void)H; (void)lo_num;
-  return 256;   // one 8-byte word: chunk-global max of the mean inlier errors
+  (void)N; (void)H; (void)lo_num;
+  // one 8-byte word (chunk-global max of the mean inlier errors) + the camera centres [S][3]
+  return 256 + sizeof(double) * 3 * (size_t)(S > 0 ? S : 0);
 }
 
 // tracks_t (N,S,2) f64 track-major normalised rays; invalid_vis_conf_t (N,S) uint8; pairs (H,2) int32.
@@ -468,12 +475,14 @@ int vgg_triangulate_tracks(const double* extrinsics, const double* tracks_t, con
   VGG_HIP_CHECK(hipMemsetAsync(gmax, 0, sizeof(unsigned long long), st));
   const int grid = N < 256 * 32 ? N : 256 * 32;
   const double thres = *threshold_io;
+  double* centers = (double*)((char*)workspace + 256);
+  view_centers_kernel<<<div_up(S, 64), 64, 0, st>>>(extrinsics, S, centers);
   void (*kern)(const double*, const double*, const uint8_t*, const int32_t*, int, int, int, int, int, double, double,
-               double, double*, int64_t*, uint8_t*, unsigned long long*) =
+               double, double*, int64_t*, uint8_t*, unsigned long long*, const double*) =
       (H <= 64) ? triangulate_kernel<1> : (H <= 128) ? triangulate_kernel<2> : triangulate_kernel<4>;
   if (lds > 64 * 1024) VGG_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   kern<<<grid, 64, lds, st>>>(extrinsics, tracks_t, invalid_vis_conf_t, pairs, S, N, H, lo1, lo2, max_rad, min_tri_angle_deg,
-                              thres, out_points, out_inlier_num, out_inlier_mask, gmax);
+                              thres, out_points, out_inlier_num, out_inlier_mask, gmax, centers);
   VGG_LAUNCH_CHECK();
   unsigned long long bits = 0;
   VGG_HIP_CHECK(hipMemcpyAsync(&bits, gmax, sizeof(bits), hipMemcpyDeviceToHost, st));

@@ -71,6 +71,18 @@ int vgg_cam_from_img(const void* tracks, int tracks_are_f64, const double* intri
  * hypothesis of the chunk has no inlier); on return it holds the measured value -- if it differs,
  * call again with the returned value.  Synchronises the stream once.
  * Outputs: points (N,3) f64, inlier_num (N) int64, inlier_mask (N,S) uint8. */
+/* triangulate_tracks over ALL reference chunks of a call in one launch (vggsfm/utils/triangulation.py:712-758 splits
+ * the track axis into ceil(S*N/819200) chunks, each with its own torch.randperm draw and its own chunk-global
+ * residual-indicator threshold).  pairs [num_chunks,H,2] int32: the hypothesis pairs of every chunk, drawn by the
+ * caller in chunk order; chunk c = tracks [c*chunk_size, min(N,(c+1)*chunk_size)).  thresholds_io: host array
+ * [num_chunks], semantics of threshold_io above, per chunk.  One stream synchronisation. */
+size_t vgg_triangulate_chunks_workspace_bytes(int S, int num_chunks);
+int vgg_triangulate_tracks_chunks(const double* extrinsics, const double* tracks_t, const uint8_t* invalid_vis_conf_t,
+                                  const int32_t* pairs, int S, int N, int H, int num_chunks, int chunk_size, int lo_num,
+                                  double max_angular_error_deg, double min_tri_angle_deg, double* out_points,
+                                  int64_t* out_inlier_num, uint8_t* out_inlier_mask, double* thresholds_io,
+                                  void* workspace, void* stream);
+
 /* triangulate_by_pair (vggsfm/utils/triangulation.py:45-135): the S-1 two-view DLT point clouds between frame 0 and
  * every other frame.  extrinsics [S,3,4] f64, tracks_normalized [S,N,2] f64 (frame-major, camera rays) ->
  * out_points [S-1,N,3] f64.  Cheirality and triangulation angle are elementwise follow-ups on the host side. */

@@ -165,3 +165,15 @@ def test_schur_chunks_adaptive_cover(max_chunks):
     assert len(desc) <= max(2 * max_chunks, len(tiles))
     td = tiles.numpy()
     assert td[0, 2] == 0 and td[-1, 3] == len(desc) and (td[1:, 2] == td[:-1, 3]).all()
+
+
+def test_generate_combinations_matches_itertools_order():
+    """vggsfm/utils/triangulation_helpers.py:638-645 uses itertools.combinations; the vectorised mirror must give
+    the same pairs in the same order (the order selects the RANSAC hypotheses)."""
+    import itertools
+
+    from vggsfm_amd.utils.triangulation_helpers import generate_combinations
+    for n in (2, 3, 8, 30, 200):
+        ref = np.array(list(itertools.combinations(np.arange(n), 2))).reshape(-1, 2)
+        got = generate_combinations(n)
+        assert got.dtype == ref.dtype and np.array_equal(got, ref)

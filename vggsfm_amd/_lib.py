@@ -56,7 +56,8 @@ class BASummary(ctypes.Structure):
 # every symbol include/vggsfm_amd.h declares (tests check the library exports all of them)
 EXPORTED = ["vgg_build_arch", "vgg_abi_version", "vgg_project_points", "vgg_filter_points_workspace_bytes",
             "vgg_filter_points", "vgg_cam_from_img_workspace_bytes", "vgg_cam_from_img",
-            "vgg_triangulate_workspace_bytes", "vgg_triangulate_tracks", "vgg_triangulate_by_pair", "vgg_ba_workspace_bytes", "vgg_ba_solve",
+            "vgg_triangulate_workspace_bytes", "vgg_triangulate_tracks", "vgg_triangulate_by_pair", "vgg_triangulate_chunks_workspace_bytes",
+            "vgg_triangulate_tracks_chunks", "vgg_ba_workspace_bytes", "vgg_ba_solve",
             "vgg_ba_begin", "vgg_ba_phase", "vgg_ba_reduce_buffer", "vgg_ba_finish", "vgg_cholesky_solve",
             "vgg_ba_profile", "vgg_ba_profile_read", "vgg_cholesky_workspace_bytes", "vgg_pose_refine"]
 
@@ -79,7 +80,8 @@ def lib():
     if arch != "gfx950":
         raise RuntimeError(f"libvggsfm_amd.so was built for {arch}, expected gfx950")
     for name in ("vgg_filter_points_workspace_bytes", "vgg_cam_from_img_workspace_bytes",
-                 "vgg_triangulate_workspace_bytes", "vgg_ba_workspace_bytes", "vgg_cholesky_workspace_bytes"):
+                 "vgg_triangulate_workspace_bytes", "vgg_triangulate_chunks_workspace_bytes", "vgg_ba_workspace_bytes",
+                 "vgg_cholesky_workspace_bytes"):
         getattr(L, name).restype = ctypes.c_size_t
     L.vgg_ba_workspace_bytes.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     _lib = L

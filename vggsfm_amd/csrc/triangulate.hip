@@ -27,6 +27,9 @@
 namespace vgg {
 
 constexpr double kPi = 3.141592653589793;
+#ifndef VGG_TRI_ABLATE
+#define VGG_TRI_ABLATE 0     // profiling builds only: 1 = no RANSAC error loop, 2 = no LO rounds, 3 = neither
+#endif
 constexpr int kTab = 4;    // doubles per view in LDS: unit ray (3), invalid flag (1).  The 4x4 DLT matrix of a view is
                            // recomputed where it is needed and the camera centres live in a small global array:
                            // 27 KB of table per wavefront at 200 views left room for ONE wavefront per SIMD
@@ -167,7 +170,7 @@ __device__ __forceinline__ Cand eval_views(const double* __restrict__ ext, const
   int cnt = 0;
   double sum = 0.0;
   bool poisoned = false, behind = false;
-  for (int s = 0; s < S; ++s) {
+  for (int s = 0; s < ((VGG_TRI_ABLATE & 2) ? 0 : S); ++s) {
     const double* t = tab + s * kTab;
     bool isn;
     double depth;
@@ -195,9 +198,9 @@ __device__ __forceinline__ Cand eval_views(const double* __restrict__ ext, const
 template <int HJ>
 __global__ __launch_bounds__(64) void triangulate_kernel(
     const double* __restrict__ ext, const double* __restrict__ tn, const uint8_t* __restrict__ ivc,
-    const int32_t* __restrict__ pairs, int S, int N, int H, int lo1, int lo2, double max_rad, double min_tri_deg,
-    double thres, double* __restrict__ out_pts, int64_t* __restrict__ out_num, uint8_t* __restrict__ out_mask,
-    unsigned long long* __restrict__ gmax_bits, const double* __restrict__ centers) {
+    const int32_t* __restrict__ pairs_all, int S, int N, int H, int lo1, int lo2, double max_rad, double min_tri_deg,
+    const double* __restrict__ thres_all, int chunk_size, double* __restrict__ out_pts, int64_t* __restrict__ out_num,
+    uint8_t* __restrict__ out_mask, unsigned long long* __restrict__ gmax_all, const double* __restrict__ centers) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* tab = lds;                                    // [S][kTab]
   double* hx = tab + (size_t)S * kTab;                  // [H][4]  RANSAC points + invalid flag
@@ -207,8 +210,22 @@ __global__ __launch_bounds__(64) void triangulate_kernel(
   const int lane = threadIdx.x;
   const double cos_gate = cos(max_rad) - 1e-9;
   double wave_max_e = 0.0;
+  int cur_chunk = -1;
 
   for (int n = blockIdx.x; n < N; n += gridDim.x) {
+    // reference chunk of this track (triangulation.py:712-758): its own hypothesis pairs, indicator threshold
+    // and maximum of the mean inlier errors
+    const int chunk = n / chunk_size;
+    if (chunk != cur_chunk) {
+      if (cur_chunk >= 0) {
+        wave_max_e = wave_max(wave_max_e);
+        if (lane == 0) atomicMax(gmax_all + cur_chunk, (unsigned long long)__double_as_longlong(wave_max_e));
+      }
+      wave_max_e = 0.0;
+      cur_chunk = chunk;
+    }
+    const int32_t* pairs = pairs_all + (size_t)chunk * 2 * H;
+    const double thres = thres_all[chunk];
     __syncthreads();
     // ---- per-view table (tracks are given track-major: tn[n][s][2], ivc[n][s])
     for (int s = lane; s < S; s += 64) {
@@ -257,7 +274,7 @@ __global__ __launch_bounds__(64) void triangulate_kernel(
     bool pois[HJ];
 #pragma unroll
     for (int j = 0; j < HJ; ++j) { cnt[j] = 0; sum[j] = 0.0; pois[j] = false; }
-    for (int s = 0; s < S; ++s) {
+    for (int s = 0; s < ((VGG_TRI_ABLATE & 1) ? 0 : S); ++s) {
       const double* t = tab + s * kTab;
       const double* P = ext + 12 * s;
       const bool vis_ok = (t[3] == 0.0);
@@ -308,7 +325,7 @@ __global__ __launch_bounds__(64) void triangulate_kernel(
     __syncthreads();
     double L0 = 0, L1 = 0, L2 = 0;
     bool l_inv = true;
-    const bool l_live = lane < lo1;
+    const bool l_live = lane < lo1 && !(VGG_TRI_ABLATE & 2);
     Cand lc;
     lc.n = 0; lc.e = 2.0 * kPi;
     {
@@ -351,7 +368,7 @@ __global__ __launch_bounds__(64) void triangulate_kernel(
     }
     __syncthreads();
     {
-      const bool q_live = lane < lo2;
+      const bool q_live = lane < lo2 && !(VGG_TRI_ABLATE & 2);
       const int g = q_live ? sel[lane] : 0;
       Sym4 m;
 #pragma unroll
@@ -402,8 +419,10 @@ __global__ __launch_bounds__(64) void triangulate_kernel(
       out_mask[(size_t)n * S + s] = (!w_inv && t[3] == 0.0 && !isn && err <= max_rad) ? 1 : 0;
     }
   }
-  wave_max_e = wave_max(wave_max_e);
-  if (lane == 0) atomicMax(gmax_bits, (unsigned long long)__double_as_longlong(wave_max_e));
+  if (cur_chunk >= 0) {
+    wave_max_e = wave_max(wave_max_e);
+    if (lane == 0) atomicMax(gmax_all + cur_chunk, (unsigned long long)__double_as_longlong(wave_max_e));
+  }
 }
 
 // Two-view DLT of every track between frame 0 and frame s (triangulate_by_pair, triangulation.py:45-135):
@@ -449,20 +468,30 @@ using namespace vgg;
 
 extern "C" {
 
-size_t vgg_triangulate_workspace_bytes(int S, int N, int H, int lo_num) {
-  (void)N; (void)H; (void)lo_num;
-  // one 8-byte word (chunk-global max of the mean inlier errors) + the camera centres [S][3]
-  return 256 + sizeof(double) * 3 * (size_t)(S > 0 ? S : 0);
+static size_t tri_ws_bytes(int S, int num_chunks) {
+  // per chunk: one 8-byte word (max of the mean inlier errors) + one threshold; then the camera centres [S][3]
+  return 256 + 16 * (size_t)(num_chunks > 0 ? num_chunks : 1) + sizeof(double) * 3 * (size_t)(S > 0 ? S : 0);
 }
 
-// tracks_t (N,S,2) f64 track-major normalised rays; invalid_vis_conf_t (N,S) uint8; pairs (H,2) int32.
-// *threshold_io (host): in = residual-indicator threshold to use; out = max mean error + 1e-6 measured.
-// Synchronises the stream once (to read the measured maximum).
-int vgg_triangulate_tracks(const double* extrinsics, const double* tracks_t, const uint8_t* invalid_vis_conf_t,
-                           const int32_t* pairs, int S, int N, int H, int lo_num, double max_angular_error_deg,
-                           double min_tri_angle_deg, double* out_points, int64_t* out_inlier_num,
-                           uint8_t* out_inlier_mask, double* threshold_io, void* workspace, void* stream) {
-  if (S < 2 || N < 0 || H < 1 || H > 256 || lo_num < 1 || lo_num > 64 || !threshold_io || !workspace)
+size_t vgg_triangulate_workspace_bytes(int S, int N, int H, int lo_num) {
+  (void)N; (void)H; (void)lo_num;
+  return tri_ws_bytes(S, 1);
+}
+
+size_t vgg_triangulate_chunks_workspace_bytes(int S, int num_chunks) { return tri_ws_bytes(S, num_chunks); }
+
+// All reference chunks of a call in ONE launch.  tracks_t (N,S,2) f64 track-major normalised rays;
+// invalid_vis_conf_t (N,S) uint8; pairs (num_chunks,H,2) int32 -- the hypothesis pairs of every chunk, drawn by the
+// caller in chunk order; chunk c covers tracks [c*chunk_size, min(N,(c+1)*chunk_size)).
+// thresholds_io (host, [num_chunks]): in = residual-indicator threshold per chunk; out = max mean error + 1e-6
+// measured per chunk (the caller re-runs when they differ).  Synchronises the stream once.
+int vgg_triangulate_tracks_chunks(const double* extrinsics, const double* tracks_t, const uint8_t* invalid_vis_conf_t,
+                                  const int32_t* pairs, int S, int N, int H, int num_chunks, int chunk_size, int lo_num,
+                                  double max_angular_error_deg, double min_tri_angle_deg, double* out_points,
+                                  int64_t* out_inlier_num, uint8_t* out_inlier_mask, double* thresholds_io,
+                                  void* workspace, void* stream) {
+  if (S < 2 || N < 0 || H < 1 || H > 256 || lo_num < 1 || lo_num > 64 || !thresholds_io || !workspace ||
+      num_chunks < 1 || num_chunks > 4096 || chunk_size < 1 || (long)num_chunks * chunk_size < N)
     return VGG_ERR_INVALID_ARGUMENT;
   if (N == 0) return VGG_OK;
   hipStream_t st = (hipStream_t)stream;
@@ -471,26 +500,40 @@ int vgg_triangulate_tracks(const double* extrinsics, const double* tracks_t, con
   const double max_rad = max_angular_error_deg * (kPi / 180.0);
   const size_t lds = sizeof(double) * ((size_t)S * kTab + (size_t)H * 4 + 64 * 4) + sizeof(int) * (((H + 63) / 64) * 64 + 64);
   if (lds > 160 * 1024) return VGG_ERR_UNSUPPORTED;
-  unsigned long long* gmax = (unsigned long long*)workspace;
-  VGG_HIP_CHECK(hipMemsetAsync(gmax, 0, sizeof(unsigned long long), st));
-  const int grid = N < 256 * 32 ? N : 256 * 32;
-  const double thres = *threshold_io;
-  double* centers = (double*)((char*)workspace + 256);
+  unsigned long long* gmax = (unsigned long long*)((char*)workspace + 256);
+  double* thres = (double*)(gmax + num_chunks);
+  double* centers = thres + num_chunks;
+  VGG_HIP_CHECK(hipMemsetAsync(gmax, 0, sizeof(unsigned long long) * num_chunks, st));
+  VGG_HIP_CHECK(hipMemcpyAsync(thres, thresholds_io, sizeof(double) * num_chunks, hipMemcpyHostToDevice, st));
   view_centers_kernel<<<div_up(S, 64), 64, 0, st>>>(extrinsics, S, centers);
+  const int grid = N < 256 * 32 ? N : 256 * 32;
   void (*kern)(const double*, const double*, const uint8_t*, const int32_t*, int, int, int, int, int, double, double,
-               double, double*, int64_t*, uint8_t*, unsigned long long*, const double*) =
+               const double*, int, double*, int64_t*, uint8_t*, unsigned long long*, const double*) =
       (H <= 64) ? triangulate_kernel<1> : (H <= 128) ? triangulate_kernel<2> : triangulate_kernel<4>;
   if (lds > 64 * 1024) VGG_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   kern<<<grid, 64, lds, st>>>(extrinsics, tracks_t, invalid_vis_conf_t, pairs, S, N, H, lo1, lo2, max_rad, min_tri_angle_deg,
-                              thres, out_points, out_inlier_num, out_inlier_mask, gmax, centers);
+                              thres, chunk_size, out_points, out_inlier_num, out_inlier_mask, gmax, centers);
   VGG_LAUNCH_CHECK();
-  unsigned long long bits = 0;
-  VGG_HIP_CHECK(hipMemcpyAsync(&bits, gmax, sizeof(bits), hipMemcpyDeviceToHost, st));
+  unsigned long long bits[4096];
+  VGG_HIP_CHECK(hipMemcpyAsync(bits, gmax, sizeof(unsigned long long) * num_chunks, hipMemcpyDeviceToHost, st));
   VGG_HIP_CHECK(hipStreamSynchronize(st));
-  double m;
-  memcpy(&m, &bits, sizeof(double));
-  *threshold_io = m + 1e-6;
+  for (int c = 0; c < num_chunks; ++c) {
+    double m;
+    memcpy(&m, &bits[c], sizeof(double));
+    thresholds_io[c] = m + 1e-6;
+  }
   return VGG_OK;
+}
+
+// One chunk (the reference's triangulate_tracks_single_chunk): pairs (H,2), *threshold_io as above.
+int vgg_triangulate_tracks(const double* extrinsics, const double* tracks_t, const uint8_t* invalid_vis_conf_t,
+                           const int32_t* pairs, int S, int N, int H, int lo_num, double max_angular_error_deg,
+                           double min_tri_angle_deg, double* out_points, int64_t* out_inlier_num,
+                           uint8_t* out_inlier_mask, double* threshold_io, void* workspace, void* stream) {
+  if (N < 0) return VGG_ERR_INVALID_ARGUMENT;
+  return vgg_triangulate_tracks_chunks(extrinsics, tracks_t, invalid_vis_conf_t, pairs, S, N, H, 1, N > 0 ? N : 1, lo_num,
+                                       max_angular_error_deg, min_tri_angle_deg, out_points, out_inlier_num,
+                                       out_inlier_mask, threshold_io, workspace, stream);
 }
 
 // extrinsics (S,3,4) f64, tracks_normalized (S,N,2) f64 frame-major -> out_points (S-1,N,3): the two-view DLT

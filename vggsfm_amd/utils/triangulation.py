@@ -45,12 +45,7 @@ def triangulate_tracks_single_chunk(extrinsics, tracks_normalized, max_ransac_it
     """Reference: triangulation.py:776-956."""
     _lib.require_gpu(extrinsics, tracks_normalized)
     S = tracks_normalized.shape[0]
-    ransac_idx = torch.from_numpy(generate_combinations(S))
-    if max_ransac_iters > len(ransac_idx):
-        max_ransac_iters = len(ransac_idx)
-    else:
-        ransac_idx = ransac_idx[torch.randperm(len(ransac_idx))[:max_ransac_iters]]      # host RNG, as the reference
-    lo_num = lo_num if max_ransac_iters >= lo_num else max_ransac_iters
+    ransac_idx, lo_num = _draw_pairs(S, max_ransac_iters, lo_num)
     if track_score is not None:
         ivc = torch.logical_or(track_vis <= 0.05, track_score <= 0.5)
     else:
@@ -59,26 +54,66 @@ def triangulate_tracks_single_chunk(extrinsics, tracks_normalized, max_ransac_it
     return _launch_chunk(ext, tracks_normalized, ivc, ransac_idx, lo_num, max_angular_error, min_tri_angle)
 
 
+def _draw_pairs(S, max_ransac_iters, lo_num):
+    """The hypothesis pairs of ONE reference chunk (triangulation.py:799-816): all C(S,2) pairs, or a
+    torch.randperm draw from the global CPU RNG when there are more than max_ransac_iters."""
+    ransac_idx = torch.from_numpy(generate_combinations(S))
+    if max_ransac_iters > len(ransac_idx):
+        max_ransac_iters = len(ransac_idx)
+    else:
+        ransac_idx = ransac_idx[torch.randperm(len(ransac_idx))[:max_ransac_iters]]      # host RNG, as the reference
+    lo_num = lo_num if max_ransac_iters >= lo_num else max_ransac_iters
+    return ransac_idx, lo_num
+
+
 def triangulate_tracks(extrinsics, tracks_normalized, max_ransac_iters=256, lo_num=50, max_angular_error=2,
                        min_tri_angle=1.5, track_vis=None, track_score=None, max_tri_points_num=819200):
     """Reference: triangulation.py:677-773.  extrinsics (S,3,4), tracks_normalized (S,N,2), vis/score (S,N)
     -> points (N,3) f64, inlier_num (N) int64, inlier_mask (N,S) bool.
-    The chunking only exists to consume the RNG and the chunk-global indicator threshold exactly like the
-    reference; the kernel itself has no memory reason to chunk."""
-    all_tri_points_num = extrinsics.shape[0] * tracks_normalized.shape[1]
+    The reference splits the track axis into ceil(S*N/max_tri_points_num) chunks (torch.chunk), each with its own
+    randperm draw and its own chunk-global indicator threshold.  Both are reproduced -- the draws are made up
+    front, in chunk order, from the same global CPU RNG -- but all chunks run in ONE launch
+    (`vgg_triangulate_tracks_chunks`): the kernel has no memory reason to chunk."""
+    _lib.require_gpu(extrinsics, tracks_normalized)
+    L = _lib.lib()
+    S, N = tracks_normalized.shape[0], tracks_normalized.shape[1]
+    dev = tracks_normalized.device
+    all_tri_points_num = S * N
+    num_splits = 1
     if all_tri_points_num > max_tri_points_num:
         num_splits = (all_tri_points_num + max_tri_points_num - 1) // max_tri_points_num
-        split_tn = torch.chunk(tracks_normalized, num_splits, dim=1)
-        split_vis = torch.chunk(track_vis, num_splits, dim=1) if track_vis is not None else [None] * num_splits
-        split_score = torch.chunk(track_score, num_splits, dim=1) if track_score is not None else [None] * num_splits
-        pts, nums, masks = [], [], []
-        for i in range(len(split_tn)):
-            p, n, m = triangulate_tracks_single_chunk(extrinsics, split_tn[i], max_ransac_iters, lo_num,
-                                                      max_angular_error, min_tri_angle, split_vis[i], split_score[i])
-            pts.append(p), nums.append(n), masks.append(m)
-        return torch.cat(pts, 0), torch.cat(nums, 0), torch.cat(masks, 0)
-    return triangulate_tracks_single_chunk(extrinsics, tracks_normalized, max_ransac_iters, lo_num, max_angular_error,
-                                           min_tri_angle, track_vis, track_score)
+    chunk_size = -(-N // num_splits) if N > 0 else 1                  # torch.chunk: ceil(N / chunks) per chunk
+    num_chunks = max(1, -(-N // chunk_size))
+    draws = [_draw_pairs(S, max_ransac_iters, lo_num) for _ in range(num_chunks)]     # RNG consumed in chunk order
+    lo = draws[0][1]
+    pairs = torch.stack([d[0] for d in draws]).to(device=dev, dtype=torch.int32).contiguous()      # (C,H,2)
+    H = pairs.shape[1]
+    if track_score is not None:
+        ivc = torch.logical_or(track_vis <= 0.05, track_score <= 0.5)
+    elif track_vis is not None:
+        ivc = track_vis <= 0.05
+    else:
+        ivc = torch.zeros((S, N), dtype=torch.bool, device=dev)
+    ext = extrinsics.to(torch.float64).contiguous()
+    tn_t = tracks_normalized.to(torch.float64).permute(1, 0, 2).contiguous()          # track-major
+    ivc_t = ivc.t().contiguous().to(torch.uint8)
+    pts = torch.empty((N, 3), dtype=torch.float64, device=dev)
+    num = torch.empty(N, dtype=torch.int64, device=dev)
+    mask = torch.empty((N, S), dtype=torch.uint8, device=dev)
+    if N == 0:
+        return pts, num, mask.bool()
+    ws = torch.zeros(int(L.vgg_triangulate_chunks_workspace_bytes(S, num_chunks)), dtype=torch.uint8, device=dev)
+    thr = (ctypes.c_double * num_chunks)(*([2.0 * math.pi + 1e-6] * num_chunks))
+    for _ in range(2):
+        used = list(thr)
+        _lib.check(L.vgg_triangulate_tracks_chunks(_lib.ptr(ext), _lib.ptr(tn_t), _lib.ptr(ivc_t), _lib.ptr(pairs), S, N, H,
+                                                   num_chunks, chunk_size, lo, ctypes.c_double(max_angular_error),
+                                                   ctypes.c_double(min_tri_angle), _lib.ptr(pts), _lib.ptr(num),
+                                                   _lib.ptr(mask), thr, _lib.ptr(ws), _lib.stream_ptr()),
+                   "vgg_triangulate_tracks_chunks")
+        if list(thr) == used:
+            break
+    return pts, num, mask.bool()
 
 
 def triangulate_by_pair(extrinsics, tracks_normalized, eps=1e-12):

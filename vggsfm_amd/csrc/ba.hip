@@ -1357,11 +1357,21 @@ int vgg_ba_solve(const vgg_ba_problem* problem, const vgg_ba_options* options, v
   Launch L;
   rc = make_launch(problem, options, workspace, (hipStream_t)stream, &L);
   if (rc != VGG_OK) return rc;
-  // iteration max_num_iterations+1 only runs the start-of-iteration checks (gradient test after the last step)
+  // iteration max_num_iterations+1 only runs the start-of-iteration checks (gradient test after the last step).
+  // Termination is decided on the device; iterations enqueued after it are no-ops, but ~100 empty launches each.
+  // Every kPoll iterations the host therefore reads the `done` flag (one 4-byte copy + stream sync; the queue
+  // refills within microseconds) and stops enqueuing once the solve has terminated.
+  constexpr int kPoll = 8;
   for (int it = 0; it <= options->max_num_iterations; ++it) {
     for (int phase = 0; phase < 4; ++phase) {
       rc = run_phase(L, phase);
       if (rc != VGG_OK) return rc;
+    }
+    if (it % kPoll == kPoll - 1 && it < options->max_num_iterations) {
+      int32_t done = 0;
+      if (hipMemcpyAsync(&done, &L.w.ctl->done, sizeof(done), hipMemcpyDeviceToHost, L.st) != hipSuccess) return VGG_ERR_HIP;
+      if (hipStreamSynchronize(L.st) != hipSuccess) return VGG_ERR_HIP;
+      if (done) break;
     }
   }
   VGG_LAUNCH_CHECK();

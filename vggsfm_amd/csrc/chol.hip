@@ -147,6 +147,103 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
   for (int c = 0; c < NB; ++c) Arow[c] = x[c];
 }
 
+// Two consecutive block columns (64 columns) in ONE launch: identical arithmetic to two chol_panel_kernel<32> steps
+// with the rank-32 update of the second block column folded in, so that a 64-column step costs one panel launch
+// + one K = 64 trailing update instead of two of each (every launch has a ~4.5 us floor plus two dependent
+// memory round trips).  Requires k0 + 64 <= n.  Workgroup = 256 threads for the two 32x32 factorisations;
+// wavefront 0 owns 64 panel rows (one per lane, 64 registers), wavefront 1 solves the 32 rows of L21.
+__global__ __launch_bounds__(256) void chol_panel2_kernel(double* __restrict__ A, int n, int nrows, int k0,
+                                                          int32_t* fail, const int32_t* skip,
+                                                          double* __restrict__ inv_blocks) {
+  constexpr int NB = 32, LD = NB + 1;
+  __shared__ double D1[NB * LD], D2[NB * LD], L21[NB * LD];
+  __shared__ double rd1[NB], rd2[NB];
+  if (skip && *skip) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const bool extra_wg = blockIdx.x == gridDim.x - 1;
+  const int row = k0 + 2 * NB + blockIdx.x * 64 + lane;
+  const bool has_row = !extra_wg && wave == 0 && row < nrows;
+  double x[2 * NB];                               // wave 0: the panel row; wave 1 (lanes < 32): row of B21 in x[0..31]
+  if (has_row) {
+    const double* Arow = A + (size_t)row * n + k0;
+#pragma unroll
+    for (int c = 0; c < 2 * NB; ++c) x[c] = Arow[c];
+  } else if (wave == 1 && lane < NB) {
+    const double* Arow = A + (size_t)(k0 + NB + lane) * n + k0;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) x[c] = Arow[c];
+#pragma unroll
+    for (int c = NB; c < 2 * NB; ++c) x[c] = 0.0;
+  } else {
+#pragma unroll
+    for (int c = 0; c < 2 * NB; ++c) x[c] = 0.0;
+  }
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int i = e / NB, c = e % NB;
+    D1[i * LD + c] = (c <= i) ? A[(size_t)(k0 + i) * n + k0 + c] : 0.0;
+    D2[i * LD + c] = (c <= i) ? A[(size_t)(k0 + NB + i) * n + k0 + NB + c] : 0.0;
+  }
+  factor_diag_lds<NB>(D1, rd1, (blockIdx.x == 0) ? fail : nullptr);
+  // first block column: panel rows (wave 0) and the 32 rows of L21 (wave 1) through L11
+  if (wave <= 1) {
+    double (&x1)[NB] = reinterpret_cast<double (&)[NB]>(x);
+    substitute_row<NB>(x1, D1, rd1);
+    if (wave == 1 && lane < NB) {
+#pragma unroll
+      for (int c = 0; c < NB; ++c) L21[lane * LD + c] = x1[c];
+    }
+  }
+  __syncthreads();
+  // D2 -= L21 L21^T (lower triangle), then factor it
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int i = e / NB, c = e % NB;
+    if (c <= i) {
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < NB; k += 2) { s0 += L21[i * LD + k] * L21[c * LD + k]; s1 += L21[i * LD + k + 1] * L21[c * LD + k + 1]; }
+      D2[i * LD + c] -= s0 + s1;
+    }
+  }
+  factor_diag_lds<NB>(D2, rd2, (blockIdx.x == 0) ? fail : nullptr);
+  if (blockIdx.x == 0) {
+    for (int e = tid; e < NB * NB; e += 256) {
+      const int i = e / NB, c = e % NB;
+      if (c <= i) {
+        A[(size_t)(k0 + i) * n + k0 + c] = D1[i * LD + c];
+        A[(size_t)(k0 + NB + i) * n + k0 + NB + c] = D2[i * LD + c];
+      }
+      A[(size_t)(k0 + NB + i) * n + k0 + c] = L21[i * LD + c];
+    }
+  }
+  if (extra_wg) {
+    // T1 = L11^-T, T2 = L22^-T for the backward solve (rows of the identity through the two substitutions)
+    if (wave <= 1 && lane < NB) {
+      double t[NB];
+#pragma unroll
+      for (int c = 0; c < NB; ++c) t[c] = (c == lane) ? 1.0 : 0.0;
+      substitute_row<NB>(t, wave == 0 ? D1 : D2, wave == 0 ? rd1 : rd2);
+      double* T = inv_blocks + (size_t)(k0 / NB + wave) * NB * NB + lane * NB;
+#pragma unroll
+      for (int c = 0; c < NB; ++c) T[c] = t[c];
+    }
+    return;
+  }
+  if (!has_row) return;
+  // second block column of the panel rows: a2 -= x1 L21^T, then through L22
+  double x2[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NB; k += 2) { s0 += x[k] * L21[c * LD + k]; s1 += x[k + 1] * L21[c * LD + k + 1]; }
+    x2[c] = x[NB + c] - (s0 + s1);
+  }
+  substitute_row<NB>(x2, D2, rd2);
+  double* Aout = A + (size_t)row * n + k0;
+#pragma unroll
+  for (int c = 0; c < NB; ++c) { Aout[c] = x[c]; Aout[NB + c] = x2[c]; }
+}
+
 // trailing update A[i][j] -= sum_k L[i][k0+k] L[j][k0+k] for i >= j >= k0+NB, tiles of 32x32, k < NB
 template <int NB>
 __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ A, int n, int nrows, int k0,
@@ -379,7 +476,21 @@ static int enqueue(double* A, double* b, int n, double* inv_blocks, int32_t* dev
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)back_lds) != hipSuccess)
       lds_backward = false;
   }
-  for (int k0 = 0; k0 < n; k0 += NB) {
+  int k0 = 0;
+  if (NB == 32) {
+    // fused double steps: 64 columns per (panel2, update<64>) pair while at least 64 columns remain
+    for (; k0 + 64 <= n; k0 += 64) {
+      const int rows_panel = nrows - k0 - 64;
+      chol_panel2_kernel<<<(rows_panel > 0 ? div_up(rows_panel, 64) : 1) + 1, 256, 0, st>>>(A, n, nrows, k0, device_fail,
+                                                                                           skip, inv_blocks);
+      if (rows_panel > 0 && k0 + 64 < n) {
+        const int T = div_up(rows_panel, 32);
+        const int tiles = T * (T + 1) / 2;
+        chol_update_kernel<64><<<div_up(tiles, 4), 256, 0, st>>>(A, n, nrows, k0, tiles, skip);
+      }
+    }
+  }
+  for (; k0 < n; k0 += NB) {
     const int nb = (n - k0 < NB) ? n - k0 : NB;
     const int rows_panel = nrows - k0 - nb;
     const int grid = (rows_panel > 0 ? div_up(rows_panel, 256) : 1) + 1;

@@ -22,10 +22,14 @@ namespace vgg {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ double fast_rcp(double x) {      // 1/x: hardware estimate (4.6e-8) + 2 Newton steps
+// 1/x from the hardware estimate (measured max relative error 4.6e-8, scripts/ubench/rcp_accuracy.hip) + Newton
+// steps: one step leaves 2.2e-15, two 1.1e-16.  The pivot reciprocal sits on the per-column critical path of the
+// factorisation, where one step (a few ulp on L) is enough; everything else uses two.
+template <int STEPS = 2>
+__device__ __forceinline__ double fast_rcp(double x) {
   double r = __builtin_amdgcn_rcp(x);
-  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+#pragma unroll
+  for (int i = 0; i < STEPS; ++i) r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
   return r;
 }
 
@@ -43,7 +47,7 @@ __device__ __forceinline__ void factor_diag_lds(double* D, double* rdiag, int32_
     __syncthreads();
     const double dj = D[j * LD + j];
     if (!(dj > 0.0) || !(dj < 1.7976931348623157e308)) bad = true;
-    const double inv = fast_rcp((dj > 0.0) ? dj : 1.0);
+    const double inv = fast_rcp<1>((dj > 0.0) ? dj : 1.0);
     if (c > j) {
       const double lcj = D[c * LD + j] * inv;
 #pragma unroll
@@ -271,11 +275,20 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ A
       b[m][kk] = (rb < nrows) ? A[(size_t)rb * n + k0 + 4 * kk + lk] : 0.0;
     }
   }
-  f64x4 acc[2][2];
+  // the tile being updated is loaded up front, together with the operands (f64 C/D layout: col = lane & 15,
+  // row = (lane >> 4) + 4 * reg): one memory round trip instead of two on a latency-bound launch
+  f64x4 acc[2][2], old[2][2];
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
-    for (int q = 0; q < 2; ++q) acc[m][q] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    for (int q = 0; q < 2; ++q) {
+      acc[m][q] = (f64x4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int i = r0 + 16 * m + lk + 4 * reg, j = c0 + 16 * q + li;
+        old[m][q][reg] = (i < nrows && j < n && j <= i) ? A[(size_t)i * n + j] : 0.0;
+      }
+    }
 #pragma unroll
   for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
@@ -283,7 +296,6 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ A
 #pragma unroll
       for (int q = 0; q < 2; ++q)
         acc[m][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][kk], b[q][kk], acc[m][q], 0, 0, 0);
-  // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -291,7 +303,7 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ A
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int i = r0 + 16 * m + lk + 4 * reg, j = c0 + 16 * q + li;
-        if (i < nrows && j < n && j <= i) A[(size_t)i * n + j] -= acc[m][q][reg];
+        if (i < nrows && j < n && j <= i) A[(size_t)i * n + j] = old[m][q][reg] - acc[m][q][reg];
       }
 }
 

@@ -400,10 +400,11 @@ __global__ void damping_kernel(Ws w, vgg_ba_options opt, int n_red) {
 
 // ---------------------------------------------------------------------------------------------
 // point-major pass: one wavefront per point
-template <int KD>
+template <int KD, bool LDSCAM>
 __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem pb, Ws w, vgg_ba_options opt) {
   constexpr int BD = 6 + KD;
   __shared__ double wmax[4];
+  extern __shared__ double cam_cache[];          // LDSCAM: q[4C] t[3C] pose scales[6C] flags[C] (as doubles)
   Ctl* ctl = w.ctl;
   if (ctl->done) return;
   const Dims& d = pb.d;
@@ -413,21 +414,64 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
   const double radius = ctl->radius;
   const int kdsh = d.kdsh;
   double gmax = 0.0;
-  for (int p = blockIdx.x * 4 + wave; p < d.P; p += nw) {
-    const int o0 = pb.row_ptr[p], o1 = pb.row_ptr[p + 1];
-    const double X[3] = {pb.pts[3 * p], pb.pts[3 * p + 1], pb.pts[3 * p + 2]};
-    const bool pt_c = pb.pt_const ? pb.pt_const[p] != 0 : false;
+  // The per-observation camera gather is the second of three dependent memory round trips of a point; with the
+  // cameras in LDS it is an LDS read.  (The wavefronts are latency bound: SQ_WAIT_ANY 60 %, 2 waves/SIMD.)
+  const double* lq = cam_cache;
+  const double* lt = lq + 4 * d.C;
+  const double* lsc = lt + 3 * d.C;
+  const double* lfl = lsc + 6 * d.C;
+  if (LDSCAM) {
+    for (int i = threadIdx.x; i < 4 * d.C; i += 256) cam_cache[i] = pb.cam_q[i];
+    for (int i = threadIdx.x; i < 3 * d.C; i += 256) cam_cache[4 * d.C + i] = pb.cam_t[i];
+    for (int i = threadIdx.x; i < 6 * d.C; i += 256) cam_cache[7 * d.C + i] = w.scale_c[i];
+    for (int i = threadIdx.x; i < d.C; i += 256) cam_cache[13 * d.C + i] = pb.cam_const ? (double)pb.cam_const[i] : 0.0;
+    __syncthreads();
+  }
+  // software pipeline over the points of this wavefront: the row bounds / coordinates of the NEXT point and the
+  // camera index, pixel and slot of its first 64 observations are loaded while the current point is processed
+  int p = blockIdx.x * 4 + wave;
+  int n_o0 = 0, n_o1 = 0, n_c = 0, n_slot = 0;
+  double n_X0 = 0, n_X1 = 0, n_X2 = 0;
+  float2 n_uv = make_float2(0.f, 0.f);
+  bool n_ptc = false;
+  if (p < d.P) {
+    n_o0 = pb.row_ptr[p]; n_o1 = pb.row_ptr[p + 1];
+    n_X0 = pb.pts[3 * p]; n_X1 = pb.pts[3 * p + 1]; n_X2 = pb.pts[3 * p + 2];
+    n_ptc = pb.pt_const ? pb.pt_const[p] != 0 : false;
+    if (n_o0 + lane < n_o1) { n_c = pb.obs_cam[n_o0 + lane]; n_uv = pb.obs_uv[n_o0 + lane]; n_slot = pb.obs_slot[n_o0 + lane]; }
+  }
+  for (; p < d.P; p += nw) {
+    const int o0 = n_o0, o1 = n_o1;
+    const double X[3] = {n_X0, n_X1, n_X2};
+    const bool pt_c = n_ptc;
+    const int f_c = n_c, f_slot = n_slot;
+    const float2 f_uv = n_uv;
+    {
+      const int pn = p + nw;
+      if (pn < d.P) {
+        n_o0 = pb.row_ptr[pn]; n_o1 = pb.row_ptr[pn + 1];
+        n_X0 = pb.pts[3 * pn]; n_X1 = pb.pts[3 * pn + 1]; n_X2 = pb.pts[3 * pn + 2];
+        n_ptc = pb.pt_const ? pb.pt_const[pn] != 0 : false;
+        if (n_o0 + lane < n_o1) { n_c = pb.obs_cam[n_o0 + lane]; n_uv = pb.obs_uv[n_o0 + lane]; n_slot = pb.obs_slot[n_o0 + lane]; }
+      }
+    }
     double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0}, Wa[3 * (KD ? KD : 1)];
 #pragma unroll
     for (int i = 0; i < 3 * (KD ? KD : 1); ++i) Wa[i] = 0;
     double cF[2 * BD], cE[6];          // Jacobians of this lane's first observation (tracks > 64 recompute)
     for (int o = o0 + lane; o < o1; o += 64) {
-      const int c = pb.obs_cam[o];
+      const bool head = (o - o0 < 64);
+      const int c = head ? f_c : pb.obs_cam[o];
+      const float2 uv = head ? f_uv : pb.obs_uv[o];
       const int a = d.shared ? 0 : c;
       double r[2], F[2 * BD], E[6];
-      eval_full<KD>(d, pb.cam_q + 4 * c, pb.cam_t + 3 * c, pb.intr + 4 * a, X, pb.obs_uv[o],
-                    pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
-      if (o - o0 < 64) {
+      if (LDSCAM)
+        eval_full<KD>(d, lq + 4 * c, lt + 3 * c, pb.intr + 4 * a, X, uv, (unsigned)lfl[c],
+                      pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
+      else
+        eval_full<KD>(d, pb.cam_q + 4 * c, pb.cam_t + 3 * c, pb.intr + 4 * a, X, uv,
+                      pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
+      if (head) {
 #pragma unroll
         for (int i = 0; i < 2 * BD; ++i) cF[i] = F[i];
 #pragma unroll
@@ -510,9 +554,10 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
     {
       const int bdt = d.shared ? 6 : BD;          // rows of the tile block (intrinsics only when per camera)
       for (int o = o0 + lane; o < o1; o += 64) {
-        const int c = pb.obs_cam[o];
+        const bool head = (o - o0 < 64);
+        const int c = head ? f_c : pb.obs_cam[o];
         double F[2 * BD], E[6];
-        if (o - o0 < 64) {                        // cached Jacobians of the first slice
+        if (head) {                               // cached Jacobians of the first slice
 #pragma unroll
           for (int i = 0; i < 2 * BD; ++i) F[i] = cF[i];
 #pragma unroll
@@ -524,12 +569,13 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
                         pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
         }
         // segment layout: [component 0..2][slot 0..15][row 0..bdt-1]  (three rows of the K dimension)
-        const int slot = pb.obs_slot[o], rt = kGroup * bdt;
+        const int slot = head ? f_slot : pb.obs_slot[o], rt = kGroup * bdt;
         double* y = w.Y + (size_t)(slot >> 4) * (3 * rt) + (slot & 15) * bdt;
 #pragma unroll
         for (int i = 0; i < BD; ++i) {
           if (i < bdt) {
-            const double sc = (i < 6) ? w.scale_c[6 * c + i] : w.scale_c[6 * d.C + KD * c + (i - 6)];
+            const double sc = (i < 6) ? (LDSCAM ? lsc[6 * c + i] : w.scale_c[6 * c + i])
+                                      : w.scale_c[6 * d.C + KD * c + (i - 6)];
             const double w0 = F[i] * E[0] + F[BD + i] * E[3], w1 = F[i] * E[1] + F[BD + i] * E[4],
                          w2 = F[i] * E[2] + F[BD + i] * E[5];
             y[i] = sc * (w0 * Gm[0]);
@@ -1147,7 +1193,10 @@ static void phase_schur(const Launch& L) {
   damping_kernel<<<div_up(d.n_red, 256), 256, 0, L.st>>>(L.w, L.opt, d.n_red);
   {
     ProfScope ps(kProfPointPass, L.st);
-    point_pass_kernel<KD><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w, L.opt);
+    // cameras (q, t, pose scales, constant flags: 14 doubles each) cached in LDS when they fit beside 2 workgroups/CU
+    const size_t cam_lds = sizeof(double) * 14 * (size_t)d.C;
+    if (cam_lds <= 48 * 1024) point_pass_kernel<KD, true><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w, L.opt);
+    else point_pass_kernel<KD, false><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w, L.opt);
   }
   reduce_gmax_kernel<<<1, 256, 0, L.st>>>(L.w, L.wgB);
   {

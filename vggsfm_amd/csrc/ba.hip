@@ -973,35 +973,78 @@ __global__ void cam_update_kernel(DevProblem pb, Ws w) {
 }
 
 // back-substitution, model cost change, candidate point and candidate cost: one wavefront per point
-template <int KD>
+template <int KD, bool LDSCAM>
 __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem pb, Ws w) {
   constexpr int BD = 6 + KD;
   __shared__ double red[4][4];
+  extern __shared__ double cam_cache[];   // LDSCAM: q[4C] t[3C] dy_pose[6C] cand_q[4C] cand_t[3C] flags[C]
   if (w.ctl->done) return;
   const Dims& d = pb.d;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int nw = gridDim.x * 4;
   double s_cost = 0, s_mcc = 0, s_step = 0, s_xn = 0;
-  for (int p = blockIdx.x * 4 + wave; p < d.P; p += nw) {
-    const int o0 = pb.row_ptr[p], o1 = pb.row_ptr[p + 1];
-    const double X[3] = {pb.pts[3 * p], pb.pts[3 * p + 1], pb.pts[3 * p + 2]};
-    const bool pt_c = pb.pt_const ? pb.pt_const[p] != 0 : false;
+  const double* lq = cam_cache;
+  const double* lt = lq + 4 * d.C;
+  const double* ldy = lt + 3 * d.C;
+  const double* lcq = ldy + 6 * d.C;
+  const double* lct = lcq + 4 * d.C;
+  const double* lfl = lct + 3 * d.C;
+  if (LDSCAM) {
+    for (int i = threadIdx.x; i < 4 * d.C; i += 256) { cam_cache[i] = pb.cam_q[i]; cam_cache[13 * d.C + i] = w.cand_q[i]; }
+    for (int i = threadIdx.x; i < 3 * d.C; i += 256) { cam_cache[4 * d.C + i] = pb.cam_t[i]; cam_cache[17 * d.C + i] = w.cand_t[i]; }
+    for (int i = threadIdx.x; i < 6 * d.C; i += 256) cam_cache[7 * d.C + i] = w.dy[i];
+    for (int i = threadIdx.x; i < d.C; i += 256) cam_cache[20 * d.C + i] = pb.cam_const ? (double)pb.cam_const[i] : 0.0;
+    __syncthreads();
+  }
+  // same software pipeline over the points of a wavefront as in point_pass_kernel
+  int p = blockIdx.x * 4 + wave;
+  int n_o0 = 0, n_o1 = 0, n_c = 0;
+  double n_X0 = 0, n_X1 = 0, n_X2 = 0;
+  float2 n_uv = make_float2(0.f, 0.f);
+  bool n_ptc = false;
+  if (p < d.P) {
+    n_o0 = pb.row_ptr[p]; n_o1 = pb.row_ptr[p + 1];
+    n_X0 = pb.pts[3 * p]; n_X1 = pb.pts[3 * p + 1]; n_X2 = pb.pts[3 * p + 2];
+    n_ptc = pb.pt_const ? pb.pt_const[p] != 0 : false;
+    if (n_o0 + lane < n_o1) { n_c = pb.obs_cam[n_o0 + lane]; n_uv = pb.obs_uv[n_o0 + lane]; }
+  }
+  for (; p < d.P; p += nw) {
+    const int o0 = n_o0, o1 = n_o1;
+    const double X[3] = {n_X0, n_X1, n_X2};
+    const bool pt_c = n_ptc;
+    const int f_c = n_c;
+    const float2 f_uv = n_uv;
+    {
+      const int pn = p + nw;
+      if (pn < d.P) {
+        n_o0 = pb.row_ptr[pn]; n_o1 = pb.row_ptr[pn + 1];
+        n_X0 = pb.pts[3 * pn]; n_X1 = pb.pts[3 * pn + 1]; n_X2 = pb.pts[3 * pn + 2];
+        n_ptc = pb.pt_const ? pb.pt_const[pn] != 0 : false;
+        if (n_o0 + lane < n_o1) { n_c = pb.obs_cam[n_o0 + lane]; n_uv = pb.obs_uv[n_o0 + lane]; }
+      }
+    }
     double t3[3] = {0, 0, 0};
     // cached values of this lane's first observation (tracks longer than 64 recompute)
     double c_r[2] = {0, 0}, c_fy[2] = {0, 0}, c_E[6] = {0, 0, 0, 0, 0, 0};
     for (int o = o0 + lane; o < o1; o += 64) {
-      const int c = pb.obs_cam[o];
+      const bool head = (o - o0 < 64);
+      const int c = head ? f_c : pb.obs_cam[o];
+      const float2 uv = head ? f_uv : pb.obs_uv[o];
       const int a = d.shared ? 0 : c;
       double r[2], F[2 * BD], E[6];
-      eval_full<KD>(d, pb.cam_q + 4 * c, pb.cam_t + 3 * c, pb.intr + 4 * a, X, pb.obs_uv[o],
-                    pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
+      if (LDSCAM)
+        eval_full<KD>(d, lq + 4 * c, lt + 3 * c, pb.intr + 4 * a, X, uv, (unsigned)lfl[c],
+                      pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
+      else
+        eval_full<KD>(d, pb.cam_q + 4 * c, pb.cam_t + 3 * c, pb.intr + 4 * a, X, uv,
+                      pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
       double fy0 = 0, fy1 = 0;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) { const double v = w.dy[6 * c + k]; fy0 += F[k] * v; fy1 += F[BD + k] * v; }
+      for (int k = 0; k < 6; ++k) { const double v = LDSCAM ? ldy[6 * c + k] : w.dy[6 * c + k]; fy0 += F[k] * v; fy1 += F[BD + k] * v; }
 #pragma unroll
       for (int k = 0; k < KD; ++k) { const double v = w.dy[6 * d.C + KD * a + k]; fy0 += F[6 + k] * v; fy1 += F[BD + 6 + k] * v; }
       t3[0] += E[0] * fy0 + E[3] * fy1; t3[1] += E[1] * fy0 + E[4] * fy1; t3[2] += E[2] * fy0 + E[5] * fy1;
-      if (o - o0 < 64) {
+      if (head) {
         c_r[0] = r[0]; c_r[1] = r[1]; c_fy[0] = fy0; c_fy[1] = fy1;
 #pragma unroll
         for (int k = 0; k < 6; ++k) c_E[k] = E[k];
@@ -1024,10 +1067,11 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
       if (!pt_c) s_xn += X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
     }
     for (int o = o0 + lane; o < o1; o += 64) {
-      const int c = pb.obs_cam[o];
+      const bool head = (o - o0 < 64);
+      const int c = head ? f_c : pb.obs_cam[o];
       const int a = d.shared ? 0 : c;
       double r[2], fy[2], E[6];
-      if (o - o0 < 64) {
+      if (head) {
         r[0] = c_r[0]; r[1] = c_r[1]; fy[0] = c_fy[0]; fy[1] = c_fy[1];
 #pragma unroll
         for (int k = 0; k < 6; ++k) E[k] = c_E[k];
@@ -1046,8 +1090,9 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
       const double m1 = -(fy[1] + E[3] * ys[0] + E[4] * ys[1] + E[5] * ys[2]);
       s_mcc += -(m0 * (r[0] + m0 / 2.0) + m1 * (r[1] + m1 / 2.0));
       double rc[2];
-      const float2 uv = pb.obs_uv[o];
-      obs_residual(d.model, w.cand_q + 4 * c, w.cand_t + 3 * c, w.cand_intr + 4 * a, Xn, (double)uv.x, (double)uv.y, rc);
+      const float2 uv = head ? f_uv : pb.obs_uv[o];
+      if (LDSCAM) obs_residual(d.model, lcq + 4 * c, lct + 3 * c, w.cand_intr + 4 * a, Xn, (double)uv.x, (double)uv.y, rc);
+      else obs_residual(d.model, w.cand_q + 4 * c, w.cand_t + 3 * c, w.cand_intr + 4 * a, Xn, (double)uv.x, (double)uv.y, rc);
       s_cost += loss_rho0(d, rc[0] * rc[0] + rc[1] * rc[1]);
     }
   }
@@ -1230,7 +1275,9 @@ static int phase_step(const Launch& L) {
   cam_update_kernel<KD><<<div_up(d.C + 1, 64), 64, 0, L.st>>>(L.dp, L.w);
   {
     ProfScope ps(kProfPointStep, L.st);
-    point_step_kernel<KD><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w);
+    const size_t cam_lds = sizeof(double) * 21 * (size_t)d.C;
+    if (cam_lds <= 64 * 1024) point_step_kernel<KD, true><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w);
+    else point_step_kernel<KD, false><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w);
   }
   reduce_step_kernel<<<1, 256, 0, L.st>>>(L.w, L.wgB);
   return VGG_OK;

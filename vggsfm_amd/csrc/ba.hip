@@ -48,6 +48,8 @@ constexpr int kGroup = 16;       // cameras per Schur tile side
 #endif
 constexpr int kSub = 32;         // entries per strided sub-chunk of a Schur workgroup (see schur_tile_kernel)
 constexpr int kMaxWG = 2048;
+constexpr int kCamSplitMax = 16;  // workgroups per camera in the camera passes
+constexpr int kCamNV = 48;        // >= values a camera pass accumulates (BD(BD+1)/2 + BD + 1 <= 45)
 
 struct Ctl {
   double radius, decrease_factor, x_cost, initial_cost, gmax_cams, gmax, cand_cost, mcc, step_norm, rel;
@@ -77,6 +79,7 @@ struct Ws {  // device workspace carve-up (pointers into the caller's buffer)
   double* part_B;             // [kMaxWG] per-workgroup gradient max
   double* part_F;             // [kMaxWG][4]
   double* cam_part;           // [C+1][2] step^2 / x^2 of camera-side parameters
+  double* cam_split;          // [C][kCamSplitMax][kCamNV] partial sums of the split camera passes
   double* Y;                  // [num_segments][16][BDt*3] zero-padded per-observation Schur factors s_c o (F^T E G_p)
   size_t y_bytes;
   double* chol_inv;           // inverse diagonal blocks of the Cholesky factor
@@ -126,6 +129,7 @@ static Ws carve(const Dims& d, int max_iters, int num_chunks, int num_segments, 
   w.part_B = (double*)take(8ull * kMaxWG);
   w.part_F = (double*)take(8ull * kMaxWG * 4);
   w.cam_part = (double*)take(8ull * (d.C + 1) * 2);
+  w.cam_split = (double*)take(8ull * (size_t)d.C * kCamSplitMax * kCamNV);
   w.y_bytes = 8ull * (size_t)(num_segments > 0 ? num_segments : 1) * kGroup * (d.shared ? 6 : d.BDp) * 3;
   w.Y = (double*)take(w.y_bytes);
   w.chol_inv = (double*)take(cholesky_workspace_bytes(d.n_red));
@@ -260,7 +264,10 @@ __global__ __launch_bounds__(256, VGG_CP_OCC) void cam_pass_kernel(DevProblem pb
   if (w.ctl->done) return;
   if (MODE == 0 && !w.ctl->need_lin) return;
   const Dims& d = pb.d;
-  const int c = blockIdx.x;
+  // grid (C, split): a camera's observations are cut into `split` contiguous slices, one workgroup each (one
+  // workgroup per camera left 200 workgroups = 0.8 wavefronts per SIMD on the chip); cam_reduce_kernel adds the
+  // slices in a fixed order
+  const int c = blockIdx.x, split = gridDim.y;
   double q[4], t[3], in4[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) q[k] = pb.cam_q[4 * c + k];
@@ -275,7 +282,10 @@ __global__ __launch_bounds__(256, VGG_CP_OCC) void cam_pass_kernel(DevProblem pb
   double acc[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) acc[i] = 0.0;
-  for (int j = pb.col_ptr[c] + threadIdx.x; j < pb.col_ptr[c + 1]; j += 256) {
+  const int j_begin = pb.col_ptr[c], j_count = pb.col_ptr[c + 1] - j_begin;
+  const int per = (j_count + split - 1) / split;
+  const int j0 = j_begin + (int)blockIdx.y * per, j1 = min(j0 + per, j_begin + j_count);
+  for (int j = j0 + threadIdx.x; j < j1; j += 256) {
     const int p = pb.cobs_pt[j];
     const float2 uv = pb.cobs_uv[j];
     double X[3] = {pb.pts[3 * p], pb.pts[3 * p + 1], pb.pts[3 * p + 2]};
@@ -311,23 +321,40 @@ __global__ __launch_bounds__(256, VGG_CP_OCC) void cam_pass_kernel(DevProblem pb
     }
   }
   block_sum<NV>(acc, red, tot);
+  static_assert(NV <= kCamNV, "cam_split row");
+  if (threadIdx.x < NV) w.cam_split[((size_t)c * kCamSplitMax + blockIdx.y) * kCamNV + threadIdx.x] = tot[threadIdx.x];
+}
+
+// sums the `split` slices of a camera in order and stores U, g, cost (MODE 0) or T (MODE 1)
+template <int KD, int MODE>
+__global__ __launch_bounds__(64) void cam_reduce_kernel(DevProblem pb, Ws w, int split) {
+  constexpr int BD = 6 + KD;
+  constexpr int NU = BD * (BD + 1) / 2;
+  constexpr int NV = (MODE == 0) ? (NU + BD + 1) : (BD * (1 + KD));
+  if (w.ctl->done) return;
+  if (MODE == 0 && !w.ctl->need_lin) return;
+  const Dims& d = pb.d;
+  const int c = blockIdx.x, kdsh = d.kdsh;
+  if (threadIdx.x >= NV) return;
+  double tot = 0.0;
+  for (int sp = 0; sp < split; ++sp) tot += w.cam_split[((size_t)c * kCamSplitMax + sp) * kCamNV + threadIdx.x];
   if (MODE == 0) {
     double* U = w.U + (size_t)c * BD * BD;
     if (threadIdx.x < NU) {
       int i = 0, rem = threadIdx.x;
       while (rem >= BD - i) { rem -= BD - i; ++i; }
       const int k = i + rem;
-      U[i * BD + k] = tot[threadIdx.x];
-      U[k * BD + i] = tot[threadIdx.x];
+      U[i * BD + k] = tot;
+      U[k * BD + i] = tot;
+    } else if (threadIdx.x < NU + BD) {
+      w.g[(size_t)c * BD + threadIdx.x - NU] = tot;
+    } else {
+      w.costc[c] = tot;
     }
-    if (threadIdx.x < BD) w.g[(size_t)c * BD + threadIdx.x] = tot[NU + threadIdx.x];
-    if (threadIdx.x == 0) w.costc[c] = tot[NU + BD];
   } else {
     // stored with row stride (1 + kdsh)
-    if (threadIdx.x < BD * (1 + KD)) {
-      const int i = threadIdx.x / (1 + KD), m = threadIdx.x - i * (1 + KD);
-      if (m < 1 + kdsh) w.T[((size_t)c * BD + i) * (1 + kdsh) + m] = tot[threadIdx.x];
-    }
+    const int i = threadIdx.x / (1 + KD), m = threadIdx.x - i * (1 + KD);
+    if (m < 1 + kdsh) w.T[((size_t)c * BD + i) * (1 + kdsh) + m] = tot;
   }
 }
 
@@ -1212,10 +1239,18 @@ struct Launch {
   double *cam_q, *cam_t, *intr, *pts;
 };
 
+// workgroups per camera of the camera passes: ~2048 workgroups in total
+static inline int cam_split_for(int C) {
+  const int s = 2048 / (C > 0 ? C : 1);
+  return s < 1 ? 1 : (s > kCamSplitMax ? kCamSplitMax : s);
+}
+
 template <int KD>
 static void phase_linearize(const Launch& L) {
   ProfScope ps(kProfLinearize, L.st);
-  cam_pass_kernel<KD, 0><<<L.d.C, 256, 0, L.st>>>(L.dp, L.w);
+  const int split = cam_split_for(L.d.C);
+  cam_pass_kernel<KD, 0><<<dim3(L.d.C, split), 256, 0, L.st>>>(L.dp, L.w);
+  cam_reduce_kernel<KD, 0><<<L.d.C, 64, 0, L.st>>>(L.dp, L.w, split);
 }
 
 template <int BD>
@@ -1246,7 +1281,9 @@ static void phase_schur(const Launch& L) {
   reduce_gmax_kernel<<<1, 256, 0, L.st>>>(L.w, L.wgB);
   {
     ProfScope ps(kProfCamRhs, L.st);
-    cam_pass_kernel<KD, 1><<<d.C, 256, 0, L.st>>>(L.dp, L.w);
+    const int split = cam_split_for(d.C);
+    cam_pass_kernel<KD, 1><<<dim3(d.C, split), 256, 0, L.st>>>(L.dp, L.w);
+    cam_reduce_kernel<KD, 1><<<d.C, 64, 0, L.st>>>(L.dp, L.w, split);
   }
   (void)hipMemsetAsync(L.w.sys, 0, sizeof(double) * L.w.sys_count, L.st);
   if (L.num_chunks > 0) {

@@ -1,0 +1,131 @@
+"""vggsfm_amd.track_table.TrackTable against a literal restatement of the reference's dict bookkeeping
+(vggsfm/runners/video_runner.py:354-473 ``convert_pred_to_point_frame_dict`` / ``_update_points_to_dict``,
+543-605 ``dicts_to_reconstruction``, 607-638 ``reconstruction_to_dicts``)."""
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+from vggsfm_amd.track_table import TrackTable
+
+
+class DictOracle:
+    """point_dict / frame_dict exactly as the reference builds them (loops and all)."""
+
+    def __init__(self):
+        self.point_dict = {}
+        self.frame_dict = defaultdict(dict)
+
+    def convert_pred(self, pred, start_idx, end_idx):           # video_runner.py:354-405
+        mapping = pred["valid_tracks"].nonzero().squeeze(1).numpy()
+        points3D = pred["points3D"]
+        idx = np.arange(len(points3D)) if "points3D_idx" not in pred else pred["points3D_idx"]
+        for f in range(start_idx, end_idx):
+            self.frame_dict[f]["extri"] = pred["extrinsics_opencv"][f - start_idx]
+            self.frame_dict[f].setdefault("visible_points", [])
+        exist_max = 0 if not self.point_dict else max(self.point_dict) + 1
+        self.update(start_idx, end_idx, pred["valid_2D_mask"], pred["pred_track"], pred["pred_vis"], idx, mapping,
+                    points3D, pred.get("points3D_rgb"), exist_max)
+
+    def update(self, start_idx, end_idx, valid_2D_mask, pred_track, pred_vis, points3D_idx, mapping=None, points3D=None,
+               rgb=None, existing_max_point_idx=0):               # video_runner.py:407-473
+        if mapping is None:
+            mapping = np.arange(len(points3D_idx))
+        for point_idx in points3D_idx:
+            abs_idx = int(point_idx) + existing_max_point_idx
+            t = mapping[point_idx]
+            m = valid_2D_mask[:, t]
+            track = self.point_dict[abs_idx]["track"] if abs_idx in self.point_dict else {}
+            for f in range(start_idx, end_idx):
+                if m[f - start_idx]:
+                    track[f] = {"uv": pred_track[f - start_idx, t], "vis": pred_vis[f - start_idx, t]}
+                    self.frame_dict[f].setdefault("visible_points", []).append(abs_idx)
+            if abs_idx not in self.point_dict:
+                self.point_dict[abs_idx] = {"id": abs_idx, "xyz": points3D[point_idx],
+                                            "rgb": None if rgb is None else rgb[point_idx], "track": track}
+
+
+def _pred(gen, S, N, n_valid):
+    valid_tracks = torch.zeros(N, dtype=torch.bool)
+    valid_tracks[torch.randperm(N, generator=gen)[:n_valid]] = True
+    return {"pred_track": torch.rand(S, N, 2, generator=gen) * 1000, "pred_vis": torch.rand(S, N, generator=gen),
+            "valid_2D_mask": torch.rand(S, N, generator=gen) > 0.3, "valid_tracks": valid_tracks,
+            "points3D": torch.randn(n_valid, 3, generator=gen), "points3D_rgb": torch.rand(n_valid, 3, generator=gen),
+            "extrinsics_opencv": torch.randn(S, 3, 4, generator=gen)}
+
+
+def _compare(tt, oracle):
+    assert tt.num_points == (max(oracle.point_dict) + 1 if oracle.point_dict else 0)
+    n_obs = 0
+    for pid, pd in oracle.point_dict.items():
+        assert torch.allclose(tt.xyz[pid], pd["xyz"].float())
+        if pd["rgb"] is not None:
+            assert torch.allclose(tt.rgb[pid], pd["rgb"].float())
+        fr, uv, vis = tt.track_of(pid)
+        assert fr.tolist() == sorted(pd["track"])
+        for k, f in enumerate(fr.tolist()):
+            assert torch.equal(uv[k], pd["track"][f]["uv"].float()) and float(vis[k]) == float(pd["track"][f]["vis"])
+        n_obs += len(pd["track"])
+    assert tt.num_observations == n_obs
+    for f, fd in oracle.frame_dict.items():
+        assert sorted(set(fd.get("visible_points", []))) == tt.visible_points(f).tolist()
+        if "extri" in fd:
+            assert bool(tt.has_extri[f]) and torch.equal(tt.extri[f], fd["extri"].float())
+
+
+def test_track_table_matches_dict_bookkeeping():
+    gen = torch.Generator().manual_seed(0)
+    tt, oracle = TrackTable(device="cpu"), DictOracle()
+    # first window (frames 0..8): new points
+    p0 = _pred(gen, 9, 60, 40)
+    tt.add_window_prediction(p0, 0, 9)
+    oracle.convert_pred(p0, 0, 9)
+    _compare(tt, oracle)
+    # second window (frames 9..16): new points appended after the existing ones ...
+    p1 = _pred(gen, 8, 50, 30)
+    tt.add_window_prediction(p1, 9, 17)
+    oracle.convert_pred(p1, 9, 17)
+    _compare(tt, oracle)
+    # ... and existing points receive tracks in the new frames (video_runner.py:894-903), via an id -> column mapping
+    exist_ids = np.array(sorted(np.random.default_rng(1).choice(40, 25, replace=False)))
+    mapping = {int(pid): k for k, pid in enumerate(exist_ids)}
+    v2d = torch.rand(8, 25, generator=gen) > 0.4
+    trk, vis = torch.rand(8, 25, 2, generator=gen) * 1000, torch.rand(8, 25, generator=gen)
+    dense_map = torch.zeros(40, dtype=torch.long)
+    dense_map[torch.as_tensor(exist_ids)] = torch.arange(25)
+    tt.update_points(9, 17, v2d, trk, vis, torch.as_tensor(exist_ids), dense_map)
+    oracle.update(9, 17, v2d, trk, vis, exist_ids, mapping)
+    _compare(tt, oracle)
+    # overwriting an existing (point, frame) observation keeps the last write (dict assignment)
+    tt.update_points(9, 17, v2d, trk + 1.0, vis, torch.as_tensor(exist_ids), dense_map)
+    oracle.update(9, 17, v2d, trk + 1.0, vis, exist_ids, mapping)
+    for fd in oracle.frame_dict.values():                       # the reference would now list those ids twice
+        fd["visible_points"] = sorted(set(fd["visible_points"]))
+    _compare(tt, oracle)
+
+
+def test_window_tensors_and_reset():
+    gen = torch.Generator().manual_seed(1)
+    tt, oracle = TrackTable(device="cpu"), DictOracle()
+    p0 = _pred(gen, 6, 30, 30)
+    tt.add_window_prediction(p0, 2, 8)
+    oracle.convert_pred(p0, 2, 8)
+    pts, ext, tracks, masks, ids = tt.window_tensors(2, 8)
+    assert pts.shape == (30, 3) and ext.shape == (6, 3, 4) and tracks.shape == (6, 30, 2)
+    # dicts_to_reconstruction semantics: image f holds one Point2D per visible point, with the track's uv
+    for f in range(2, 8):
+        vis_pts = sorted(set(oracle.frame_dict[f]["visible_points"]))
+        assert torch.nonzero(masks[f - 2]).squeeze(1).tolist() == vis_pts
+        for pid in vis_pts:
+            assert torch.equal(tracks[f - 2, pid], oracle.point_dict[pid]["track"][f]["uv"].float())
+    # joint BA result with filtered points -> renumbered table (reconstruction_to_dicts)
+    keep = torch.rand(30, generator=gen) > 0.3
+    new_pts = pts + 0.1
+    tt2 = TrackTable(device="cpu")
+    tt2.reset_from_tensors(new_pts, ext, tracks, masks, keep, start_idx=2)
+    assert tt2.num_points == int(keep.sum())
+    old_of_new = torch.nonzero(keep).squeeze(1)
+    for new_id, old_id in enumerate(old_of_new.tolist()):
+        assert torch.allclose(tt2.xyz[new_id], new_pts[old_id])
+        fr, uv, vis = tt2.track_of(new_id)
+        assert fr.tolist() == sorted(oracle.point_dict[old_id]["track"]) and bool((vis == 1).all())

@@ -182,6 +182,9 @@ int vgg_ba_solve(const vgg_ba_problem* problem, const vgg_ba_options* options, v
  *                      gradient max of local points                            -> reduce buffer 2 (MAX)
  *   phase 2 STEP     : Cholesky + back-substitution + candidate cost         -> reduce buffer 3 (SUM)
  *   phase 3 UPDATE   : trust-region decision, commit
+ *   phase 4 / 5      : pack / unpack the lower triangle of the reduced system + rhs into / from reduce buffer 4
+ *                      (n(n+1)/2 + n doubles): all-reducing buffer 4 between them replaces the all-reduce of
+ *                      buffer 1 (n^2 + n doubles, upper triangle all zero) at half the payload
  * vgg_ba_reduce_buffer returns the device address / element count (doubles) of each reduce buffer. */
 int vgg_ba_begin(const vgg_ba_problem* problem, const vgg_ba_options* options, void* workspace, size_t workspace_bytes,
                  int rank, int world_size, void* stream);

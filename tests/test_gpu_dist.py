@@ -57,7 +57,12 @@ def test_sharded_equals_single_rank(cam, shared, world):
         hub.exchange([s.bufs[0] for s in solvers], "sum")
         for s in solvers:
             s._phase(1)
-        hub.exchange([s.bufs[1] for s in solvers], "sum")
+            s._phase(4)                                     # pack lower triangle + rhs (the real collective's payload)
+        n = ref["n_reduced"]
+        assert solvers[0].bufs[4].numel() == n * (n + 1) // 2 + n
+        hub.exchange([s.bufs[4] for s in solvers], "sum")
+        for s in solvers:
+            s._phase(5)
         hub.exchange([s.bufs[2] for s in solvers], "max")
         for s in solvers:
             s._phase(2)

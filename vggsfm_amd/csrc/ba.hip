@@ -78,6 +78,8 @@ struct Ws {  // device workspace carve-up (pointers into the caller's buffer)
   double* T;                  // [C][BDp][1+kdsh]
   double* part_B;             // [kMaxWG] per-workgroup gradient max
   double* part_F;             // [kMaxWG][4]
+  double* packed;             // lower triangle of S (row by row) + rhs: the multi-GPU reduce payload
+  size_t packed_count;
   double* cam_part;           // [C+1][2] step^2 / x^2 of camera-side parameters
   double* cam_split;          // [C][kCamSplitMax][kCamNV] partial sums of the split camera passes
   double* Y;                  // [num_segments][16][BDt*3] zero-padded per-observation Schur factors s_c o (F^T E G_p)
@@ -121,6 +123,8 @@ static Ws carve(const Dims& d, int max_iters, int num_chunks, int num_segments, 
   w.sys_count = (size_t)d.n_red * d.n_red + d.n_red;
   w.sys = (double*)take(8ull * w.sys_count);
   w.S = w.sys; w.rhs = w.S + (size_t)d.n_red * d.n_red;
+  w.packed_count = (size_t)d.n_red * (d.n_red + 1) / 2 + d.n_red;
+  w.packed = (double*)take(8ull * w.packed_count);
   w.gmax_pts = (double*)take(64);
   w.stepsum = (double*)take(64);
   w.G = (double*)take(8ull * 6 * d.P); w.hs = (double*)take(8ull * 3 * d.P);
@@ -1239,6 +1243,20 @@ struct Launch {
   double *cam_q, *cam_t, *intr, *pts;
 };
 
+// Multi-GPU payload of the reduced system: only the lower triangle is ever filled, so the all-reduce carries
+// n(n+1)/2 + n doubles instead of n^2 + n (phases 4 / 5, called by the distributed host loop only).
+__global__ __launch_bounds__(256) void pack_lower_kernel(Ws w, int n, int unpack) {
+  if (w.ctl->done) return;
+  const int i = blockIdx.x;                                   // row i, or row n = the right-hand side
+  const size_t base = (i < n) ? (size_t)i * (i + 1) / 2 : (size_t)n * (n + 1) / 2;
+  const int len = (i < n) ? i + 1 : n;
+  double* full = (i < n) ? w.S + (size_t)i * n : w.rhs;
+  for (int j = threadIdx.x; j < len; j += 256) {
+    if (unpack) full[j] = w.packed[base + j];
+    else w.packed[base + j] = full[j];
+  }
+}
+
 // workgroups per camera of the camera passes: ~2048 workgroups in total
 static inline int cam_split_for(int C) {
   const int s = 2048 / (C > 0 ? C : 1);
@@ -1365,6 +1383,8 @@ static int run_phase(const Launch& L, int phase) {
     case 2:
       return dispatch_kd(L.d.kd, [&] { return phase_step<0>(L); }, [&] { return phase_step<1>(L); }, [&] { return phase_step<2>(L); });
     case 3: phase_update(L); return VGG_OK;
+    case 4: pack_lower_kernel<<<L.d.n_red + 1, 256, 0, L.st>>>(L.w, L.d.n_red, 0); return VGG_OK;
+    case 5: pack_lower_kernel<<<L.d.n_red + 1, 256, 0, L.st>>>(L.w, L.d.n_red, 1); return VGG_OK;
     default: return VGG_ERR_INVALID_ARGUMENT;
   }
 }
@@ -1470,6 +1490,7 @@ int vgg_ba_reduce_buffer(const vgg_ba_problem* problem, const vgg_ba_options* op
     case 1: *device_ptr = w.sys; *count = w.sys_count; break;
     case 2: *device_ptr = w.gmax_pts; *count = 1; break;
     case 3: *device_ptr = w.stepsum; *count = 4; break;
+    case 4: *device_ptr = w.packed; *count = w.packed_count; break;
     default: return VGG_ERR_INVALID_ARGUMENT;
   }
   return VGG_OK;

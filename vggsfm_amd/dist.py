@@ -7,7 +7,8 @@ independent.  Every residual touches exactly one point, so V_p, g_p, the Schur c
 back-substitution of a point are rank-local; what couples the ranks is only the camera side:
 
   phase 0 LINEARIZE  local U_c = sum F^T F, g_c = sum F^T r, cost        -> all-reduce SUM  (C*(BD^2+BD+1) doubles)
-  phase 1 SCHUR      local reduced system S, rhs of the rank's points     -> all-reduce SUM  (n^2 + n doubles)
+  phase 1 SCHUR      local reduced system S, rhs of the rank's points     -> all-reduce SUM  (packed lower triangle
+                                                                              + rhs: n(n+1)/2 + n doubles)
                      local max |g_p|                                       -> all-reduce MAX  (1 double)
   phase 2 STEP       every rank factors S redundantly, back-substitutes its points,
                      local candidate cost / model change / step norm       -> all-reduce SUM  (4 doubles)
@@ -66,7 +67,7 @@ class ShardedBA:
         self.nbytes = nbytes
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=problem.pts.device)
         self.bufs = []
-        for which in range(4):
+        for which in range(5):
             p = ctypes.POINTER(ctypes.c_double)()
             cnt = ctypes.c_size_t()
             _lib.check(self.L.vgg_ba_reduce_buffer(ctypes.byref(self.cp), ctypes.byref(self.co), _lib.ptr(self.ws), which,
@@ -95,7 +96,9 @@ class ShardedBA:
             ar(self.bufs[0], "sum")
         self._phase(1)
         if ar:
-            ar(self.bufs[1], "sum")
+            self._phase(4)                      # lower triangle + rhs -> packed buffer (half the payload)
+            ar(self.bufs[4], "sum")
+            self._phase(5)
             ar(self.bufs[2], "max")
         self._phase(2)
         if ar:

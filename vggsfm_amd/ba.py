@@ -170,7 +170,8 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     if max_chunks is not None:
         # one resident round per launch: the smallest chunk size (multiple of SUB, >= MIN_CHUNK) whose workgroup
         # count fits the device (CUs x workgroups per CU), so no workgroup starts late and runs alone on its CU
-        for sel in (~is_diag, is_diag):
+        caps = max_chunks if isinstance(max_chunks, (tuple, list)) else (max_chunks, max_chunks)
+        for sel, max_chunks in ((~is_diag, caps[0]), (is_diag, caps[1])):
             if not bool(sel.any()):
                 continue
             kc = kcounts[sel]
@@ -250,7 +251,9 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
         if S > 1:
             cam_const[1] = 2                        # SetConstantCamPositions(second image, {0})
     cus = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == "cuda" else 256
-    slots = cus * (4 if shared_camera else 2)       # resident schur_tile workgroups (occupancy of the BD variant)
+    # resident schur_tile workgroups per CU (occupancy of the kernel variant): off-diagonal launch 3 (BD = 6) or 2,
+    # diagonal launch 4 or 2 -- one full round each
+    slots = (cus * 3, cus * 4) if shared_camera else (cus * 2, cus * 2)
     chunk_desc, entries, tile_desc, obs_slot, nseg = build_schur_tiles(row_ptr, obs_cam, max_chunks=slots)
     prob = DeviceProblem(cam_q, cam_t, intr, pts, row_ptr, obs_cam, obs_uv, col_ptr, cobs_pt, cobs_uv, chunk_desc,
                          entries, tile_desc, obs_slot, nseg, MODEL_ID[camera_type], cam_const=cam_const)

@@ -34,6 +34,9 @@ int cholesky_solve_enqueue(double* A, double* b, int n, double* inv_blocks, int3
 size_t cholesky_workspace_bytes(int n);
 
 constexpr int kGroup = 16;       // cameras per Schur tile side
+#ifndef VGG_OFFDIAG_OCC
+#define VGG_OFFDIAG_OCC 3   // wavefronts per SIMD of the off-diagonal Schur kernel (BD = 6): see DESIGN.md section 6
+#endif
 #ifndef VGG_PP_OCC
 #define VGG_PP_OCC 2
 #endif
@@ -680,7 +683,7 @@ __global__ void begin_iteration_kernel(Ws w, vgg_ba_options opt) {
 typedef double f64x4_t __attribute__((ext_vector_type(4)));
 
 template <int BD, bool DIAG>
-__global__ __launch_bounds__(256, (BD == 6 ? 4 : 2)) void schur_tile_kernel(Ws w, const int32_t* __restrict__ chunk_desc,
+__global__ __launch_bounds__(256, (BD == 6 ? (DIAG ? 4 : VGG_OFFDIAG_OCC) : 2)) void schur_tile_kernel(Ws w, const int32_t* __restrict__ chunk_desc,
                                                          const int32_t* __restrict__ entries, int chunk0) {
   constexpr int YS = BD * 3;                      // doubles per Y block
   constexpr int SEG = kGroup * YS;                // doubles per segment (16 slots)

@@ -137,7 +137,8 @@ static Ws carve(const Dims& d, int max_iters, int num_chunks, int num_segments, 
   w.part_F = (double*)take(8ull * kMaxWG * 4);
   w.cam_part = (double*)take(8ull * (d.C + 1) * 2);
   w.cam_split = (double*)take(8ull * (size_t)d.C * kCamSplitMax * kCamNV);
-  w.y_bytes = 8ull * (size_t)(num_segments > 0 ? num_segments : 1) * kGroup * (d.shared ? 6 : d.BDp) * 3;
+  // + one all-zero segment behind the last real one (target of the tile kernel's loads past the end of a list)
+  w.y_bytes = 8ull * ((size_t)(num_segments > 0 ? num_segments : 0) + 1) * kGroup * (d.shared ? 6 : d.BDp) * 3;
   w.Y = (double*)take(w.y_bytes);
   w.chol_inv = (double*)take(cholesky_workspace_bytes(d.n_red));
   {
@@ -684,7 +685,7 @@ typedef double f64x4_t __attribute__((ext_vector_type(4)));
 
 template <int BD, bool DIAG>
 __global__ __launch_bounds__(256, (BD == 6 ? (DIAG ? 4 : VGG_OFFDIAG_OCC) : 2)) void schur_tile_kernel(Ws w, const int32_t* __restrict__ chunk_desc,
-                                                         const int32_t* __restrict__ entries, int chunk0) {
+                                                         const int32_t* __restrict__ entries, int chunk0, int zero_seg) {
   constexpr int YS = BD * 3;                      // doubles per Y block
   constexpr int SEG = kGroup * YS;                // doubles per segment (16 slots)
   constexpr int R = kGroup * BD;                  // rows / cols of the tile
@@ -728,21 +729,19 @@ __global__ __launch_bounds__(256, (BD == 6 ? (DIAG ? 4 : VGG_OFFDIAG_OCC) : 2)) 
   constexpr int NV = (V + TPS - 1) / TPS;         // double2 per thread per batch
   const int sseg = tid / TPS, l32 = tid % TPS;
   const int se = DIAG ? sseg : (sseg >> 1), sside = DIAG ? 0 : (sseg & 1);
-  auto load_seg_index = [&](int eb) -> int {      // -1: no such entry (tail of the chunk)
-    if (eb + se >= e1) return -1;
-    const int4 en = ent[eb + se];
-    return sside ? en.z : en.y;
-  };
+  // The segment index of a batch is loaded unconditionally (clamped entry) and only CONSUMED one iteration later;
+  // entries past the end of the list are redirected to the all-zero segment behind the last real one.  Nothing in
+  // the current iteration depends on the loaded value, so no s_waitcnt sits between the prefetch and the MFMAs.
+  const int32_t* seg_field = entries + 1 + sside;               // entries[e] = (point, segA, segB, masks)
+  auto load_seg_index = [&](int eb) -> int { return seg_field[4 * (size_t)min(eb + se, e1 - 1)]; };
+  auto seg_valid = [&](int eb) -> bool { return eb + se < e1; };
   double2 sv[NV];
-  auto issue_loads = [&](int seg_index) {
-    const double2* src = reinterpret_cast<const double2*>(w.Y) + (size_t)(seg_index < 0 ? 0 : seg_index) * V;
+  auto issue_loads = [&](int seg_index, bool valid) __attribute__((always_inline)) {
+    const double2* src = reinterpret_cast<const double2*>(w.Y) + (size_t)(valid ? seg_index : zero_seg) * V;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int off = l32 + TPS * i;
-      sv[i] = (seg_index >= 0 && off < V) ? src[off] : make_double2(0.0, 0.0);
-    }
+    for (int i = 0; i < NV; ++i) { const int off = l32 + TPS * i; sv[i] = (off < V) ? src[off] : make_double2(0.0, 0.0); }
   };
-  auto write_lds = [&](int buf) {
+  auto write_lds = [&](int buf) __attribute__((always_inline)) {
     double2* dst = reinterpret_cast<double2*>(&Ops[buf][sside][se][0]);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -755,22 +754,24 @@ __global__ __launch_bounds__(256, (BD == 6 ? (DIAG ? 4 : VGG_OFFDIAG_OCC) : 2)) 
   // (ks enters the address as a compile-time immediate: ks R doubles)
   const int kbase = lk * SEG, swz = (lk & 1) * SWZ;
 
-  issue_loads(load_seg_index(ebase(0)));
+  issue_loads(load_seg_index(ebase(0)), seg_valid(ebase(0)));
   int seg_next = load_seg_index(ebase(1));
+  bool valid_next = seg_valid(ebase(1));
   write_lds(0);
   __syncthreads();
 #if VGG_ABLATE == 2
-  issue_loads(-1);
+  issue_loads(0, false);
   write_lds(0);
   __syncthreads();
 #endif
   // software pipeline shared by the two sub-tile assignments below
-  auto sweep = [&](auto&& mfma_batch) {
+  auto sweep = [&](auto&& mfma_batch) __attribute__((always_inline)) {
     int buf = 0;
     for (int b = 0; b < nb; ++b, buf ^= 1) {
 #if VGG_ABLATE != 2                               // (profiling builds only: 1 = no MFMA, 2 = no global loads)
-      issue_loads(seg_next);                      // batch b+1 (zeros past the end of the tile's list)
+      issue_loads(seg_next, valid_next);          // batch b+1 (the zero segment past the end of the tile's list)
       seg_next = load_seg_index(ebase(b + 2));
+      valid_next = seg_valid(ebase(b + 2));
 #endif
 #if VGG_ABLATE != 1
       mfma_batch(buf);
@@ -1241,7 +1242,7 @@ struct ProfScope {
 
 struct Launch {
   Dims d; DevProblem dp; Ws w; vgg_ba_options opt; hipStream_t st; int wgB;
-  const int32_t* chunk_desc; const int32_t* entries; int num_chunks, num_offdiag_chunks;
+  const int32_t* chunk_desc; const int32_t* entries; int num_chunks, num_offdiag_chunks, num_segments;
   const int32_t* tile_desc; int num_tiles;
   double *cam_q, *cam_t, *intr, *pts;
 };
@@ -1279,11 +1280,11 @@ static void launch_schur_tiles(const Launch& L) {
   const int noff = L.num_offdiag_chunks, ndiag = L.num_chunks - noff;
   if (noff > 0) {
     ProfScope ps(kProfSchurTile, L.st);
-    schur_tile_kernel<BD, false><<<noff, 256, 0, L.st>>>(L.w, L.chunk_desc, L.entries, 0);
+    schur_tile_kernel<BD, false><<<noff, 256, 0, L.st>>>(L.w, L.chunk_desc, L.entries, 0, L.num_segments);
   }
   if (ndiag > 0) {
     ProfScope ps(kProfSchurTileDiag, L.st);
-    schur_tile_kernel<BD, true><<<ndiag, 256, 0, L.st>>>(L.w, L.chunk_desc, L.entries, noff);
+    schur_tile_kernel<BD, true><<<ndiag, 256, 0, L.st>>>(L.w, L.chunk_desc, L.entries, noff, L.num_segments);
   }
 }
 
@@ -1364,6 +1365,7 @@ static int make_launch(const vgg_ba_problem* pb, const vgg_ba_options* opt, void
   L->wgB = min(max(div_up(L->d.P, 4), 1), kMaxWG);
   L->chunk_desc = pb->chunk_desc; L->entries = pb->entries; L->num_chunks = pb->num_chunks;
   L->num_offdiag_chunks = pb->num_offdiag_chunks;
+  L->num_segments = pb->num_segments;
   if (pb->num_offdiag_chunks < 0 || pb->num_offdiag_chunks > pb->num_chunks) return VGG_ERR_INVALID_ARGUMENT;
   L->tile_desc = pb->tile_desc; L->num_tiles = pb->num_tiles;
   L->cam_q = pb->cam_q; L->cam_t = pb->cam_t; L->intr = pb->intr; L->pts = pb->pts;

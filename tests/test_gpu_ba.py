@@ -195,3 +195,33 @@ def test_window_bundle_adjustment_matches_oracle(cam, shared):
     np.testing.assert_allclose(pts.cpu().numpy(), po, atol=2e-6)
     np.testing.assert_allclose(ext.cpu().numpy(), eo, atol=1e-7)
     assert sg["final_cost"] < 0.2 * sg["initial_cost"]
+
+
+def test_ba_full_size_c3_properties():
+    """BASELINE configs[2] at full size (200 frames x 100k tracks, SIMPLE_RADIAL, shared camera; ~5 M observations, far
+    beyond what the oracle finishes in seconds): size-independent properties.  Noise-free observations of the
+    ground-truth scene => BA must drive the cost to the float32-storage floor of the pixels and recover the
+    ground-truth cameras / points / intrinsics from a perturbed start (the gauge is fixed by image 0 and t_x of
+    image 1, both left at their ground-truth values)."""
+    sc = make_scene(200, 100000, "SIMPLE_RADIAL", shared_camera=True, seed=0, noise_px=0.0, outlier_frac=0.0)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=0)
+    ext0[0] = sc.extrinsics[0]
+    ext0[1, 0, 3] = sc.extrinsics[1, 0, 3]
+    opt = BundleAdjustmentOptions()
+    opt.solver_options.gradient_tolerance = 1e-10
+    opt.solver_options.max_num_iterations = 40
+    pts, ext, K, extra, sg = BA.bundle_adjustment(D(pts0), D(ext0), D(K0), D(sc.tracks), D(sc.mask), None, D(extra0),
+                                                  True, "SIMPLE_RADIAL", opt)
+    n_res = 2 * int(sc.mask[:, sc.mask.sum(0) >= 2].sum())
+    assert sg["n_reduced"] == 6 * 200 + 2
+    assert sg["final_cost"] < 1e-6 * sg["initial_cost"]
+    assert sg["final_cost"] / n_res < 1e-8                       # ~3e-5 px rms: float32 pixels
+    # monotone cost over the successful steps (Levenberg-Marquardt invariant)
+    costs = [it["cost"] for it in sg["iterations"] if it["successful"]]
+    assert all(b <= a * (1 + 1e-12) for a, b in zip(costs, costs[1:]))
+    # (accuracy floor: the observations are stored in float32, 3e-5 px)
+    np.testing.assert_allclose(ext.cpu().numpy(), sc.extrinsics, atol=2e-5)
+    vi = sg["valid_idx"].cpu().numpy()
+    np.testing.assert_allclose(pts.cpu().numpy(), sc.points3D[vi], atol=1e-4)
+    np.testing.assert_allclose(float(K[0, 0, 0]), 1000.0, rtol=1e-6)
+    np.testing.assert_allclose(float(extra[0, 0]), sc.extra_params[0, 0], atol=1e-6)

@@ -225,3 +225,24 @@ def test_ba_full_size_c3_properties():
     np.testing.assert_allclose(pts.cpu().numpy(), sc.points3D[vi], atol=1e-4)
     np.testing.assert_allclose(float(K[0, 0, 0]), 1000.0, rtol=1e-6)
     np.testing.assert_allclose(float(extra[0, 0]), sc.extra_params[0, 0], atol=1e-6)
+
+
+def test_ba_per_frame_intrinsics_at_scale_properties():
+    """BASELINE configs[3] shape at reduced size (per-frame focal + distortion => 8x8 camera blocks, the 128 x 128
+    Schur tile variant over 8 camera groups): noise-free scene recovered from a perturbed start."""
+    sc = make_scene(120, 15000, "SIMPLE_RADIAL", shared_camera=False, seed=6, noise_px=0.0, outlier_frac=0.0)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=6)
+    ext0[0] = sc.extrinsics[0]
+    ext0[1, 0, 3] = sc.extrinsics[1, 0, 3]
+    opt = BundleAdjustmentOptions()
+    opt.solver_options.gradient_tolerance = 1e-10
+    opt.solver_options.max_num_iterations = 60
+    pts, ext, K, extra, sg = BA.bundle_adjustment(D(pts0), D(ext0), D(K0), D(sc.tracks), D(sc.mask), None, D(extra0),
+                                                  False, "SIMPLE_RADIAL", opt)
+    assert sg["n_reduced"] == 8 * 120
+    assert sg["final_cost"] < 1e-6 * sg["initial_cost"]
+    costs = [it["cost"] for it in sg["iterations"] if it["successful"]]
+    assert all(b <= a * (1 + 1e-12) for a, b in zip(costs, costs[1:]))
+    np.testing.assert_allclose(ext.cpu().numpy(), sc.extrinsics, atol=5e-5)
+    np.testing.assert_allclose(K.cpu().numpy()[:, 0, 0], sc.intrinsics[:, 0, 0], rtol=2e-5)
+    np.testing.assert_allclose(extra.cpu().numpy(), sc.extra_params, atol=2e-5)

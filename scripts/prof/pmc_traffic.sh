@@ -12,6 +12,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
       python bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/bench_$C.log 2>&1)
 done
 # calibration: known-size streaming reads with the kernels' access widths
+make -s -C $ROOT/scripts/ubench fetch_calib >/dev/null 2>&1
 if [ -x $ROOT/scripts/ubench/fetch_calib ]; then
   rm -rf /tmp/pmc_calib
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_calib -- $ROOT/scripts/ubench/fetch_calib > $OUT/calib.log 2>&1

@@ -64,3 +64,35 @@ def test_reference_reader_roundtrip(tmp_path, cam, shared):
         # every track element points back at the right 2D point of its image
         for im_id, p2 in zip(pt.image_ids, pt.point2D_idxs):
             assert images[im_id].point3D_ids[p2] == p + 1
+
+
+def test_tensor_to_pycolmap_drop_in_selection_rules():
+    """vggsfm_amd.utils.tensor_to_pycolmap keeps the reference's rules (tensor_to_pycolmap.py:62-68,128-146): tracks with
+    >= 2 inliers, 1-based ids in order, observations of points beyond max_points3D_val dropped, one shared camera."""
+    import torch
+
+    from vggsfm_amd.utils.tensor_to_pycolmap import batch_matrix_to_pycolmap, pycolmap_to_batch_matrix
+    rng = np.random.default_rng(0)
+    S, P = 5, 40
+    pts = rng.normal(size=(P, 3))
+    pts[3] = [4000.0, 0, 1]
+    masks = rng.random((S, P)) > 0.4
+    masks[:, 7] = False
+    masks[1:, 8] = False                                   # a single observation: not a valid track
+    ext = np.tile(np.eye(3, 4)[None], (S, 1, 1))
+    K = np.tile(np.array([[500.0, 0, 320], [0, 500, 240], [0, 0, 1]])[None], (S, 1, 1))
+    K[1:, 0, 0] = 600.0
+    tracks = rng.random((S, P, 2)).astype(np.float32) * 100
+    rec = batch_matrix_to_pycolmap(torch.from_numpy(pts), torch.from_numpy(ext), torch.from_numpy(K),
+                                   torch.from_numpy(tracks), torch.from_numpy(masks), torch.tensor([640, 480]),
+                                   shared_camera=True, camera_type="SIMPLE_RADIAL", extra_params=torch.zeros(S, 1))
+    valid = np.nonzero(masks.sum(0) >= 2)[0]
+    assert 7 not in valid and 8 not in valid
+    assert rec.num_points3D() == len(valid) and rec.num_images() == S
+    assert sorted(rec.point3D_ids()) == list(range(1, len(valid) + 1))
+    k3 = int(np.nonzero(valid == 3)[0][0])
+    assert not rec.masks[:, k3].any()                      # point 3 lies beyond max_points3D_val: no Point2D refers to it
+    assert (rec.intrinsics[:, 0, 0] == 500.0).all()        # shared camera = frame 0's
+    p, e, Kb, xp = pycolmap_to_batch_matrix(rec, device="cpu", camera_type="SIMPLE_RADIAL")
+    assert p.shape == (len(valid), 3) and e.shape == (S, 3, 4) and Kb.shape == (S, 3, 3) and xp.shape == (S, 1)
+    assert np.array_equal(p.numpy(), pts[valid])

@@ -114,6 +114,13 @@ __device__ __forceinline__ double sq_of_norm3(double a, double b, double c) {
   return n * n;
 }
 
+// kFilterLanes adjacent lanes share one point: lane q projects the frames s = q, q + L, q + 2L, ... (the per-frame
+// projection is a long dependent fp64 chain and one thread per point left 1.5 wavefronts per SIMD at 100k
+// points), the inlier bit-words are OR-combined with shuffles, every lane of the group then holds the whole
+// mask and runs the (early-exit) pair search redundantly.
+constexpr int kFilterLanes = 4;
+constexpr int kFilterPoints = kFilterThreads / kFilterLanes;      // points per workgroup
+
 template <int KD, typename TrackT>
 __global__ __launch_bounds__(kFilterThreads) void filter_kernel(
     const double* __restrict__ pts, int P, const TrackT* __restrict__ tracks, const double* __restrict__ ext,
@@ -121,40 +128,59 @@ __global__ __launch_bounds__(kFilterThreads) void filter_kernel(
     double max_err_sq, double min_tri_angle, int check_triangle, double hard_max, double behind_value,
     uint8_t* __restrict__ out_mask, uint8_t* __restrict__ out_detail) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  unsigned long long* bits = reinterpret_cast<unsigned long long*>(smem_raw);   // [NW][kFilterThreads]
+  unsigned long long* bits = reinterpret_cast<unsigned long long*>(smem_raw);   // [NW][kFilterPoints]
   const int tid = threadIdx.x;
-  const int p = blockIdx.x * kFilterThreads + tid;
+  const int lp = tid / kFilterLanes, q = tid % kFilterLanes;
+  const int p = blockIdx.x * kFilterPoints + lp;
   const bool live = p < P;
   double X = 0, Y = 0, Z = 0;
   if (live) { X = pts[3 * p]; Y = pts[3 * p + 1]; Z = pts[3 * p + 2]; }
   int count = 0;
-  unsigned long long word = 0;
-  for (int s = 0; s < S; ++s) {
-    bool inl = false;
-    if (live) {
-      double px, py, cx, cy, cz;
-      project_one<KD>(ext + 12 * s, K + 9 * s, KD ? extra + KD * s : nullptr, X, Y, Z, px, py, cx, cy, cz);
-      const double tx = (double)tracks[((size_t)s * P + p) * 2], ty = (double)tracks[((size_t)s * P + p) * 2 + 1];
-      const double dx = px - tx, dy = py - ty;
-      const double n = sqrt(dx * dx + dy * dy);
-      double err = n * n;
-      if (cz <= 0) err = behind_value;
-      inl = err <= max_err_sq;
+  const int nw = (S + 63) >> 6;
+  for (int wd = 0; wd < nw; ++wd) {
+    unsigned long long word = 0;
+    const int s_end = min(S, 64 * (wd + 1));
+    for (int s = 64 * wd + q; s < s_end; s += kFilterLanes) {
+      bool inl = false;
+      if (live) {
+        double px, py, cx, cy, cz;
+        project_one<KD>(ext + 12 * s, K + 9 * s, KD ? extra + KD * s : nullptr, X, Y, Z, px, py, cx, cy, cz);
+        const double tx = (double)tracks[((size_t)s * P + p) * 2], ty = (double)tracks[((size_t)s * P + p) * 2 + 1];
+        const double dx = px - tx, dy = py - ty;
+        const double n = sqrt(dx * dx + dy * dy);
+        double err = n * n;
+        if (cz <= 0) err = behind_value;
+        inl = err <= max_err_sq;
+      }
+      if (inl) word |= 1ull << (s & 63);
     }
-    if (inl) { word |= 1ull << (s & 63); ++count; }
-    if ((s & 63) == 63 || s == S - 1) { bits[(s >> 6) * kFilterThreads + tid] = word; word = 0; }
+#pragma unroll
+    for (int off = 1; off < kFilterLanes; off <<= 1) word |= __shfl_xor(word, off, 64);
+    count += __popcll(word);
+    if (q == 0) bits[wd * kFilterPoints + lp] = word;
   }
+  __syncthreads();
   bool valid = count >= 2;
   if (hard_max > 0) valid = valid && fabs(X) <= hard_max && fabs(Y) <= hard_max && fabs(Z) <= hard_max;
   bool tri_any = false;
   if (check_triangle && valid && live) {
-    // frames a < b, both inliers; iterate by decreasing frame distance
-    for (int dist = S - 1; dist >= 1 && !tri_any; --dist) {
-      for (int a = 0; a + dist < S; ++a) {
+    // frames a < b, both inliers ("exists a pair with angle >= threshold": the order of the search is free).
+    // Start from the widest inlier pair -- first and last inlier frame -- and shrink: for a track seen in a
+    // window of a long sequence this is O(1) instead of walking thousands of non-inlier (a, b) combinations.
+    int lo = S, hi = -1;
+    for (int wd = 0; wd < nw; ++wd) {
+      const unsigned long long wbits = bits[wd * kFilterPoints + lp];
+      if (wbits) {
+        if (lo == S) lo = 64 * wd + __ffsll((long long)wbits) - 1;
+        hi = 64 * wd + 63 - __clzll((long long)wbits);
+      }
+    }
+    for (int dist = hi - lo; dist >= 1 && !tri_any; --dist) {
+      for (int a = lo; a + dist <= hi; ++a) {
         const int b = a + dist;
-        const bool ia = (bits[(a >> 6) * kFilterThreads + tid] >> (a & 63)) & 1ull;
+        const bool ia = (bits[(a >> 6) * kFilterPoints + lp] >> (a & 63)) & 1ull;
         if (!ia) continue;
-        const bool ib = (bits[(b >> 6) * kFilterThreads + tid] >> (b & 63)) & 1ull;
+        const bool ib = (bits[(b >> 6) * kFilterPoints + lp] >> (b & 63)) & 1ull;
         if (!ib) continue;
         const double* ca = centers + 3 * a;
         const double* cb = centers + 3 * b;
@@ -166,11 +192,11 @@ __global__ __launch_bounds__(kFilterThreads) void filter_kernel(
     }
   }
   const bool ret = check_triangle ? (tri_any && valid) : valid;
-  if (live) out_mask[p] = ret ? 1 : 0;
+  if (live && q == 0) out_mask[p] = ret ? 1 : 0;
   if (out_detail) {
-    for (int s = 0; s < S; ++s) {
+    for (int s = q; s < S; s += kFilterLanes) {
       if (live) {
-        bool d = (bits[(s >> 6) * kFilterThreads + tid] >> (s & 63)) & 1ull;
+        bool d = (bits[(s >> 6) * kFilterPoints + lp] >> (s & 63)) & 1ull;
         if (check_triangle) d = d && tri_any;
         out_detail[(size_t)s * P + p] = d ? 1 : 0;
       }
@@ -305,8 +331,8 @@ int vgg_filter_points(const double* points3D, int P, const void* tracks, int tra
     if (!workspace) return VGG_ERR_WORKSPACE;
     centers_kernel<<<div_up(S, 64), 64, 0, st>>>(extrinsics, S, centers);
   }
-  const size_t lds = (size_t)((S + 63) / 64) * kFilterThreads * sizeof(unsigned long long);
-  const int grid = div_up(P, kFilterThreads);
+  const size_t lds = (size_t)((S + 63) / 64) * kFilterPoints * sizeof(unsigned long long);
+  const int grid = div_up(P, kFilterPoints);
   const double thr = max_reproj_error * max_reproj_error;
 #define VGG_FILTER(KD, T)                                                                                          \
   filter_kernel<KD, T><<<grid, kFilterThreads, lds, st>>>(points3D, P, (const T*)tracks, extrinsics, intrinsics,   \

@@ -50,6 +50,7 @@ WORKLOADS = {
     "c2": (50, 20000, "SIMPLE_PINHOLE", False),
     "c3": (200, 100000, "SIMPLE_RADIAL", True),
     "c4shard": (400, 37500, "SIMPLE_RADIAL", False),
+    "c4full": (400, 300000, "SIMPLE_RADIAL", False),      # whole configs[3] on ONE GPU (robustness / capacity check)
 }
 
 

@@ -117,7 +117,9 @@ def test_ba_matches_oracle_trajectory(S, N, cam, shared, kind):
     assert compared >= min(8, so["num_iterations"])
     assert abs(sg["final_cost"] - so["final_cost"]) <= 1e-8 * so["final_cost"]
     np.testing.assert_allclose(ext.cpu().numpy(), eo, rtol=0, atol=5e-6)
-    np.testing.assert_allclose(K.cpu().numpy()[:, 0, 0], Ko[:, 0, 0], rtol=1e-7)
+    # (final values: both sides stop at the gradient tolerance, not at the exact optimum, and the last accept /
+    #  reject decisions sit at the rounding-noise floor -- hence 1e-6, the north-star figure is 1e-4)
+    np.testing.assert_allclose(K.cpu().numpy()[:, 0, 0], Ko[:, 0, 0], rtol=1e-6)
     np.testing.assert_allclose(pts.cpu().numpy(), po, rtol=0, atol=5e-5)
     if xo is not None:
         np.testing.assert_allclose(extra.cpu().numpy(), xo, rtol=0, atol=1e-7)

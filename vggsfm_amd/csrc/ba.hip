@@ -469,11 +469,22 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
   double n_X0 = 0, n_X1 = 0, n_X2 = 0;
   float2 n_uv = make_float2(0.f, 0.f);
   bool n_ptc = false;
+  // (two stages: the row bounds / coordinates are loaded TWO points ahead, the observations ONE point ahead, so
+  //  that the observation loads never wait for the row-bound load they depend on)
+  int m_o0 = 0, m_o1 = 0;
+  double m_X0 = 0, m_X1 = 0, m_X2 = 0;
+  bool m_ptc = false;
   if (p < d.P) {
     n_o0 = pb.row_ptr[p]; n_o1 = pb.row_ptr[p + 1];
     n_X0 = pb.pts[3 * p]; n_X1 = pb.pts[3 * p + 1]; n_X2 = pb.pts[3 * p + 2];
     n_ptc = pb.pt_const ? pb.pt_const[p] != 0 : false;
     if (n_o0 + lane < n_o1) { n_c = pb.obs_cam[n_o0 + lane]; n_uv = pb.obs_uv[n_o0 + lane]; n_slot = pb.obs_slot[n_o0 + lane]; }
+    if (p + nw < d.P) {
+      const int pm = p + nw;
+      m_o0 = pb.row_ptr[pm]; m_o1 = pb.row_ptr[pm + 1];
+      m_X0 = pb.pts[3 * pm]; m_X1 = pb.pts[3 * pm + 1]; m_X2 = pb.pts[3 * pm + 2];
+      m_ptc = pb.pt_const ? pb.pt_const[pm] != 0 : false;
+    }
   }
   for (; p < d.P; p += nw) {
     const int o0 = n_o0, o1 = n_o1;
@@ -482,12 +493,15 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
     const int f_c = n_c, f_slot = n_slot;
     const float2 f_uv = n_uv;
     {
-      const int pn = p + nw;
-      if (pn < d.P) {
-        n_o0 = pb.row_ptr[pn]; n_o1 = pb.row_ptr[pn + 1];
-        n_X0 = pb.pts[3 * pn]; n_X1 = pb.pts[3 * pn + 1]; n_X2 = pb.pts[3 * pn + 2];
-        n_ptc = pb.pt_const ? pb.pt_const[pn] != 0 : false;
-        if (n_o0 + lane < n_o1) { n_c = pb.obs_cam[n_o0 + lane]; n_uv = pb.obs_uv[n_o0 + lane]; n_slot = pb.obs_slot[n_o0 + lane]; }
+      // stage 1 -> current of the next iteration: observations of point p + nw (its bounds arrived an iteration ago)
+      n_o0 = m_o0; n_o1 = m_o1; n_X0 = m_X0; n_X1 = m_X1; n_X2 = m_X2; n_ptc = m_ptc;
+      if (p + nw < d.P && n_o0 + lane < n_o1) { n_c = pb.obs_cam[n_o0 + lane]; n_uv = pb.obs_uv[n_o0 + lane]; n_slot = pb.obs_slot[n_o0 + lane]; }
+      // stage 2: bounds / coordinates of point p + 2 nw
+      const int pm = p + 2 * nw;
+      if (pm < d.P) {
+        m_o0 = pb.row_ptr[pm]; m_o1 = pb.row_ptr[pm + 1];
+        m_X0 = pb.pts[3 * pm]; m_X1 = pb.pts[3 * pm + 1]; m_X2 = pb.pts[3 * pm + 2];
+        m_ptc = pb.pt_const ? pb.pt_const[pm] != 0 : false;
       }
     }
     double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0}, Wa[3 * (KD ? KD : 1)];
@@ -1037,11 +1051,22 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
   double n_X0 = 0, n_X1 = 0, n_X2 = 0;
   float2 n_uv = make_float2(0.f, 0.f);
   bool n_ptc = false;
+  // (two stages: the row bounds / coordinates are loaded TWO points ahead, the observations ONE point ahead, so
+  //  that the observation loads never wait for the row-bound load they depend on)
+  int m_o0 = 0, m_o1 = 0;
+  double m_X0 = 0, m_X1 = 0, m_X2 = 0;
+  bool m_ptc = false;
   if (p < d.P) {
     n_o0 = pb.row_ptr[p]; n_o1 = pb.row_ptr[p + 1];
     n_X0 = pb.pts[3 * p]; n_X1 = pb.pts[3 * p + 1]; n_X2 = pb.pts[3 * p + 2];
     n_ptc = pb.pt_const ? pb.pt_const[p] != 0 : false;
     if (n_o0 + lane < n_o1) { n_c = pb.obs_cam[n_o0 + lane]; n_uv = pb.obs_uv[n_o0 + lane]; }
+    if (p + nw < d.P) {
+      const int pm = p + nw;
+      m_o0 = pb.row_ptr[pm]; m_o1 = pb.row_ptr[pm + 1];
+      m_X0 = pb.pts[3 * pm]; m_X1 = pb.pts[3 * pm + 1]; m_X2 = pb.pts[3 * pm + 2];
+      m_ptc = pb.pt_const ? pb.pt_const[pm] != 0 : false;
+    }
   }
   for (; p < d.P; p += nw) {
     const int o0 = n_o0, o1 = n_o1;
@@ -1050,12 +1075,15 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
     const int f_c = n_c;
     const float2 f_uv = n_uv;
     {
-      const int pn = p + nw;
-      if (pn < d.P) {
-        n_o0 = pb.row_ptr[pn]; n_o1 = pb.row_ptr[pn + 1];
-        n_X0 = pb.pts[3 * pn]; n_X1 = pb.pts[3 * pn + 1]; n_X2 = pb.pts[3 * pn + 2];
-        n_ptc = pb.pt_const ? pb.pt_const[pn] != 0 : false;
-        if (n_o0 + lane < n_o1) { n_c = pb.obs_cam[n_o0 + lane]; n_uv = pb.obs_uv[n_o0 + lane]; }
+      // stage 1 -> current of the next iteration: observations of point p + nw (its bounds arrived an iteration ago)
+      n_o0 = m_o0; n_o1 = m_o1; n_X0 = m_X0; n_X1 = m_X1; n_X2 = m_X2; n_ptc = m_ptc;
+      if (p + nw < d.P && n_o0 + lane < n_o1) { n_c = pb.obs_cam[n_o0 + lane]; n_uv = pb.obs_uv[n_o0 + lane]; }
+      // stage 2: bounds / coordinates of point p + 2 nw
+      const int pm = p + 2 * nw;
+      if (pm < d.P) {
+        m_o0 = pb.row_ptr[pm]; m_o1 = pb.row_ptr[pm + 1];
+        m_X0 = pb.pts[3 * pm]; m_X1 = pb.pts[3 * pm + 1]; m_X2 = pb.pts[3 * pm + 2];
+        m_ptc = pb.pt_const ? pb.pt_const[pm] != 0 : false;
       }
     }
     double t3[3] = {0, 0, 0};

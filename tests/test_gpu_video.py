@@ -121,3 +121,22 @@ def test_joint_bundle_adjustment_properties_and_oracle():
     np.testing.assert_allclose(ext.cpu().numpy(), e_ref, atol=2e-6)
     np.testing.assert_allclose(pts.cpu().numpy()[keep_ref], p_ref[keep_ref], atol=2e-5)
     assert abs(float(K[0, 0, 0]) / Ko[0, 0, 0] - 1) < 1e-6
+
+
+@pytest.mark.gpu
+def test_triangulate_extra_points_matches_oracle_composition():
+    """runner.py:696-736 (dense extra points of a frame neighbourhood)."""
+    from vggsfm_amd.utils.triangulation import triangulate_extra_points
+    S, N = 9, 2000
+    sc = make_scene(S, N, "SIMPLE_RADIAL", shared_camera=False, seed=45, outlier_frac=0.05)
+    pts, valid = triangulate_extra_points(D(sc.tracks), D(sc.vis), D(sc.score), D(sc.extrinsics), D(sc.intrinsics),
+                                          D(sc.extra_params), max_reproj_error=4)
+    tn = G.cam_from_img(sc.tracks, sc.intrinsics, sc.extra_params)
+    p_ref, n_ref, _ = G.triangulate_tracks_chunk(sc.extrinsics, tn, G.generate_combinations(S), track_vis=sc.vis,
+                                                 track_score=sc.score)
+    v_ref, _ = G.filter_all_points3D(p_ref, sc.tracks.astype(np.float64), sc.extrinsics, sc.intrinsics, sc.extra_params,
+                                     max_reproj_error=4)
+    v_ref = v_ref & (n_ref > 3)
+    assert np.array_equal(valid.cpu().numpy(), v_ref)
+    np.testing.assert_allclose(pts.cpu().numpy()[v_ref], p_ref[v_ref], rtol=1e-9, atol=1e-9)
+    assert v_ref.mean() > 0.3          # (9 frames, visibility windows of 3-4 frames: many tracks have <= 3 inliers)

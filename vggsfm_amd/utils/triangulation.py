@@ -373,3 +373,17 @@ def iterative_global_BA(pred_tracks, intrinsics, extrinsics, pred_vis, pred_scor
     pts = pts[after]
     BA_inlier_masks = filt2[:, after]
     return pts, ext, K, extra, vt, BA_inlier_masks, summary
+
+
+def triangulate_extra_points(extra_track, extra_vis, extra_score, extrinsics, intrinsics, extra_params=None,
+                             max_reproj_error=4):
+    """The geometry of the dense-point pass of ``VGGSfMRunner.triangulate_extra_points`` (vggsfm/runners/runner.py:696-736)
+    for one neighbourhood of frames: undistort, LO-RANSAC triangulate with the refined cameras, keep points with more
+    than 3 inlier views that also pass the reprojection / triangulation-angle filter.
+    extra_track (S,N,2) px, extra_vis / extra_score (S,N), cameras of the S neighbour frames.
+    Returns (points3D (N,3), valid (N,) bool)."""
+    tn = cam_from_img(extra_track, intrinsics, extra_params)
+    pts, inlier_num, _ = triangulate_tracks(extrinsics, tn, track_vis=extra_vis, track_score=extra_score)
+    valid, _ = filter_all_points3D(pts, extra_track, extrinsics, intrinsics, extra_params=extra_params,
+                                   max_reproj_error=max_reproj_error)
+    return pts, (inlier_num > 3) & valid

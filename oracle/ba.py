@@ -193,7 +193,8 @@ def build_observations(points3d, extrinsics, tracks, masks, max_points3D_val=300
 
 def bundle_adjustment(points3d, extrinsics, intrinsics, tracks, masks, extra_params=None, shared_camera=False,
                       camera_type="SIMPLE_PINHOLE", options=None, normalize=False, constant_points=None,
-                      constant_pose_frames=None, filter_negative_depth=True, refine_focal=True, refine_extra=True):
+                      constant_pose_frames=None, filter_negative_depth=True, refine_focal=True, refine_extra=True,
+                      loss=0, loss_scale=1.0):
     """What `batch_matrix_to_pycolmap -> pycolmap.bundle_adjustment [-> normalize] ->
     pycolmap_to_batch_matrix` computes.  Returns (points3D_opt (P_valid,3) with zero rows for deleted
     points, extrinsics (S,3,4), intrinsics (S,3,3), extra_params (S,1)|None, summary)."""
@@ -227,7 +228,8 @@ def bundle_adjustment(points3d, extrinsics, intrinsics, tracks, masks, extra_par
     pt_const = None if constant_points is None else np.ascontiguousarray(
         np.asarray(constant_points, bool)[valid_idx].astype(np.uint8))
     summary = solve_csr(cam_q, cam_t, intr, pts, cam_intr, row_ptr, obs_cam, obs_uv, MODEL[camera_type], options,
-                        refine_focal=refine_focal, refine_extra=refine_extra, cam_const=cam_const, pt_const=pt_const)
+                        refine_focal=refine_focal, refine_extra=refine_extra, loss=loss, loss_scale=loss_scale,
+                        cam_const=cam_const, pt_const=pt_const)
     ext = np.concatenate([quat_to_rotmat(cam_q), cam_t[:, :, None]], -1)
     pts[deleted] = 0.0
     if normalize:

@@ -248,3 +248,33 @@ def test_ba_per_frame_intrinsics_at_scale_properties():
     np.testing.assert_allclose(ext.cpu().numpy(), sc.extrinsics, atol=5e-5)
     np.testing.assert_allclose(K.cpu().numpy()[:, 0, 0], sc.intrinsics[:, 0, 0], rtol=2e-5)
     np.testing.assert_allclose(extra.cpu().numpy(), sc.extra_params, atol=2e-5)
+
+
+@pytest.mark.parametrize("loss,scale", [("HUBER", 1.0), ("CAUCHY", 2.0), ("SOFT_L1", 1.5)])
+def test_ba_robust_losses_match_oracle(loss, scale):
+    """Ceres loss functions + corrector (`BundleAdjustmentOptions.loss_function_type`, COLMAP CreateLossFunction):
+    Huber-weighted (and Cauchy / SoftL1) normal equations on a scene WITH outliers, GPU vs oracle."""
+    from vggsfm_amd.ba_options import LOSS_ID
+    sc = make_scene(12, 900, "SIMPLE_RADIAL", shared_camera=True, seed=17, outlier_frac=0.08)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=17)
+    opt = BundleAdjustmentOptions()
+    opt.loss_function_type, opt.loss_function_scale = loss, scale
+    opt.solver_options.max_num_iterations = 30
+    oo = OB.ceres_options(30)
+    po, eo, Ko, xo, so = OB.bundle_adjustment(pts0, ext0, K0, sc.tracks, sc.mask, extra0, True, "SIMPLE_RADIAL", options=oo,
+                                              loss=LOSS_ID[loss], loss_scale=scale)
+    pts, ext, K, extra, sg = BA.bundle_adjustment(D(pts0), D(ext0), D(K0), D(sc.tracks), D(sc.mask), None, D(extra0), True,
+                                                  "SIMPLE_RADIAL", opt)
+    compared = 0
+    for a, b in zip(sg["iterations"], so["iterations"]):
+        if b["iteration"] > 0 and abs(b["cost_change"]) < 1e-9 * b["cost"]:
+            break
+        assert a["successful"] == b["successful"], (a, b)
+        assert abs(a["cost"] - b["cost"]) <= 1e-9 * b["cost"], (a, b)
+        compared += 1
+    assert compared >= 4
+    # the robust cost is far below the squared cost of the same residuals (the outliers are down-weighted)
+    assert abs(sg["final_cost"] - so["final_cost"]) <= 1e-8 * so["final_cost"]
+    np.testing.assert_allclose(ext.cpu().numpy(), eo, atol=5e-6)
+    np.testing.assert_allclose(pts.cpu().numpy(), po, atol=5e-5)
+    np.testing.assert_allclose(float(K[0, 0, 0]), Ko[0, 0, 0], rtol=1e-6)

@@ -278,3 +278,32 @@ def test_ba_robust_losses_match_oracle(loss, scale):
     np.testing.assert_allclose(ext.cpu().numpy(), eo, atol=5e-6)
     np.testing.assert_allclose(pts.cpu().numpy(), po, atol=5e-5)
     np.testing.assert_allclose(float(K[0, 0, 0]), Ko[0, 0, 0], rtol=1e-6)
+
+
+@pytest.mark.parametrize("shared", [True, False])
+@pytest.mark.parametrize("rf,rk", [(True, False), (False, True), (False, False)])
+def test_ba_partial_intrinsics_refinement_matches_oracle(shared, rf, rk):
+    """`refine_focal_length` / `refine_extra_params` combinations (COLMAP SetConstantCamIntrinsics subsets): focal
+    only, distortion only (the `only_k` layout of the camera block), neither."""
+    sc = make_scene(10, 700, "SIMPLE_RADIAL", shared_camera=shared, seed=19, outlier_frac=0.0)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=19)
+    opt = BundleAdjustmentOptions()
+    opt.refine_focal_length, opt.refine_extra_params = rf, rk
+    opt.solver_options.max_num_iterations = 25
+    po, eo, Ko, xo, so = OB.bundle_adjustment(pts0, ext0, K0, sc.tracks, sc.mask, extra0, shared, "SIMPLE_RADIAL",
+                                              options=OB.ceres_options(25), refine_focal=rf, refine_extra=rk)
+    pts, ext, K, extra, sg = BA.bundle_adjustment(D(pts0), D(ext0), D(K0), D(sc.tracks), D(sc.mask), None, D(extra0),
+                                                  shared, "SIMPLE_RADIAL", opt)
+    assert sg["n_reduced"] == so["n_reduced"]
+    for a, b in zip(sg["iterations"], so["iterations"]):
+        if b["iteration"] > 0 and abs(b["cost_change"]) < 1e-9 * b["cost"]:
+            break
+        assert a["successful"] == b["successful"] and abs(a["cost"] - b["cost"]) <= 1e-9 * b["cost"], (a, b)
+    assert abs(sg["final_cost"] - so["final_cost"]) <= 1e-8 * so["final_cost"]
+    if not rf:
+        assert np.array_equal(K.cpu().numpy(), K0)                 # focal untouched
+    if not rk:
+        assert np.array_equal(extra.cpu().numpy(), extra0)         # distortion untouched
+    np.testing.assert_allclose(ext.cpu().numpy(), eo, atol=5e-6)
+    np.testing.assert_allclose(K.cpu().numpy()[:, 0, 0], Ko[:, 0, 0], rtol=1e-6)
+    np.testing.assert_allclose(extra.cpu().numpy(), xo, atol=1e-6)

@@ -20,7 +20,24 @@ Abuf = Abuf0.clone()
 ws_ch = torch.empty(int(L.vgg_cholesky_workspace_bytes(n)), dtype=torch.uint8, device="cuda")
 fail = torch.zeros(1, dtype=torch.int32, device="cuda")
 orig_build = BA.build_schur_tiles
-for frac in (1.0, 0.9, 0.8):
+hip = ctypes.CDLL("libamdhip64.so")
+
+
+class RawStream:
+    """HIP stream restricted to a set of CUs (hipExtStreamCreateWithCUMask); quacks like torch.cuda.Stream here."""
+
+    def __init__(self, mask_words):
+        self.h = ctypes.c_void_p()
+        arr = (ctypes.c_uint32 * len(mask_words))(*mask_words)
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(self.h), len(mask_words), arr)
+        assert rc == 0, rc
+        self.cuda_stream = self.h.value
+
+
+MASK_CHOL = [0xFFFFFFFF] + [0] * 7                     # 32 CUs for the factorisation
+MASK_REST = [0] + [0xFFFFFFFF] * 7                     # 224 CUs for everything else
+
+for frac in (1.0, 0.875):
     def patched(row_ptr, obs_cam, group=BA.GROUP, chunk=BA.CHUNK, max_chunks=None, _f=frac):
         if max_chunks is not None:
             max_chunks = tuple(int(m * _f) for m in max_chunks)
@@ -53,5 +70,11 @@ for frac in (1.0, 0.9, 0.8):
         Abuf.copy_(Abuf0); torch.cuda.synchronize(); phase1(s1); chol(s1)
     def both_conc():
         Abuf.copy_(Abuf0); torch.cuda.synchronize(); phase1(s1); chol(s2)
+    m1, m2 = RawStream(MASK_REST), RawStream(MASK_CHOL)
+    def both_masked():
+        Abuf.copy_(Abuf0); torch.cuda.synchronize(); phase1(m1); chol(m2)
+    t_p1m = timed(lambda: phase1(m1))
+    t_chm = timed(lambda: (Abuf.copy_(Abuf0), torch.cuda.synchronize(), chol(m2)))
     print(f"tile slots x{frac}: phase1 {t_p1:.3f} ms, cholesky (+copy,sync) {t_ch:.3f} ms, sequential {timed(both_seq):.3f} ms, "
-          f"concurrent {timed(both_conc):.3f} ms")
+          f"concurrent {timed(both_conc):.3f} ms | CU-masked: phase1 on 224 CUs {t_p1m:.3f} ms, cholesky on 32 CUs {t_chm:.3f} ms, "
+          f"concurrent {timed(both_masked):.3f} ms")

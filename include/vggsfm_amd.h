@@ -129,8 +129,7 @@ typedef struct {
   const uint8_t* pt_const;    /* [num_pts] or NULL */
   /* Schur tile work list (device) */
   int32_t num_chunks;
-  int32_t num_offdiag_chunks; /* chunks [0, num_offdiag_chunks) belong to off-diagonal tiles (groupI < groupJ), the rest
-                                 to diagonal tiles; the two sets are separate launches */
+  int32_t num_tile_batches;   /* >= 1: the tiles are cut into batches of consecutive camera groups groupI (tile_batches) */
   const int32_t* chunk_desc;  /* [num_chunks,6] = groupI, groupJ, tile_entry_begin, tile_entry_end, j, J:
                                  workgroup j of the J of its tile takes the 32-entry sub-chunks j, j+J, ... */
   const int32_t* entries;     /* [num_entries,4] = point, segment_A, segment_B, maskA | maskB<<16
@@ -141,6 +140,12 @@ typedef struct {
   int32_t num_tiles;
   const int32_t* tile_desc;   /* [num_tiles,4] = groupI, groupJ, chunk_begin, chunk_end (chunks of one tile
                                  are consecutive; their partial sums are reduced in this order) */
+  const int32_t* tile_batches;/* HOST array [num_tile_batches,6] = chunk_begin, first_diagonal_chunk, chunk_end, tile_begin,
+                                 tile_end, first_camera_group.  Batch-major order of chunk_desc / tile_desc: inside a batch
+                                 the chunks of the off-diagonal tiles (groupI < groupJ) come first, then the diagonal
+                                 ones (separate launches).  Column block g of the reduced system only receives sums
+                                 from tiles with groupI <= g: it is complete once the batches up to that of group g
+                                 are done, so the factorisation can start while later batches are being computed. */
 } vgg_ba_problem;
 
 typedef struct {
@@ -150,6 +155,10 @@ typedef struct {
   double function_tolerance, gradient_tolerance, parameter_tolerance;
   double initial_trust_region_radius, max_trust_region_radius, min_trust_region_radius;
   double min_lm_diagonal, max_lm_diagonal, min_relative_decrease;
+  int32_t overlap_factorization; /* 0 = off; otherwise the number of CUs (a multiple of 32) given to the factorisation
+                                    while it overlaps the tile batches 1.. (>= 2 batches; they then run on the other
+                                    CUs, both on CU-masked side streams joined back into `stream`).  Single GPU only:
+                                    the multi-GPU loop all-reduces the complete system between phases 1 and 2 */
 } vgg_ba_options;
 
 typedef struct {

@@ -229,6 +229,33 @@ def test_ba_full_size_c3_properties():
     np.testing.assert_allclose(float(extra[0, 0]), sc.extra_params[0, 0], atol=1e-6)
 
 
+@pytest.mark.parametrize("shared,S,N", [(True, 72, 6000), (False, 56, 4000)])
+def test_ba_overlapped_factorization_matches_single_stream(monkeypatch, shared, S, N):
+    """Opt-in mode (ba.OVERLAP_FACTORIZATION): Schur tiles in 3 batches, batches 1.. and the Cholesky factorisation
+    on two CU-masked streams, the late batches added to the panel when it is loaded (S2).  Only the summation order
+    changes: same trajectory to rounding as the single-stream solve, and bit-identical from run to run (a race
+    between a batch and the panel that reads it would show up here)."""
+    sc = make_scene(S, N, "SIMPLE_RADIAL", shared_camera=shared, seed=11)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=11)
+    opt = BundleAdjustmentOptions()
+    opt.solver_options.max_num_iterations = 15
+
+    def solve():
+        return BA.bundle_adjustment(D(pts0), D(ext0), D(K0), D(sc.tracks), D(sc.mask), None, D(extra0), shared,
+                                    "SIMPLE_RADIAL", opt)
+    ref = solve()
+    monkeypatch.setattr(BA, "OVERLAP_FACTORIZATION", True)
+    monkeypatch.setattr(BA, "OVERLAP_MIN_OBS", 0)
+    monkeypatch.setattr(BA, "OVERLAP_MIN_FRAMES", 0)
+    a, b = solve(), solve()
+    for x, y in zip(a[:4], b[:4]):
+        assert torch.equal(x, y)
+    assert a[4]["num_iterations"] == ref[4]["num_iterations"]
+    assert abs(a[4]["final_cost"] - ref[4]["final_cost"]) <= 1e-9 * ref[4]["final_cost"]
+    for x, y in zip(a[:4], ref[:4]):
+        np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-7, atol=1e-7)
+
+
 def test_ba_per_frame_intrinsics_at_scale_properties():
     """BASELINE configs[3] shape at reduced size (per-frame focal + distortion => 8x8 camera blocks, the 128 x 128
     Schur tile variant over 8 camera groups): noise-free scene recovered from a perturbed start."""

@@ -144,10 +144,13 @@ def test_normalize_matches_oracle():
     np.testing.assert_allclose(p1.numpy(), p2, rtol=1e-13, atol=1e-13)
 
 
+@pytest.mark.parametrize("num_batches", [1, 2, 3])
 @pytest.mark.parametrize("max_chunks", [1, 7, 40, 100000])
-def test_schur_chunks_adaptive_cover(max_chunks):
+def test_schur_chunks_adaptive_cover(max_chunks, num_batches):
     """Adaptive chunk size: every entry belongs to exactly one workgroup's strided sub-chunks and the
-    workgroup count respects the device capacity (or is one per tile when there are more tiles than slots)."""
+    workgroup count respects the device capacity (or is one per tile when there are more tiles than slots).
+    Batches: consecutive chunk / tile ranges, off-diagonal chunks before the diagonal ones inside each batch,
+    camera groups gI non-decreasing over the batches, and every tile of a batch has gI >= first_camera_group."""
     torch.manual_seed(0)
     S, P = 40, 300
     m = torch.rand(S, P) < 0.4
@@ -156,15 +159,29 @@ def test_schur_chunks_adaptive_cover(max_chunks):
     obs_cam = pm[:, 1].to(torch.int32)
     row_ptr = torch.zeros(P + 1, dtype=torch.int32)
     row_ptr[1:] = torch.cumsum(m.sum(0), 0).to(torch.int32)
-    desc, ent, tiles, slot, nseg = BA.build_schur_tiles(row_ptr, obs_cam, max_chunks=max_chunks)
+    desc, ent, tiles, slot, nseg, batches = BA.build_schur_tiles(row_ptr, obs_cam, max_chunks=max_chunks,
+                                                                 num_batches=num_batches, later_scale=0.875)
     seen = np.zeros(len(ent), int)
     for gI, gJ, tb, te, j, J in desc.numpy():
         for s0 in range(tb + j * BA.SUB, te, J * BA.SUB):
             seen[s0:min(s0 + BA.SUB, te)] += 1
     assert (seen == 1).all()
-    assert len(desc) <= max(2 * max_chunks, len(tiles))
-    td = tiles.numpy()
+    assert len(desc) <= max(2 * max_chunks * num_batches, len(tiles))
+    td, cd, bd = tiles.numpy(), desc.numpy(), batches.numpy()
     assert td[0, 2] == 0 and td[-1, 3] == len(desc) and (td[1:, 2] == td[:-1, 3]).all()
+    assert not batches.is_cuda and bd.shape == (num_batches, 6)
+    assert bd[0, 0] == 0 and bd[-1, 2] == len(cd) and bd[0, 3] == 0 and bd[-1, 4] == len(td)
+    assert (bd[1:, 0] == bd[:-1, 2]).all() and (bd[1:, 3] == bd[:-1, 4]).all() and (np.diff(bd[:, 5]) >= 0).all()
+    for c0, cm, c1, t0, t1, g0 in bd:
+        assert (cd[c0:cm, 0] != cd[c0:cm, 1]).all() and (cd[cm:c1, 0] == cd[cm:c1, 1]).all()
+        assert (td[t0:t1, 0] >= g0).all() and (td[t0:t1, 2] >= c0).all() and (td[t0:t1, 3] <= c1).all()
+        if t1 > t0:
+            assert td[t0:t1, 0].min() == g0
+    # a camera group belongs to one batch only (column blocks of the reduced system complete batch by batch)
+    owner = {}
+    for b, (c0, cm, c1, t0, t1, g0) in enumerate(bd):
+        for g in np.unique(td[t0:t1, 0]):
+            assert owner.setdefault(int(g), b) == b
 
 
 def test_generate_combinations_matches_itertools_order():

@@ -25,10 +25,10 @@ class BAProblem(ctypes.Structure):
                 ("pts", ctypes.c_void_p), ("row_ptr", ctypes.c_void_p), ("obs_cam", ctypes.c_void_p),
                 ("obs_uv", ctypes.c_void_p), ("col_ptr", ctypes.c_void_p), ("cobs_pt", ctypes.c_void_p),
                 ("cobs_uv", ctypes.c_void_p), ("cam_const", ctypes.c_void_p), ("intr_const", ctypes.c_void_p),
-                ("pt_const", ctypes.c_void_p), ("num_chunks", ctypes.c_int32), ("num_offdiag_chunks", ctypes.c_int32),
+                ("pt_const", ctypes.c_void_p), ("num_chunks", ctypes.c_int32), ("num_tile_batches", ctypes.c_int32),
                 ("chunk_desc", ctypes.c_void_p),
                 ("entries", ctypes.c_void_p), ("num_segments", ctypes.c_int32), ("obs_slot", ctypes.c_void_p),
-                ("num_tiles", ctypes.c_int32), ("tile_desc", ctypes.c_void_p)]
+                ("num_tiles", ctypes.c_int32), ("tile_desc", ctypes.c_void_p), ("tile_batches", ctypes.c_void_p)]
 
 
 class BAOptions(ctypes.Structure):
@@ -37,7 +37,8 @@ class BAOptions(ctypes.Structure):
                 ("gradient_tolerance", ctypes.c_double), ("parameter_tolerance", ctypes.c_double),
                 ("initial_trust_region_radius", ctypes.c_double), ("max_trust_region_radius", ctypes.c_double),
                 ("min_trust_region_radius", ctypes.c_double), ("min_lm_diagonal", ctypes.c_double),
-                ("max_lm_diagonal", ctypes.c_double), ("min_relative_decrease", ctypes.c_double)]
+                ("max_lm_diagonal", ctypes.c_double), ("min_relative_decrease", ctypes.c_double),
+                ("overlap_factorization", ctypes.c_int32)]
 
 
 class BAIteration(ctypes.Structure):

@@ -27,6 +27,14 @@ GROUP = 16          # cameras per Schur tile side (must match kGroup in csrc/ba.
 CHUNK = 1024        # tile entries per workgroup
 SUB = 32            # entries per strided sub-chunk (kSub in csrc/ba.hip)
 MIN_CHUNK = 128     # lower bound of the adaptive chunk size
+# Single-GPU solves can factorise on a CU-masked stream while the later Schur tile batches run on the other CUs.
+# Correct and bit-reproducible, but measured SLOWER on MI355X in round 1 (3.50 vs 3.09 ms per iteration at 200 x 100k:
+# the factorisation's trailing updates need 3 rounds on 32 CUs and every dependent launch pays ~7.5 us while a second
+# queue is active) -- hence off by default.
+OVERLAP_FACTORIZATION = False
+OVERLAP_MIN_OBS, OVERLAP_MIN_FRAMES = 1_000_000, 8 * GROUP   # smaller problems keep one batch
+TILE_BATCHES = 3     # Schur tile launches per iteration when the factorisation overlaps them (large problems)
+CHOL_CUS = 32        # CUs given to the factorisation while it overlaps (options.overlap_factorization; multiple of 32)
 
 
 # ------------------------------------------------------------------ rotations (Eigen conventions)
@@ -95,7 +103,7 @@ class DeviceProblem:
     refine_extra: bool = True
     loss: int = 0
     loss_scale: float = 1.0
-    num_offdiag_chunks: int = -1      # derived from chunk_desc on first use
+    batch_desc: Optional[torch.Tensor] = None   # (B,6) int32 on the HOST (build_schur_tiles); None = derive one batch
 
     @property
     def num_obs(self):
@@ -112,15 +120,19 @@ class DeviceProblem:
             t = getattr(self, name)
             setattr(P, name, None if t is None else t.data_ptr())
         P.num_chunks = self.chunk_desc.shape[0]
-        if self.num_offdiag_chunks < 0:
-            self.num_offdiag_chunks = int((self.chunk_desc[:, 0] != self.chunk_desc[:, 1]).sum().item())
-        P.num_offdiag_chunks = self.num_offdiag_chunks
+        if self.batch_desc is None:                 # a hand-built problem: one batch, off-diagonal chunks first
+            noff = int((self.chunk_desc[:, 0] != self.chunk_desc[:, 1]).sum().item())
+            self.batch_desc = torch.tensor([[0, noff, self.chunk_desc.shape[0], 0, self.tile_desc.shape[0], 0]],
+                                           dtype=torch.int32)
+        self.batch_desc = self.batch_desc.contiguous()
+        P.num_tile_batches = self.batch_desc.shape[0]
+        P.tile_batches = self.batch_desc.data_ptr()   # host memory, kept alive by self
         P.num_tiles = self.tile_desc.shape[0]
         P.num_segments = self.num_segments
         return P
 
 
-def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=None):
+def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=None, num_batches=1, later_scale=1.0):
     """Block-sparse Schur work list (device, torch ops; structure is fixed for the whole solve).
 
     A *segment* is the run of one point's observations that falls into one group of `group`
@@ -129,13 +141,22 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     workgroups ("chunks", off-diagonal tiles first), workgroup j taking the sub-chunks j, j+J, ... of SUB entries (kSub in ba.hip).
     Returns (chunk_desc (n,6) int32 = gI,gJ,tile_begin,tile_end,j,J ; entries (E,4) int32 = point,segA,segB,maskA|maskB<<16 ;
     tile_desc (T,4) int32 = gI,gJ,chunk_begin,chunk_end ; obs_slot (O,) int32 = segment*16 + camera%16 ;
-    number of segments)."""
+    number of segments ; batch_desc (B,6) int32 ON THE HOST).
+
+    Batches: the tiles are cut into `num_batches` runs of consecutive camera groups gI with about equal entry
+    counts (batch-major order: inside a batch the off-diagonal tiles, then the diagonal ones).  Column block g of
+    the reduced system only receives sums from tiles with gI <= g, so it is complete once the batches up to the one
+    of group g are done -- which lets the factorisation start on the first batch while the later ones are still
+    being computed.  batch_desc row = (chunk_begin, first_diagonal_chunk, chunk_end, tile_begin, tile_end,
+    first_camera_group).  `later_scale` shrinks the workgroup caps of the batches after the first (they run on a
+    CU-masked stream beside the factorisation)."""
     dev = obs_cam.device
     O = obs_cam.shape[0]
     P = row_ptr.shape[0] - 1
     if O == 0:
         z = torch.zeros((0, 4), dtype=torch.int32, device=dev)
-        return torch.zeros((0, 6), dtype=torch.int32, device=dev), z, z.clone(), torch.zeros(0, dtype=torch.int32, device=dev), 0
+        return (torch.zeros((0, 6), dtype=torch.int32, device=dev), z, z.clone(), torch.zeros(0, dtype=torch.int32, device=dev), 0,
+                torch.zeros((1, 6), dtype=torch.int32))
     counts = (row_ptr[1:] - row_ptr[:-1]).long()
     obs_pt = torch.repeat_interleave(torch.arange(P, device=dev), counts)
     grp = (obs_cam // group).long()
@@ -157,32 +178,43 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     A = torch.repeat_interleave(idx, npair)
     pair_start = torch.cumsum(npair, 0) - npair
     B = A + (torch.arange(total, device=dev) - pair_start[A])
-    # tile key: off-diagonal tiles first, then the diagonal ones (they are separate launches)
-    key = seg_grp[A] * ngroups + seg_grp[B] + (seg_grp[A] == seg_grp[B]).long() * (ngroups * ngroups)
+    # batch of a camera group: runs of consecutive groups gI with about equal numbers of entries
+    gA, gB = seg_grp[A], seg_grp[B]
+    per_group = torch.bincount(gA, minlength=ngroups).double()
+    nb = max(1, min(int(num_batches), ngroups))
+    cum = torch.cumsum(per_group, 0) - per_group                    # entries before group g
+    batch_of_group = torch.clamp((cum * nb / max(float(per_group.sum().item()), 1.0)).long(), max=nb - 1)
+    batch_of_group = torch.cummax(batch_of_group, 0).values
+    # tile key: batch-major; inside a batch the off-diagonal tiles first, then the diagonal ones (separate launches)
+    nn = ngroups * ngroups
+    key = batch_of_group[gA] * (2 * nn) + (gA == gB).long() * nn + gA * ngroups + gB
     order = torch.argsort(key, stable=True)
     A, B, key = A[order], B[order], key[order]
     entries = torch.stack([seg_pt[A], A, B, seg_mask[A] | (seg_mask[B] << 16)], 1).to(torch.int32)
     ukeys, kcounts = torch.unique_consecutive(key, return_counts=True)
     tile_start = torch.cumsum(kcounts, 0) - kcounts
-    is_diag = ukeys >= ngroups * ngroups
-    ukeys = ukeys % (ngroups * ngroups)
+    tbatch = ukeys // (2 * nn)
+    is_diag = (ukeys % (2 * nn)) >= nn
+    ukeys = ukeys % nn
     csize = torch.full_like(kcounts, chunk)
     if max_chunks is not None:
         # one resident round per launch: the smallest chunk size (multiple of SUB, >= MIN_CHUNK) whose workgroup
         # count fits the device (CUs x workgroups per CU), so no workgroup starts late and runs alone on its CU
         caps = max_chunks if isinstance(max_chunks, (tuple, list)) else (max_chunks, max_chunks)
-        for sel, max_chunks in ((~is_diag, caps[0]), (is_diag, caps[1])):
-            if not bool(sel.any()):
-                continue
-            kc = kcounts[sel]
-            lo, hi = MIN_CHUNK // SUB, max(MIN_CHUNK // SUB, int(-(-int(kc.max().item()) // SUB)))
-            fits = lambda c: int(((kc + c * SUB - 1) // (c * SUB)).sum().item()) <= max_chunks
-            if not fits(hi):
-                lo = hi                             # more tiles than slots: one workgroup per tile
-            while lo < hi:
-                mid = (lo + hi) // 2
-                lo, hi = (lo, mid) if fits(mid) else (mid + 1, hi)
-            csize[sel] = lo * SUB
+        for b in range(nb):
+            scale = 1.0 if b == 0 else later_scale
+            for sel, cap in ((~is_diag & (tbatch == b), int(caps[0] * scale)), (is_diag & (tbatch == b), int(caps[1] * scale))):
+                if not bool(sel.any()):
+                    continue
+                kc = kcounts[sel]
+                lo, hi = MIN_CHUNK // SUB, max(MIN_CHUNK // SUB, int(-(-int(kc.max().item()) // SUB)))
+                fits = lambda c: int(((kc + c * SUB - 1) // (c * SUB)).sum().item()) <= cap
+                if not fits(hi):
+                    lo = hi                         # more tiles than slots: one workgroup per tile
+                while lo < hi:
+                    mid = (lo + hi) // 2
+                    lo, hi = (lo, mid) if fits(mid) else (mid + 1, hi)
+                csize[sel] = lo * SUB
     nchunks = (kcounts + csize - 1) // csize
     ctile = torch.repeat_interleave(torch.arange(ukeys.shape[0], device=dev), nchunks)
     cfirst = torch.cumsum(nchunks, 0) - nchunks
@@ -191,14 +223,33 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
                               tile_start[ctile] + kcounts[ctile], local, nchunks[ctile]], 1).to(torch.int32)
     tile_desc = torch.stack([ukeys // ngroups, ukeys % ngroups, cfirst, cfirst + nchunks], 1).to(torch.int32)
     obs_slot = (seg_id * group + obs_cam.long() % group).to(torch.int32)
-    return chunk_desc.contiguous(), entries.contiguous(), tile_desc.contiguous(), obs_slot.contiguous(), int(nseg)
+    # host-side batch table
+    tb, td, tn, tf = tbatch.cpu(), is_diag.cpu(), nchunks.cpu(), cfirst.cpu()
+    tg = (ukeys // ngroups).cpu()
+    batch_desc = torch.zeros((nb, 6), dtype=torch.int32)
+    for b in range(nb):
+        ids = torch.nonzero(tb == b).squeeze(1)
+        if ids.numel() == 0:                        # (cannot happen for b = 0; later batches may be empty)
+            prev = int(batch_desc[b - 1, 2]) if b else 0
+            prevt = int(batch_desc[b - 1, 4]) if b else 0
+            batch_desc[b] = torch.tensor([prev, prev, prev, prevt, prevt, ngroups])
+            continue
+        c0 = int(tf[ids[0]])
+        c1 = int(tf[ids[-1]] + tn[ids[-1]])
+        dg = ids[td[ids]]
+        cm = int(tf[dg[0]]) if dg.numel() else c1
+        batch_desc[b] = torch.tensor([c0, cm, c1, int(ids[0]), int(ids[-1]) + 1, int(tg[ids].min())])
+    return (chunk_desc.contiguous(), entries.contiguous(), tile_desc.contiguous(), obs_slot.contiguous(), int(nseg),
+            batch_desc.contiguous())
 
 
 def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_params=None, shared_camera=False,
                     camera_type="SIMPLE_PINHOLE", max_points3D_val=3000, filter_negative_depth=True,
-                    gauge="colmap"):
+                    gauge="colmap", overlap=None):
     """tensors (reference layout, on the GPU) -> DeviceProblem + bookkeeping.
-    Returns (problem, valid_idx (P',) long, deleted (P',) bool)."""
+    Returns (problem, valid_idx (P',) long, deleted (P',) bool).
+    overlap: cut the Schur tiles into TILE_BATCHES batches so that a single-GPU solve can factorise beside the later
+    ones (default OVERLAP_FACTORIZATION; pass False for a multi-GPU shard, whose system is all-reduced first)."""
     if camera_type not in MODEL_ID:
         raise ValueError(f"Camera type {camera_type} is not supported yet")
     dev = tracks.device
@@ -254,9 +305,14 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
     # resident schur_tile workgroups per CU (occupancy of the kernel variant): off-diagonal launch 3 (BD = 6) or 2,
     # diagonal launch 4 or 2 -- one full round each
     slots = (cus * 3, cus * 4) if shared_camera else (cus * 2, cus * 2)
-    chunk_desc, entries, tile_desc, obs_slot, nseg = build_schur_tiles(row_ptr, obs_cam, max_chunks=slots)
+    # three batches when the factorisation can overlap the later ones (enough camera groups, enough work per batch)
+    overlap = OVERLAP_FACTORIZATION if overlap is None else bool(overlap)
+    nb = TILE_BATCHES if (overlap and int(obs_cam.shape[0]) >= OVERLAP_MIN_OBS and S >= OVERLAP_MIN_FRAMES) else 1
+    chunk_desc, entries, tile_desc, obs_slot, nseg, batch_desc = build_schur_tiles(
+        row_ptr, obs_cam, max_chunks=slots, num_batches=nb, later_scale=(cus - CHOL_CUS) / cus)
     prob = DeviceProblem(cam_q, cam_t, intr, pts, row_ptr, obs_cam, obs_uv, col_ptr, cobs_pt, cobs_uv, chunk_desc,
-                         entries, tile_desc, obs_slot, nseg, MODEL_ID[camera_type], cam_const=cam_const)
+                         entries, tile_desc, obs_slot, nseg, MODEL_ID[camera_type], cam_const=cam_const,
+                         batch_desc=batch_desc)
     return prob, valid_idx, deleted
 
 
@@ -277,12 +333,13 @@ def window_bundle_adjustment(points3d, extrinsics, intrinsics, tracks, masks, nu
                              filter_negative_depth=False)
 
 
-def _c_options(options: BundleAdjustmentOptions):
+def _c_options(options: BundleAdjustmentOptions, overlap=True):
     so = options.solver_options
     return _lib.BAOptions(so.max_num_iterations, so.max_num_consecutive_invalid_steps, int(so.jacobi_scaling),
                           so.function_tolerance, so.gradient_tolerance, so.parameter_tolerance,
                           so.initial_trust_region_radius, so.max_trust_region_radius, so.min_trust_region_radius,
-                          so.min_lm_diagonal, so.max_lm_diagonal, so.min_relative_decrease)
+                          so.min_lm_diagonal, so.max_lm_diagonal, so.min_relative_decrease,
+                          CHOL_CUS if (overlap and OVERLAP_FACTORIZATION) else 0)
 
 
 def _summary_dict(summ, log, n):

@@ -30,7 +30,7 @@
 namespace vgg {
 
 int cholesky_solve_enqueue(double* A, double* b, int n, double* inv_blocks, int32_t* device_fail, const int32_t* skip_flag,
-                           hipStream_t st);
+                           hipStream_t st, const CholOverlap* overlap);
 size_t cholesky_workspace_bytes(int n);
 
 constexpr int kGroup = 16;       // cameras per Schur tile side
@@ -75,6 +75,7 @@ struct Ws {  // device workspace carve-up (pointers into the caller's buffer)
   double *U, *g, *costc;
   double* sys;                // reduce buffer 1: S[n*n] | rhs[n]
   double *S, *rhs;
+  double* S2;                 // [n*n] sums of the tile batches that are computed while the factorisation runs (overlap mode)
   double* gmax_pts;           // reduce buffer 2 (MAX): 1 double (padded to 8)
   double* stepsum;            // reduce buffer 3: cost, mcc, step_sq, xnorm_sq  (padded to 8)
   double *G, *hs, *Ms;        // per point: 6, 3, 3*kdsh
@@ -126,6 +127,7 @@ static Ws carve(const Dims& d, int max_iters, int num_chunks, int num_segments, 
   w.sys_count = (size_t)d.n_red * d.n_red + d.n_red;
   w.sys = (double*)take(8ull * w.sys_count);
   w.S = w.sys; w.rhs = w.S + (size_t)d.n_red * d.n_red;
+  w.S2 = (double*)take(8ull * (size_t)d.n_red * d.n_red);
   w.packed_count = (size_t)d.n_red * (d.n_red + 1) / 2 + d.n_red;
   w.packed = (double*)take(8ull * w.packed_count);
   w.gmax_pts = (double*)take(64);
@@ -877,11 +879,13 @@ __global__ __launch_bounds__(256, (BD == 6 ? (DIAG ? 4 : VGG_OFFDIAG_OCC) : 2)) 
 // grid = (R*R/256, num_tiles): one element per thread, chunks summed in order.
 template <int BD>
 __global__ __launch_bounds__(256) void tile_reduce_kernel(Ws w, int n_red, int C, int KD,
-                                                          const int32_t* __restrict__ tile_desc) {
+                                                          const int32_t* __restrict__ tile_desc, int tile0,
+                                                          double* __restrict__ dst) {
   constexpr int R = kGroup * BD;
   if (w.ctl->done) return;
-  const int gI = tile_desc[4 * blockIdx.y], gJ = tile_desc[4 * blockIdx.y + 1];
-  const int c0 = tile_desc[4 * blockIdx.y + 2], c1 = tile_desc[4 * blockIdx.y + 3];
+  const int tile = tile0 + blockIdx.y;
+  const int gI = tile_desc[4 * tile], gJ = tile_desc[4 * tile + 1];
+  const int c0 = tile_desc[4 * tile + 2], c1 = tile_desc[4 * tile + 3];
   const int n = n_red;
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= R * R) return;
@@ -897,7 +901,7 @@ __global__ __launch_bounds__(256) void tile_reduce_kernel(Ws w, int n_red, int C
   for (; ch + 1 < c1; ch += 2) { s0 += w.tile_part[(size_t)ch * R * R + e]; s1 += w.tile_part[(size_t)(ch + 1) * R * R + e]; }
   if (ch < c1) s0 += w.tile_part[(size_t)ch * R * R + e];
   const int hi = ri > cj ? ri : cj, lo = ri > cj ? cj : ri;
-  w.S[(size_t)hi * n + lo] = -(s0 + s1);
+  dst[(size_t)hi * n + lo] = -(s0 + s1);
 }
 
 // diagonal blocks, camera/intrinsics coupling, damping, right-hand side.  One workgroup (64) per camera,
@@ -1270,8 +1274,9 @@ struct ProfScope {
 
 struct Launch {
   Dims d; DevProblem dp; Ws w; vgg_ba_options opt; hipStream_t st; int wgB;
-  const int32_t* chunk_desc; const int32_t* entries; int num_chunks, num_offdiag_chunks, num_segments;
+  const int32_t* chunk_desc; const int32_t* entries; int num_chunks, num_segments;
   const int32_t* tile_desc; int num_tiles;
+  const int32_t* batches; int num_batches;      // HOST table [num_batches][6], see vgg_ba_problem.tile_batches
   double *cam_q, *cam_t, *intr, *pts;
 };
 
@@ -1303,17 +1308,68 @@ static void phase_linearize(const Launch& L) {
   cam_reduce_kernel<KD, 0><<<L.d.C, 64, 0, L.st>>>(L.dp, L.w, split);
 }
 
+// one batch of Schur tiles: the off-diagonal launch, the diagonal launch, and the ordered sum of their chunks into
+// dst (S, or S2 for a batch that runs beside the factorisation)
 template <int BD>
-static void launch_schur_tiles(const Launch& L) {
-  const int noff = L.num_offdiag_chunks, ndiag = L.num_chunks - noff;
-  if (noff > 0) {
-    ProfScope ps(kProfSchurTile, L.st);
-    schur_tile_kernel<BD, false><<<noff, 256, 0, L.st>>>(L.w, L.chunk_desc, L.entries, 0, L.num_segments);
+static void launch_schur_batch(const Launch& L, int batch, hipStream_t st, double* dst) {
+  const int32_t* B = L.batches + 6 * batch;
+  const int c0 = B[0], cm = B[1], c1 = B[2], t0 = B[3], t1 = B[4];
+  if (cm > c0) {
+    ProfScope ps(kProfSchurTile, st);
+    schur_tile_kernel<BD, false><<<cm - c0, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, c0, L.num_segments);
   }
-  if (ndiag > 0) {
-    ProfScope ps(kProfSchurTileDiag, L.st);
-    schur_tile_kernel<BD, true><<<ndiag, 256, 0, L.st>>>(L.w, L.chunk_desc, L.entries, noff, L.num_segments);
+  if (c1 > cm) {
+    ProfScope ps(kProfSchurTileDiag, st);
+    schur_tile_kernel<BD, true><<<c1 - cm, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, cm, L.num_segments);
   }
+  if (t1 > t0)
+    tile_reduce_kernel<BD><<<dim3(div_up(kGroup * BD * kGroup * BD, 256), t1 - t0), 256, 0, st>>>(L.w, L.d.n_red, L.d.C, L.d.kd,
+                                                                                                  L.tile_desc, t0, dst);
+}
+
+template <int KD>
+static void launch_schur_batches(const Launch& L, int b0, int b1, hipStream_t st, double* dst, hipEvent_t* done_events) {
+  for (int b = b0; b < b1; ++b) {
+    if (L.d.shared || KD == 0) launch_schur_batch<6>(L, b, st, dst);
+    else launch_schur_batch<6 + KD>(L, b, st, dst);
+    if (done_events) (void)hipEventRecord(done_events[b], st);
+  }
+}
+
+// Overlap mode (options.overlap_factorization = number of CUs given to the factorisation, a multiple of 32; >= 2
+// tile batches): two CU-masked streams split the chip while batches 1.. and the factorisation run side by side.
+// Without the masks the two only overlap by accident (the tile launches fill every CU); see DESIGN.md section 6.
+struct OverlapCtx {
+  int chol_cus = 0;
+  hipStream_t st_chol = nullptr, st_rest = nullptr;
+  hipEvent_t ready = nullptr, chol_done = nullptr, batch_done[8] = {};
+};
+static OverlapCtx* overlap_ctx(const Launch& L) {
+  static OverlapCtx ctx[16];
+  static bool failed[16] = {};
+  const int cus = L.opt.overlap_factorization;
+  if (cus <= 0 || cus % 32 != 0 || L.num_batches < 2 || L.num_batches > 8 || L.num_chunks <= 0) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || failed[dev]) return nullptr;
+  OverlapCtx& c = ctx[dev];
+  if (c.chol_cus == cus) return &c;
+  if (c.chol_cus != 0) return nullptr;             // one split per process
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= cus || prop.multiProcessorCount % 32 != 0) {
+    failed[dev] = true; return nullptr;
+  }
+  const int words = prop.multiProcessorCount / 32, cw = cus / 32;
+  uint32_t mask_chol[16] = {}, mask_rest[16] = {};
+  if (words > 16) { failed[dev] = true; return nullptr; }
+  for (int i = 0; i < words; ++i) { mask_chol[i] = (i < cw) ? 0xFFFFFFFFu : 0u; mask_rest[i] = (i < cw) ? 0u : 0xFFFFFFFFu; }
+  bool ok = hipExtStreamCreateWithCUMask(&c.st_chol, words, mask_chol) == hipSuccess &&
+            hipExtStreamCreateWithCUMask(&c.st_rest, words, mask_rest) == hipSuccess &&
+            hipEventCreateWithFlags(&c.ready, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&c.chol_done, hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; ok && i < 8; ++i) ok = hipEventCreateWithFlags(&c.batch_done[i], hipEventDisableTiming) == hipSuccess;
+  if (!ok) { (void)hipGetLastError(); failed[dev] = true; return nullptr; }
+  c.chol_cus = cus;
+  return &c;
 }
 
 template <int KD>
@@ -1337,12 +1393,12 @@ static void phase_schur(const Launch& L) {
   }
   (void)hipMemsetAsync(L.w.sys, 0, sizeof(double) * L.w.sys_count, L.st);
   if (L.num_chunks > 0) {
-    if (d.shared || KD == 0) {
-      launch_schur_tiles<6>(L);
-      tile_reduce_kernel<6><<<dim3(96 * 96 / 256, L.num_tiles), 256, 0, L.st>>>(L.w, d.n_red, d.C, KD, L.tile_desc);
+    if (overlap_ctx(L)) {
+      // only the first batch here; the others are enqueued by phase_step beside the factorisation and land in S2
+      (void)hipMemsetAsync(L.w.S2, 0, sizeof(double) * (size_t)d.n_red * d.n_red, L.st);
+      launch_schur_batches<KD>(L, 0, 1, L.st, L.w.S, nullptr);
     } else {
-      launch_schur_tiles<6 + KD>(L);
-      tile_reduce_kernel<6 + KD><<<dim3(div_up(16 * (6 + KD) * 16 * (6 + KD), 256), L.num_tiles), 256, 0, L.st>>>(L.w, d.n_red, d.C, KD, L.tile_desc);
+      launch_schur_batches<KD>(L, 0, L.num_batches, L.st, L.w.S, nullptr);
     }
   }
   assemble_kernel<KD><<<d.C + 1, 64, 0, L.st>>>(L.dp, L.w);
@@ -1354,9 +1410,28 @@ static int phase_step(const Launch& L) {
   begin_iteration_kernel<<<1, 1, 0, L.st>>>(L.w, L.opt);
   fix_constant_kernel<<<div_up(d.n_red, 256), 256, 0, L.st>>>(L.w, d.n_red);
   int rc;
-  {
+  if (OverlapCtx* oc = overlap_ctx(L)) {
+    (void)hipEventRecord(oc->ready, L.st);
+    (void)hipStreamWaitEvent(oc->st_rest, oc->ready, 0);
+    (void)hipStreamWaitEvent(oc->st_chol, oc->ready, 0);
+    launch_schur_batches<KD>(L, 1, L.num_batches, oc->st_rest, L.w.S2, oc->batch_done);
+    CholOverlap ov;
+    ov.S2 = L.w.S2;
+    ov.first_col = 6 * kGroup * L.batches[6 * 1 + 5];
+    ov.num_waits = L.num_batches - 1;
+    for (int b = 1; b < L.num_batches; ++b) {
+      ov.wait_col[b - 1] = 6 * kGroup * L.batches[6 * b + 5];
+      ov.wait_ev[b - 1] = oc->batch_done[b];
+    }
+    {
+      ProfScope ps(kProfCholesky, oc->st_chol);
+      rc = cholesky_solve_enqueue(L.w.S, L.w.rhs, d.n_red, L.w.chol_inv, &L.w.ctl->linear_fail, &L.w.ctl->done, oc->st_chol, &ov);
+    }
+    (void)hipEventRecord(oc->chol_done, oc->st_chol);
+    (void)hipStreamWaitEvent(L.st, oc->chol_done, 0);
+  } else {
     ProfScope ps(kProfCholesky, L.st);
-    rc = cholesky_solve_enqueue(L.w.S, L.w.rhs, d.n_red, L.w.chol_inv, &L.w.ctl->linear_fail, &L.w.ctl->done, L.st);
+    rc = cholesky_solve_enqueue(L.w.S, L.w.rhs, d.n_red, L.w.chol_inv, &L.w.ctl->linear_fail, &L.w.ctl->done, L.st, nullptr);
   }
   if (rc != VGG_OK) return rc;
   cam_update_kernel<KD><<<div_up(d.C + 1, 64), 64, 0, L.st>>>(L.dp, L.w);
@@ -1392,9 +1467,18 @@ static int make_launch(const vgg_ba_problem* pb, const vgg_ba_options* opt, void
   L->st = st;
   L->wgB = min(max(div_up(L->d.P, 4), 1), kMaxWG);
   L->chunk_desc = pb->chunk_desc; L->entries = pb->entries; L->num_chunks = pb->num_chunks;
-  L->num_offdiag_chunks = pb->num_offdiag_chunks;
   L->num_segments = pb->num_segments;
-  if (pb->num_offdiag_chunks < 0 || pb->num_offdiag_chunks > pb->num_chunks) return VGG_ERR_INVALID_ARGUMENT;
+  L->batches = pb->tile_batches; L->num_batches = pb->num_tile_batches;
+  if (pb->num_chunks > 0) {
+    if (!pb->tile_batches || pb->num_tile_batches < 1) return VGG_ERR_INVALID_ARGUMENT;
+    int prev_c = 0, prev_t = 0, prev_g = 0;
+    for (int b = 0; b < pb->num_tile_batches; ++b) {   // consecutive, ordered ranges
+      const int32_t* B = pb->tile_batches + 6 * b;
+      if (B[0] != prev_c || B[1] < B[0] || B[2] < B[1] || B[3] != prev_t || B[4] < B[3] || B[5] < prev_g) return VGG_ERR_INVALID_ARGUMENT;
+      prev_c = B[2]; prev_t = B[4]; prev_g = B[5];
+    }
+    if (prev_c != pb->num_chunks || prev_t != pb->num_tiles) return VGG_ERR_INVALID_ARGUMENT;
+  }
   L->tile_desc = pb->tile_desc; L->num_tiles = pb->num_tiles;
   L->cam_q = pb->cam_q; L->cam_t = pb->cam_t; L->intr = pb->intr; L->pts = pb->pts;
   return VGG_OK;

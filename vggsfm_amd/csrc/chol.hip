@@ -94,7 +94,8 @@ __device__ __forceinline__ void substitute_row(double (&x)[NB], const double* D,
 template <int NB>
 __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A, int n, int nrows, int k0,
                                                          int32_t* fail, const int32_t* skip,
-                                                         double* __restrict__ inv_blocks) {
+                                                         double* __restrict__ inv_blocks,
+                                                         const double* __restrict__ S2) {
   constexpr int LD = NB + 1;
   __shared__ double D[NB * LD];
   __shared__ double rdiag[NB];
@@ -110,13 +111,19 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
     const double* Arow = A + (size_t)row * n + k0;
 #pragma unroll
     for (int c = 0; c < NB; ++c) x[c] = Arow[c];   // unconditional: all NB loads in flight at once
+    if (S2 && row < n) {                           // lazily added overlapped-batch contributions (see panel2)
+      const double* Srow = S2 + (size_t)row * n + k0;
+#pragma unroll
+      for (int c = 0; c < NB; ++c) x[c] += Srow[c];
+    }
   } else {
 #pragma unroll
     for (int c = 0; c < NB; ++c) x[c] = (extra_wg && c == tid) ? 1.0 : 0.0;
   }
   for (int e = tid; e < NB * NB; e += 256) {
     const int i = e / NB, c = e % NB;
-    D[i * LD + c] = (i < nb && c <= i) ? A[(size_t)(k0 + i) * n + k0 + c] : ((i == c) ? 1.0 : 0.0);
+    const size_t o = (size_t)(k0 + i) * n + k0 + c;
+    D[i * LD + c] = (i < nb && c <= i) ? A[o] + (S2 ? S2[o] : 0.0) : ((i == c) ? 1.0 : 0.0);
   }
   factor_diag_lds<NB>(D, rdiag, (blockIdx.x == 0) ? fail : nullptr);
   if (blockIdx.x == 0) {
@@ -158,7 +165,8 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
 // wavefront 0 owns 64 panel rows (one per lane, 64 registers), wavefront 1 solves the 32 rows of L21.
 __global__ __launch_bounds__(256) void chol_panel2_kernel(double* __restrict__ A, int n, int nrows, int k0,
                                                           int32_t* fail, const int32_t* skip,
-                                                          double* __restrict__ inv_blocks) {
+                                                          double* __restrict__ inv_blocks,
+                                                          const double* __restrict__ S2) {
   constexpr int NB = 32, LD = NB + 1;
   __shared__ double D1[NB * LD], D2[NB * LD], L21[NB * LD];
   __shared__ double rd1[NB], rd2[NB];
@@ -168,14 +176,27 @@ __global__ __launch_bounds__(256) void chol_panel2_kernel(double* __restrict__ A
   const int row = k0 + 2 * NB + blockIdx.x * 64 + lane;
   const bool has_row = !extra_wg && wave == 0 && row < nrows;
   double x[2 * NB];                               // wave 0: the panel row; wave 1 (lanes < 32): row of B21 in x[0..31]
+  // S2 (optional, n x n, same layout): contributions to these 64 columns that were computed while earlier columns
+  // were being factored (overlapped Schur tile batches); they are added when the columns become the panel.  The
+  // appended rhs row (row n) has no S2 row.
   if (has_row) {
     const double* Arow = A + (size_t)row * n + k0;
 #pragma unroll
     for (int c = 0; c < 2 * NB; ++c) x[c] = Arow[c];
+    if (S2 && row < n) {
+      const double* Srow = S2 + (size_t)row * n + k0;
+#pragma unroll
+      for (int c = 0; c < 2 * NB; ++c) x[c] += Srow[c];
+    }
   } else if (wave == 1 && lane < NB) {
     const double* Arow = A + (size_t)(k0 + NB + lane) * n + k0;
 #pragma unroll
     for (int c = 0; c < NB; ++c) x[c] = Arow[c];
+    if (S2) {
+      const double* Srow = S2 + (size_t)(k0 + NB + lane) * n + k0;
+#pragma unroll
+      for (int c = 0; c < NB; ++c) x[c] += Srow[c];
+    }
 #pragma unroll
     for (int c = NB; c < 2 * NB; ++c) x[c] = 0.0;
   } else {
@@ -184,8 +205,9 @@ __global__ __launch_bounds__(256) void chol_panel2_kernel(double* __restrict__ A
   }
   for (int e = tid; e < NB * NB; e += 256) {
     const int i = e / NB, c = e % NB;
-    D1[i * LD + c] = (c <= i) ? A[(size_t)(k0 + i) * n + k0 + c] : 0.0;
-    D2[i * LD + c] = (c <= i) ? A[(size_t)(k0 + NB + i) * n + k0 + NB + c] : 0.0;
+    const size_t o1 = (size_t)(k0 + i) * n + k0 + c, o2 = (size_t)(k0 + NB + i) * n + k0 + NB + c;
+    D1[i * LD + c] = (c <= i) ? A[o1] + (S2 ? S2[o1] : 0.0) : 0.0;
+    D2[i * LD + c] = (c <= i) ? A[o2] + (S2 ? S2[o2] : 0.0) : 0.0;
   }
   factor_diag_lds<NB>(D1, rd1, (blockIdx.x == 0) ? fail : nullptr);
   // first block column: panel rows (wave 0) and the 32 rows of L21 (wave 1) through L11
@@ -477,7 +499,14 @@ size_t cholesky_workspace_bytes(int n) {
 // perform the forward substitution for free and only L^T y = z is left.
 template <int NB>
 static int enqueue(double* A, double* b, int n, double* inv_blocks, int32_t* device_fail, const int32_t* skip,
-                   hipStream_t st) {
+                   hipStream_t st, const CholOverlap* ov) {
+  int next_wait = 0;
+  // before the panel over columns [k0, k1): wait for the producers of those columns; S2 only where it can be non-zero
+  auto panel_s2 = [&](int k1) -> const double* {
+    if (!ov) return nullptr;
+    while (next_wait < ov->num_waits && ov->wait_col[next_wait] < k1) (void)hipStreamWaitEvent(st, ov->wait_ev[next_wait++], 0);
+    return (k1 > ov->first_col) ? ov->S2 : nullptr;
+  };
   const bool fused_rhs = (b == A + (size_t)n * n);
   const int nrows = fused_rhs ? n + 1 : n;
   // fast backward solve: y and one T block in LDS (up to 150 KB); larger systems use the single-workgroup kernel
@@ -493,8 +522,9 @@ static int enqueue(double* A, double* b, int n, double* inv_blocks, int32_t* dev
     // fused double steps: 64 columns per (panel2, update<64>) pair while at least 64 columns remain
     for (; k0 + 64 <= n; k0 += 64) {
       const int rows_panel = nrows - k0 - 64;
+      const double* S2 = panel_s2(k0 + 64);
       chol_panel2_kernel<<<(rows_panel > 0 ? div_up(rows_panel, 64) : 1) + 1, 256, 0, st>>>(A, n, nrows, k0, device_fail,
-                                                                                           skip, inv_blocks);
+                                                                                           skip, inv_blocks, S2);
       if (rows_panel > 0 && k0 + 64 < n) {
         const int T = div_up(rows_panel, 32);
         const int tiles = T * (T + 1) / 2;
@@ -506,7 +536,8 @@ static int enqueue(double* A, double* b, int n, double* inv_blocks, int32_t* dev
     const int nb = (n - k0 < NB) ? n - k0 : NB;
     const int rows_panel = nrows - k0 - nb;
     const int grid = (rows_panel > 0 ? div_up(rows_panel, 256) : 1) + 1;
-    chol_panel_kernel<NB><<<grid, 256, 0, st>>>(A, n, nrows, k0, device_fail, skip, inv_blocks);
+    const double* S2 = panel_s2(k0 + nb);
+    chol_panel_kernel<NB><<<grid, 256, 0, st>>>(A, n, nrows, k0, device_fail, skip, inv_blocks, S2);
     const int rows_below = nrows - k0 - NB;
     if (rows_below > 0 && k0 + NB < n) {
       const int T = div_up(rows_below, 32);
@@ -514,6 +545,7 @@ static int enqueue(double* A, double* b, int n, double* inv_blocks, int32_t* dev
       chol_update_kernel<NB><<<div_up(tiles, 4), 256, 0, st>>>(A, n, nrows, k0, tiles, skip);
     }
   }
+  (void)panel_s2(n + 1);                        // (n == 0 cannot happen; every producer is waited for by now)
   if (!fused_rhs) chol_solve_kernel<NB><<<1, 256, 0, st>>>(A, b, n, 1, lds_backward ? 0 : 1, skip);
   else if (!lds_backward) chol_solve_kernel<NB><<<1, 256, 0, st>>>(A, b, n, 0, 1, skip);
   if (lds_backward) chol_backward_kernel<NB><<<1, kBackThreads, back_lds, st>>>(A, b, n, inv_blocks, skip);
@@ -522,9 +554,9 @@ static int enqueue(double* A, double* b, int n, double* inv_blocks, int32_t* dev
 }
 
 int cholesky_solve_enqueue(double* A, double* b, int n, double* inv_blocks, int32_t* device_fail, const int32_t* skip,
-                           hipStream_t st) {
+                           hipStream_t st, const CholOverlap* overlap) {
   if (!inv_blocks) return VGG_ERR_INVALID_ARGUMENT;
-  return enqueue<32>(A, b, n, inv_blocks, device_fail, skip, st);
+  return enqueue<32>(A, b, n, inv_blocks, device_fail, skip, st, overlap);
 }
 
 }  // namespace vgg
@@ -534,6 +566,6 @@ size_t vgg_cholesky_workspace_bytes(int n) { return n > 0 ? vgg::cholesky_worksp
 
 int vgg_cholesky_solve(double* A, double* b, int n, void* workspace, int32_t* device_fail, void* stream) {
   if (n <= 0 || !A || !b || !workspace) return VGG_ERR_INVALID_ARGUMENT;
-  return vgg::cholesky_solve_enqueue(A, b, n, (double*)workspace, device_fail, nullptr, (hipStream_t)stream);
+  return vgg::cholesky_solve_enqueue(A, b, n, (double*)workspace, device_fail, nullptr, (hipStream_t)stream, nullptr);
 }
 }

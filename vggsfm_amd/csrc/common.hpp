@@ -50,4 +50,16 @@ __device__ __forceinline__ double load_f64(const T* p) { return (double)(*p); }
 
 inline int div_up(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Overlap of the factorisation with the computation of the reduced system (ba.hip <-> chol.hip): contributions to
+// columns >= first_col arrive in a second matrix S2 (same n x n layout) from work running on another stream; event k
+// signals that every contribution to columns >= wait_col[k] (ascending) is in place.  The factorisation waits for
+// event k before the first panel that touches such a column and adds S2 to the panel when it loads it.
+struct CholOverlap {
+  const double* S2;
+  int first_col;
+  int num_waits;
+  int wait_col[8];
+  hipEvent_t wait_ev[8];
+};
+
 }  // namespace vgg

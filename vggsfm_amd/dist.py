@@ -62,7 +62,7 @@ class ShardedBA:
         problem.loss_scale = self.options.loss_function_scale
         self.rank, self.world = rank, world_size
         self.cp = problem.c_struct()
-        self.co = BA._c_options(self.options)
+        self.co = BA._c_options(self.options, overlap=(world_size == 1))
         nbytes = int(self.L.vgg_ba_workspace_bytes(ctypes.byref(self.cp), ctypes.byref(self.co)))
         self.nbytes = nbytes
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=problem.pts.device)

@@ -16,7 +16,7 @@ from .ba_options import LOSS_ID, AbsolutePoseRefinementOptions
 def _options(refopts: AbsolutePoseRefinementOptions):
     # RefineAbsolutePose: Ceres defaults + COLMAP's gradient_tolerance / max_num_iterations
     return _lib.BAOptions(refopts.max_num_iterations, 10, 1, 1e-6, refopts.gradient_tolerance, 1e-8,
-                          1e4, 1e16, 1e-32, 1e-6, 1e32, 1e-3)
+                          1e4, 1e16, 1e-32, 1e-6, 1e32, 1e-3, 0)
 
 
 def pose_refinement_batch(extrinsics, intr_params, points2D, points3D, inlier_mask, frame_ids, camera_type,

@@ -216,6 +216,28 @@ int vgg_pose_refine(const double* points3D, const void* tracks, int tracks_are_f
                     int camera_model, const uint8_t* refine_flags, const vgg_ba_options* options, int loss,
                     double loss_scale, vgg_ba_summary* summaries, void* stream);
 
+/* pycolmap.absolute_pose_estimation, the RANSAC part   vggsfm/utils/triangulation.py:324-326,400-432 (fallback of
+ * refine_pose), vggsfm/runners/video_runner.py:987-998 (align_next_window, use_pnp)
+ * = COLMAP EstimateAbsolutePose restated (third-party, absent from the reference tree; PARITY UNPINNED, see
+ * oracle/p3p.py): P3P minimal samples, squared reprojection error on the normalised image plane, points with
+ * depth <= 0 never inliers, support = (most inliers, then smallest inlier residual sum, then lowest index).
+ * Deviations: the caller draws a fixed number of samples (no adaptive trial count), no EPnP step inside the loop;
+ * the caller runs vgg_pose_refine on the returned inliers afterwards, as COLMAP does.
+ * All num_frames (virtual) frames run concurrently.  A virtual frame is (frame, focal length factor): COLMAP's
+ * estimate_focal_length runs one RANSAC per factor -- the caller passes the points normalised with each scaled
+ * camera, frames_per_sample_set consecutive virtual frames share one sample set.
+ *   points2D_normalized [num_frames][num_points][2] f64, points3D [num_points][3] f64,
+ *   candidate_mask [num_frames][num_points] uint8 or NULL (matches that take part), samples
+ *   [num_frames / frames_per_sample_set][num_hypotheses][3] int32 indices into num_points (distinct, candidates),
+ *   max_error_sq [num_frames] f64 (squared threshold on the normalised plane = (max_error / focal)^2).
+ * Outputs per virtual frame: out_pose [12] row-major [R|t] (zeros if nothing found), out_num_inliers (0 if nothing
+ * found), out_residual_sum, out_best (hypothesis * 4 + solution, -1 if none), out_inlier_mask [num_points]. */
+size_t vgg_p3p_ransac_workspace_bytes(int num_frames, int num_hypotheses);
+int vgg_p3p_ransac(const double* points2D_normalized, const double* points3D, const uint8_t* candidate_mask,
+                   const int32_t* samples, int num_frames, int frames_per_sample_set, int num_points, int num_hypotheses,
+                   const double* max_error_sq, double* out_pose, int32_t* out_num_inliers, double* out_residual_sum,
+                   int32_t* out_best, uint8_t* out_inlier_mask, void* workspace, void* stream);
+
 /* Optional per-kernel timing (HIP events recorded on the launch stream around the dominant kernels).
  * kernel_id: 0 cam_pass<linearize> 1 point_pass 2 cam_pass<rhs> 3 schur_tile<off-diagonal tiles> 4 cholesky (all
  * launches of one solve) 5 point_step 6 schur_tile<diagonal tiles>.  vgg_ba_profile_read synchronises on the

@@ -60,7 +60,8 @@ EXPORTED = ["vgg_build_arch", "vgg_abi_version", "vgg_project_points", "vgg_filt
             "vgg_triangulate_workspace_bytes", "vgg_triangulate_tracks", "vgg_triangulate_by_pair", "vgg_triangulate_chunks_workspace_bytes",
             "vgg_triangulate_tracks_chunks", "vgg_ba_workspace_bytes", "vgg_ba_solve",
             "vgg_ba_begin", "vgg_ba_phase", "vgg_ba_reduce_buffer", "vgg_ba_finish", "vgg_cholesky_solve",
-            "vgg_ba_profile", "vgg_ba_profile_read", "vgg_cholesky_workspace_bytes", "vgg_pose_refine"]
+            "vgg_ba_profile", "vgg_ba_profile_read", "vgg_cholesky_workspace_bytes", "vgg_pose_refine",
+            "vgg_p3p_ransac_workspace_bytes", "vgg_p3p_ransac"]
 
 _lib = None
 
@@ -82,7 +83,7 @@ def lib():
         raise RuntimeError(f"libvggsfm_amd.so was built for {arch}, expected gfx950")
     for name in ("vgg_filter_points_workspace_bytes", "vgg_cam_from_img_workspace_bytes",
                  "vgg_triangulate_workspace_bytes", "vgg_triangulate_chunks_workspace_bytes", "vgg_ba_workspace_bytes",
-                 "vgg_cholesky_workspace_bytes"):
+                 "vgg_cholesky_workspace_bytes", "vgg_p3p_ransac_workspace_bytes"):
         getattr(L, name).restype = ctypes.c_size_t
     L.vgg_ba_workspace_bytes.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     _lib = L

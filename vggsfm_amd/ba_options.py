@@ -43,6 +43,22 @@ class AbsolutePoseRefinementOptions:
     print_summary: bool = False
 
 
+@dataclass
+class RANSACOptions:
+    max_error: float = 12.0                           # pixels (COLMAP AbsolutePoseEstimationOptions.ransac.max_error default)
+    num_hypotheses: int = 1024                        # device path: fixed number of minimal samples (COLMAP: adaptive, <= 10000)
+
+
+@dataclass
+class AbsolutePoseEstimationOptions:
+    """pycolmap.AbsolutePoseEstimationOptions as the reference sets it (triangulation.py:324-326, video_runner.py:988-989)."""
+    estimate_focal_length: bool = False
+    num_focal_length_samples: int = 30
+    min_focal_length_ratio: float = 0.2
+    max_focal_length_ratio: float = 5.0
+    ransac: RANSACOptions = field(default_factory=RANSACOptions)
+
+
 LOSS_ID = {"TRIVIAL": 0, "CAUCHY": 1, "HUBER": 2, "SOFT_L1": 3}
 TERMINATION = {0: "NO_CONVERGENCE (iteration cap)", 1: "CONVERGENCE (gradient tolerance)",
                2: "CONVERGENCE (function tolerance)", 3: "CONVERGENCE (parameter tolerance)",

@@ -154,8 +154,8 @@ def triangulate_by_pair(extrinsics, tracks_normalized, eps=1e-12):
 # tensors into pycolmap objects with O(S*P) Python loops and back; here everything stays on the device.
 # ==========================================================================================
 from .. import ba as _ba                                    # noqa: E402
-from ..ba_options import AbsolutePoseRefinementOptions, BundleAdjustmentOptions  # noqa: E402
-from ..pose import pose_refinement_batch                    # noqa: E402
+from ..ba_options import AbsolutePoseEstimationOptions, AbsolutePoseRefinementOptions, BundleAdjustmentOptions  # noqa: E402
+from ..pose import absolute_pose_estimation_batch, pose_refinement_batch  # noqa: E402
 from .triangulation_helpers import cam_from_img, filter_all_points3D, prepare_ba_options  # noqa: E402
 
 
@@ -259,8 +259,9 @@ def init_refine_pose(extrinsics, intrinsics, extra_params, inlier, points3D, tra
 def refine_pose(extrinsics, intrinsics, extra_params, inlier, points3D, tracks, valid_track_mask, image_size,
                 shared_camera=False, max_reproj_error=12, camera_type="SIMPLE_PINHOLE", force_estimate=False):
     """Reference: triangulation.py:260-479.  Inliers = given mask AND reprojection error <= 12 px with
-    positive depth; frames with > 100 such inliers are refined.  The reference's RANSAC fallback
-    (pycolmap.absolute_pose_estimation, P3P, random) is not reproduced: such frames keep their pose."""
+    positive depth; frames with > 100 such inliers are refined.  With `force_estimate` the other frames (and frames
+    refined to a focal length outside [0.1, 30] x image size) go through ``absolute_pose_estimation_batch`` -- the
+    device restatement of pycolmap.absolute_pose_estimation (P3P RANSAC + refinement; random, parity unpinned)."""
     _check_camera_type(camera_type)
     S = extrinsics.shape[0]
     P = tracks.shape[1]
@@ -279,10 +280,38 @@ def refine_pose(extrinsics, intrinsics, extra_params, inlier, points3D, tracks, 
     counts = inl.sum(1)
     for r in torch.nonzero(counts <= 100).squeeze(1).tolist():
         print(f"Frame {r} only has {int(counts[r])} geo_vis inliers")
-        if force_estimate:
-            print(f"Warning! absolute pose estimation (P3P RANSAC) is not part of the device path; frame {r} keeps its pose")
-    ext, K, extra, _ = _refine_frames(extrinsics, intrinsics, extra_params, tracks2D, points3D, inl, list(range(S)),
-                                      shared_camera, camera_type, 100, first_frame_refines_intrinsics=True)
+    ext, K, extra, refined = _refine_frames(extrinsics, intrinsics, extra_params, tracks2D, points3D, inl, list(range(S)),
+                                            shared_camera, camera_type, 100, first_frame_refines_intrinsics=True)
+    if force_estimate:
+        # reference :397-432: frames with <= 100 inliers, or refined to a wild focal length, are re-estimated from the
+        # visibility-only matches by absolute_pose_estimation (P3P RANSAC over 30 focal length factors + refinement);
+        # with <= 50 such matches -- or when the estimate fails -- all points are used
+        scale_px = float(image_size.max())
+        focal = K[:, 0, 0]
+        est = (counts <= 100) | (refined & ((focal < 0.1 * scale_px) | (focal > 30 * scale_px)))
+        if bool(est.any()):
+            dev = tracks.device
+            cand = inlier[:, valid_track_mask].bool().clone()
+            few = cand.sum(1) <= 50
+            for r in torch.nonzero(est).squeeze(1).tolist():
+                print(f"Estimating absolute poses by visible matches for frame {r}" if not bool(few[r]) else
+                      f"Warning! Estimating absolute poses by non visible matches for frame {r}")
+            cand[few] = True
+            flags = torch.full((S,), 3, dtype=torch.uint8, device=dev)
+            if shared_camera:
+                flags[1:] = 0
+            estopt = AbsolutePoseEstimationOptions(estimate_focal_length=True)
+            estopt.ransac.max_error = float(max_reproj_error)
+            refopt = AbsolutePoseRefinementOptions(refine_focal_length=True, refine_extra_params=True)
+            params = _intr_params(K, extra)
+            ids = torch.nonzero(est).squeeze(1)
+            ext, params, ok, _, _ = absolute_pose_estimation_batch(ext, params, tracks2D, points3D, cand, ids, camera_type, flags,
+                                                                   estopt, refopt)
+            retry = ids[~ok[ids] & ~few[ids]]
+            if retry.numel():                                   # estanswer is None -> once more with every point
+                ext, params, _, _, _ = absolute_pose_estimation_batch(ext, params, tracks2D, points3D, torch.ones_like(cand), retry,
+                                                                      camera_type, flags, estopt, refopt)
+            K, extra = _from_intr_params(params, camera_type)
     scale = image_size.max()
     valid = get_valid_frame_mask(K, ext, extra, scale)
     if (~valid).sum() > 0:

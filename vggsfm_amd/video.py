@@ -19,8 +19,8 @@ import torch
 from . import _lib
 from . import ba as _ba
 from .ba import window_bundle_adjustment  # noqa: F401  (re-export: the local BA of a window)
-from .ba_options import AbsolutePoseRefinementOptions, BundleAdjustmentOptions
-from .pose import pose_refinement_batch
+from .ba_options import AbsolutePoseEstimationOptions, AbsolutePoseRefinementOptions, BundleAdjustmentOptions
+from .pose import absolute_pose_estimation_batch, pose_refinement_batch
 from .utils.triangulation import _from_intr_params, _intr_params, triangulate_tracks
 from .utils.triangulation_helpers import cam_from_img, filter_all_points3D
 
@@ -70,10 +70,11 @@ def filter_points_and_compute_masks(points, tracks, extrinsics, intrinsics, extr
 
 
 def align_next_window(extrinsics, tracks, inlier, points3D, intrinsics, extra_params=None, camera_type="SIMPLE_RADIAL",
-                      min_vis_num=50):
-    """video_runner.py:938-1017 (use_pnp=False): frame 0 keeps its pose; every other frame is refined on the fixed
-    3D points with focal length and distortion constant (CauchyLoss(1), gradient tolerance 1.0); a frame with
-    <= min_vis_num inliers uses ALL points (`inlier_mask[:] = 1`).  All frames run concurrently, one workgroup each."""
+                      min_vis_num=50, use_pnp=False, generator=None):
+    """video_runner.py:938-1017: frame 0 keeps its pose; every other frame is refined on the fixed 3D points with
+    focal length and distortion constant (CauchyLoss(1), gradient tolerance 1.0); a frame with <= min_vis_num inliers
+    uses ALL points (`inlier_mask[:] = 1`).  use_pnp: the poses first come from absolute_pose_estimation on the inlier
+    matches (P3P RANSAC, max_error 12 px; device restatement, random => parity unpinned).  All frames run concurrently."""
     _lib.require_gpu(extrinsics, tracks, inlier, points3D)
     S = extrinsics.shape[0]
     dev = tracks.device
@@ -87,7 +88,13 @@ def align_next_window(extrinsics, tracks, inlier, points3D, intrinsics, extra_pa
     params = _intr_params(K.to(torch.float64), ep)
     flags = torch.zeros(S, dtype=torch.uint8, device=dev)          # refine_focal_length = refine_extra_params = False
     ids = torch.arange(1, S, device=dev)
-    ext, _, _ = pose_refinement_batch(extrinsics.to(torch.float64), params, tracks, points3D, inl, ids, camera_type, flags,
+    ext = extrinsics.to(torch.float64)
+    if use_pnp:
+        estopt = AbsolutePoseEstimationOptions()
+        estopt.ransac.max_error = 12
+        ext, _, _, _, _ = absolute_pose_estimation_batch(ext, params, tracks, points3D, inl, ids, camera_type, flags, estopt,
+                                                         AbsolutePoseRefinementOptions(), generator=generator)
+    ext, _, _ = pose_refinement_batch(ext, params, tracks, points3D, inl, ids, camera_type, flags,
                                       AbsolutePoseRefinementOptions())
     return ext
 

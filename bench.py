@@ -80,9 +80,12 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=5)
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="one Schur tile batch, factorisation after it on the same stream (A/B of the CU-masked overlap)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="opt-in: 3 Schur tile batches, factorisation on a CU-masked stream beside the later ones "
+                         "(ba.OVERLAP_FACTORIZATION; measured slower in round 1, DESIGN.md section 7)")
     args = ap.parse_args()
+    if args.overlap:
+        BA.OVERLAP_FACTORIZATION = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -105,7 +108,7 @@ def main():
     ext0_c, K0_c, extra0_c, _ = perturb_for_ba(sc, seed=0)          # cameras identical on every rank
     prob, valid_idx, deleted = BA.compile_problem(D(pts0, dev), D(ext0_c, dev), D(K0_c, dev), D(sc.tracks, dev),
                                                   D(sc.mask, dev), D(extra0_c, dev), shared, cam_type,
-                                                  overlap=(world == 1 and not args.no_overlap))
+                                                  overlap=(world == 1 and args.overlap))
     init = [t.clone() for t in (prob.cam_q, prob.cam_t, prob.intr, prob.pts)]
     L = _lib.lib()
     opts = BundleAdjustmentOptions()
@@ -216,8 +219,8 @@ def main():
                     note="v_mfma_f64_16x16x4_f64 on the off-diagonal Schur tiles; algorithmic flops = 2*3*BD^2 per "
                          "co-observing camera pair of a point (padding of the 16-camera segments not counted); "
                          "FP64 MFMA peak = FP64 vector peak = 78.6 TFLOP/s"
-                         + (f"; {per_iter} launches per iteration (tile batches): the first on all 256 CUs, the others on "
-                            f"{256 - BA.CHOL_CUS} CUs beside the factorisation, priced against the whole-chip peak"
+                         + (f"; --overlap: {per_iter} launches per iteration (tile batches), the first on all 256 CUs, the "
+                            f"others on {256 - BA.CHOL_CUS} CUs beside the factorisation, priced against the whole-chip peak"
                             if per_iter > 1 else "") if dom.startswith("schur_tile") else "")
         roof["launches_per_iteration"] = per_iter
         # per ITERATION (tile kernels: sum over the batches; with overlap the entries are not additive -- the

@@ -28,8 +28,20 @@ def test_golden_cases_present():
     assert len(CASES) >= 3
 
 
+def _estimation_returns_none(ext, params, points2D, points3D, cand, frame_ids, *a, **k):
+    """The harness that produced the golden vectors runs the reference behind oracle/pycolmap_shim.py, whose
+    ``absolute_pose_estimation`` returns None (the real one draws from COLMAP's RNG: nothing to pin) -- the reference
+    then keeps the pose (vggsfm/utils/triangulation.py:434).  Same here: every estimate "fails".  The device
+    estimator itself is tested in tests/test_gpu_p3p.py."""
+    S, P = cand.shape
+    z = torch.zeros(S, dtype=torch.bool, device=cand.device)
+    return ext, params, z, z.to(torch.int32), torch.zeros_like(cand, dtype=torch.bool)
+
+
 @pytest.mark.parametrize("case", CASES)
-def test_triangulator_matches_reference_driver(case):
+def test_triangulator_matches_reference_driver(case, monkeypatch):
+    from vggsfm_amd.utils import triangulation as T
+    monkeypatch.setattr(T, "absolute_pose_estimation_batch", _estimation_returns_none)
     g = np.load(os.path.join(GOLD, f"triangulator_{case}.npz"), allow_pickle=False)
     cam, shared, W = str(g["camera_type"]), bool(g["shared"]), int(g["W"])
     kw = {str(k): int(v) for k, v in zip(g["kw_keys"], g["kw_vals"])}

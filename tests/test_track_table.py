@@ -58,7 +58,7 @@ def _compare(tt, oracle):
     assert tt.num_points == (max(oracle.point_dict) + 1 if oracle.point_dict else 0)
     n_obs = 0
     for pid, pd in oracle.point_dict.items():
-        assert torch.allclose(tt.xyz[pid], pd["xyz"].float())
+        assert torch.equal(tt.xyz[pid], pd["xyz"].double())
         if pd["rgb"] is not None:
             assert torch.allclose(tt.rgb[pid], pd["rgb"].float())
         fr, uv, vis = tt.track_of(pid)
@@ -70,7 +70,7 @@ def _compare(tt, oracle):
     for f, fd in oracle.frame_dict.items():
         assert sorted(set(fd.get("visible_points", []))) == tt.visible_points(f).tolist()
         if "extri" in fd:
-            assert bool(tt.has_extri[f]) and torch.equal(tt.extri[f], fd["extri"].float())
+            assert bool(tt.has_extri[f]) and torch.equal(tt.extri[f], fd["extri"].double())
 
 
 def test_track_table_matches_dict_bookkeeping():

@@ -6,10 +6,10 @@ The reference keeps ``point_dict[id] = {xyz, rgb, track: {frame: {uv, vis}}}`` a
 O(points x frames) interpreter loops every window (its authors flag one of them as "too slow",
 video_runner.py:194).  Here the same state is a handful of tensors on the device:
 
-    xyz (P,3) f32, rgb (P,3) f32       point table; the point id is the row index (ids are dense, like the dicts' keys)
+    xyz (P,3) f64, rgb (P,3) f32       point table; the point id is the row index (ids are dense, like the dicts' keys)
     obs_point, obs_frame (O,) i64      one row per (point, frame) observation, kept sorted by (point, frame)
     obs_uv (O,2) f32, obs_vis (O,) f32
-    extri (F,3,4), has_extri (F,)      per-frame extrinsics
+    extri (F,3,4) f64, has_extri (F,)  per-frame extrinsics
 
 Every method is a few vectorised tensor ops; the dense (tracks, masks) views that bundle adjustment consumes are
 produced by scatter, not by loops.
@@ -20,13 +20,13 @@ import torch
 class TrackTable:
     def __init__(self, device="cuda", num_frames=0):
         self.device = torch.device(device)
-        self.xyz = torch.zeros((0, 3), dtype=torch.float32, device=self.device)
+        self.xyz = torch.zeros((0, 3), dtype=torch.float64, device=self.device)   # (BA output precision is kept)
         self.rgb = torch.zeros((0, 3), dtype=torch.float32, device=self.device)
         self.obs_point = torch.zeros(0, dtype=torch.long, device=self.device)
         self.obs_frame = torch.zeros(0, dtype=torch.long, device=self.device)
         self.obs_uv = torch.zeros((0, 2), dtype=torch.float32, device=self.device)
         self.obs_vis = torch.zeros(0, dtype=torch.float32, device=self.device)
-        self.extri = torch.zeros((num_frames, 3, 4), dtype=torch.float32, device=self.device)
+        self.extri = torch.zeros((num_frames, 3, 4), dtype=torch.float64, device=self.device)
         self.has_extri = torch.zeros(num_frames, dtype=torch.bool, device=self.device)
 
     # ------------------------------------------------------------------ sizes
@@ -95,10 +95,10 @@ class TrackTable:
         if need > self.num_points:
             is_new = abs_idx >= self.num_points
             grow = need - self.num_points
-            new_xyz = torch.zeros((grow, 3), dtype=torch.float32, device=dev)
+            new_xyz = torch.zeros((grow, 3), dtype=torch.float64, device=dev)
             new_rgb = torch.zeros((grow, 3), dtype=torch.float32, device=dev)
             if points3D is not None:
-                new_xyz[abs_idx[is_new] - self.num_points] = points3D.to(dev, torch.float32)[points3D_idx[is_new]]
+                new_xyz[abs_idx[is_new] - self.num_points] = points3D.to(dev, torch.float64)[points3D_idx[is_new]]
             if points3D_rgb is not None:
                 new_rgb[abs_idx[is_new] - self.num_points] = points3D_rgb.to(dev, torch.float32)[points3D_idx[is_new]]
             self.xyz = torch.cat([self.xyz, new_xyz])
@@ -154,7 +154,7 @@ class TrackTable:
         P = points3D.shape[0]
         keep = torch.ones(P, dtype=torch.bool, device=dev) if keep is None else keep.to(dev)
         masks = masks.to(dev).bool() & keep[None]
-        self.xyz = points3D.to(dev, torch.float32)[keep]
+        self.xyz = points3D.to(dev, torch.float64)[keep]
         self.rgb = (torch.zeros((P, 3), device=dev) if rgb is None else rgb.to(dev, torch.float32))[keep]
         new_id = torch.cumsum(keep.long(), 0) - 1
         fr, pi = torch.nonzero(masks, as_tuple=True)

@@ -145,3 +145,170 @@ def joint_bundle_adjustment(points3d, extrinsics, intrinsics, tracks, masks, ext
     if normalize:
         e_opt, p_opt = _ba.normalize_reconstruction(e_opt, p_opt, keep)
     return p_opt, e_opt, K_opt[0:1], (None if x_opt is None else x_opt[0:1]), inl, keep, summ
+
+
+class VideoGeometry:
+    """The geometric half of ``VideoRunner`` (vggsfm/runners/video_runner.py:64-247 ``run``, 640-905 ``move_window``,
+    1051-1187 ``prepare_window_data``, 494-541 ``joint_BA``) with the learned parts injected as callables and the
+    ``point_dict`` / ``frame_dict`` state held in a device-resident :class:`TrackTable`:
+
+        camera_prior(frame_from, frame_to) -> (frame_to - frame_from, 3, 4) predicted extrinsics (OpenCV), any gauge
+            -- the reference's ``average_camera_prediction`` over (last window, next window), video_runner.py:662-667
+        track_existing(frame_from, frame_to, query_uv (P,2)) -> (tracks (S,P,2), vis (S,P))
+            -- ``predict_tracks`` with the carried-over points as queries in frame_from, video_runner.py:1133-1146
+        track_new(frame_from, frame_to) -> (tracks (S,N,2), vis (S,N), score (S,N) | None)
+            -- ``predict_tracks`` with fresh query points, video_runner.py:1204-1216
+
+    Everything else -- similarity alignment of the predicted cameras, the window-shrinking rule, pose alignment on
+    the carried-over points, the reprojection filters, LO-RANSAC triangulation of the new tracks, the local BA with
+    constant carried-over points and constant first pose, the table updates, the joint BA with filters and
+    normalisation -- runs here, on the device, with the kernels of the batch path."""
+
+    def __init__(self, intrinsics, extra_params=None, camera_type="SIMPLE_RADIAL", max_query_pts=1024, device="cuda",
+                 generator=None):
+        from .track_table import TrackTable
+        self.device = torch.device(device)
+        self.intrinsics = intrinsics[0:1].to(self.device).clone()                       # 1x3x3 (video_runner.py:149)
+        if extra_params is None and camera_type == "SIMPLE_RADIAL":
+            extra_params = torch.zeros(1, 1, device=self.device, dtype=self.intrinsics.dtype)   # :146-147
+        self.extra_params = None if extra_params is None else extra_params[0:1].to(self.device).clone()
+        self.camera_type = camera_type
+        self.max_query_pts = int(max_query_pts)
+        self.generator = generator
+        self.table = TrackTable(self.device)
+
+    # ------------------------------------------------------------------ state
+    def add_initial_window(self, pred, start_idx, end_idx):
+        """``convert_pred_to_point_frame_dict(init_pred, ...)`` (video_runner.py:152)."""
+        self.table.add_window_prediction(pred, start_idx, end_idx)
+
+    def select_existing_points(self, frame_idx, max_ratio=1):
+        """video_runner.py:1062-1084: the points visible in `frame_idx`, at most max_query_pts * max_ratio of them
+        (uniform subset, ids ascending), with their 3D position and their pixel in that frame."""
+        t = self.table
+        sel = torch.nonzero(t.obs_frame == frame_idx).squeeze(1)
+        cap = self.max_query_pts * max_ratio
+        if sel.numel() > cap:
+            pick = torch.randperm(sel.numel(), device=self.device, generator=self.generator)[:cap]
+            sel = sel[torch.sort(pick).values]                                   # (observations are sorted by point id)
+        ids = t.obs_point[sel]
+        return ids, t.xyz[ids], t.obs_uv[sel]
+
+    # ------------------------------------------------------------------ one window
+    def move_window(self, start_idx, end_idx, window_size, camera_prior, track_existing, track_new,
+                    min_valid_track_length=3, track_vis_thres=0.05, use_pnp=False):
+        """video_runner.py:640-905.  (start_idx, end_idx) is the LAST window.  Returns (start_idx, end_idx, success)."""
+        last_window_size = end_idx - start_idx
+        assert last_window_size > 0, "last_window_size should be positive"
+        t = self.table
+        last_start_idx, start_idx = start_idx, end_idx
+        end_idx = start_idx + window_size
+        print(f"Processing window from {start_idx} to {end_idx}")
+        # predicted cameras of (last window, next window), aligned to the last window's reconstruction
+        pred_extri = camera_prior(last_start_idx, end_idx).to(self.device, torch.float64)
+        last_extri = t.extri[last_start_idx:start_idx].to(torch.float64)
+        rel_r, rel_t, rel_s = align_camera_extrinsics(pred_extri[:last_window_size], last_extri)
+        aligned_next = apply_transformation(pred_extri[last_window_size:], rel_r, rel_t, rel_s)
+        # prepare_window_data: carried-over points tracked through (start_idx - 1 .. end_idx)
+        ids, xyz, uv = self.select_existing_points(start_idx - 1)
+        tracks_e, vis_e = track_existing(start_idx - 1, end_idx, uv)
+        tracks_e, vis_e = tracks_e.to(self.device), vis_e.to(self.device)
+        inl_e = vis_e > track_vis_thres
+        extri_plus_one = torch.cat([t.extri[start_idx - 1:start_idx].to(torch.float64), aligned_next], dim=0)
+        # frames that see fewer than 50 carried-over points end the window early (video_runner.py:709-749)
+        few = inl_e.sum(dim=1) < 50
+        if bool(few.any()):
+            first_invalid = int(torch.nonzero(few)[0, 0])
+            if first_invalid > 2:
+                window_size = first_invalid - 1
+                print(f"Shrink the window from {start_idx}-{end_idx} to {start_idx}-{start_idx + window_size}")
+                end_idx = start_idx + window_size
+                tracks_e, vis_e, inl_e = tracks_e[:window_size + 1], vis_e[:window_size + 1], inl_e[:window_size + 1]
+                extri_plus_one = extri_plus_one[:window_size + 1]
+            else:
+                print("No valid frame, step back")
+                return last_start_idx - 1, start_idx - 1, False
+        K, ep = self.intrinsics, self.extra_params
+        align_ext = align_next_window(extri_plus_one, tracks_e, inl_e, xyz, K, ep, self.camera_type, use_pnp=use_pnp,
+                                      generator=self.generator)
+        pts_e, tr_e, m_e, keep_e = filter_points_and_compute_masks(xyz, tracks_e, align_ext, K, ep, min_valid_track_length)
+        ids_e = ids[keep_e]
+        # new tracks over the (possibly shrunk) window, triangulated with the aligned cameras
+        tracks_n, vis_n, score_n = track_new(start_idx - 1, end_idx)
+        tracks_n, vis_n = tracks_n.to(self.device), vis_n.to(self.device)
+        score_n = None if score_n is None else score_n.to(self.device)
+        pts_n, tr_n, m_n, vis_nf = triangulate_window_tracks(tracks_n, vis_n, score_n, align_ext, K, ep,
+                                                            min_valid_track_length=min_valid_track_length)
+        ne = int(pts_e.shape[0])
+        pts_all = torch.cat([pts_e.to(torch.float64), pts_n.to(torch.float64)], dim=0)
+        tr_all = torch.cat([tr_e, tr_n.to(tr_e.dtype)], dim=1)
+        m_all = torch.cat([m_e, m_n], dim=1)
+        # local BA: first pose and carried-over points constant, intrinsics fixed (video_runner.py:800-838)
+        S1 = align_ext.shape[0]
+        Kw = K.expand(S1, -1, -1)
+        epw = None if ep is None else ep.expand(S1, -1)
+        p_opt, ext_opt, _, _, summ = window_bundle_adjustment(pts_all, align_ext, Kw, tr_all, m_all, ne, epw, True,
+                                                              self.camera_type)
+        if summ["termination"] == 5:                                 # FAILURE (log_ba_summary -> RuntimeError)
+            raise RuntimeError("Bundle adjustment failed")
+        pts_opt = torch.zeros_like(pts_all)                          # pycolmap_to_batch_matrix: one row per track
+        pts_opt[summ["valid_idx"]] = p_opt
+        # the new points that survive the optimised cameras enter the table
+        npts, ntr, nm, nkeep = filter_points_and_compute_masks(pts_opt[ne:], tr_all[:, ne:], ext_opt, K, ep,
+                                                               min_valid_track_length)
+        pred = {"extrinsics_opencv": ext_opt[1:], "pred_track": ntr[1:], "pred_vis": vis_nf[:, nkeep][1:],
+                "valid_2D_mask": nm[1:], "valid_tracks": torch.ones(int(nkeep.sum()), dtype=torch.bool, device=self.device),
+                "points3D": npts, "points3D_rgb": None}
+        t.add_window_prediction(pred, start_idx, end_idx)
+        # the carried-over points keep xyz / id and gain the observations of this window (video_runner.py:868-903)
+        _, etr, em, ekeep = filter_points_and_compute_masks(pts_opt[:ne], tr_all[:, :ne], ext_opt, K, ep, min_valid_track_length)
+        evis = vis_e[:, keep_e][:, ekeep]
+        eids = ids_e[ekeep]
+        if eids.numel():
+            mapping = torch.zeros(t.num_points, dtype=torch.long, device=self.device)
+            mapping[eids] = torch.arange(eids.numel(), device=self.device)
+            t.update_points(start_idx, end_idx, em[1:], etr[1:], evis[1:], eids, mapping)
+        return start_idx, end_idx, True
+
+    # ------------------------------------------------------------------ joint BA
+    def joint_BA(self, start_idx, end_idx, reproj_error=2.0, tri_angle=1.5, normalize=True):
+        """video_runner.py:494-541: BA over every frame so far with the shared camera refined, the ObservationManager
+        filters, normalisation; the table is rebuilt from the result (``reconstruction_to_dicts``)."""
+        t = self.table
+        xyz, ext, tracks, masks, _ = t.window_tensors(start_idx, end_idx)
+        pts, e, K, x, inl, keep, summ = joint_bundle_adjustment(xyz, ext, self.intrinsics, tracks, masks, self.extra_params,
+                                                                self.camera_type, reproj_error, tri_angle, normalize)
+        self.intrinsics = K.to(torch.float32)[0:1].clone()           # (.float() in the reference)
+        if self.camera_type == "SIMPLE_RADIAL" and x is not None:
+            self.extra_params = x.to(torch.float32)[0:1].clone()
+        vi = summ["valid_idx"]
+        rgb = t.rgb[vi] if t.rgb.shape[0] == xyz.shape[0] else None
+        t.reset_from_tensors(pts, e, tracks[:, vi], inl, keep, rgb, start_idx)
+        return summ
+
+    # ------------------------------------------------------------------ the loop of VideoRunner.run
+    def run(self, num_frames, init_end_idx, window_size, camera_prior, track_existing, track_new, joint_BA_interval=6,
+            use_pnp=False):
+        """video_runner.py:156-189 after the initial window has been added: slide until the last frame, joint BA every
+        `joint_BA_interval` windows and once more at the end."""
+        start_idx, end_idx, T = 0, init_end_idx, num_frames
+        window_counter = 0
+        while end_idx < T:
+            ws = T - end_idx if (T - end_idx) <= int(1.25 * window_size) else window_size
+            start_idx, end_idx, ok = self.move_window(start_idx, end_idx, ws, camera_prior, track_existing, track_new,
+                                                      use_pnp=use_pnp)
+            if not ok:
+                print("Moving window failed, trying again. (This should not happen in most cases)")
+                self.max_query_pts *= 2
+                start_idx, end_idx, ok = self.move_window(start_idx, end_idx, window_size, camera_prior, track_existing,
+                                                          track_new, use_pnp=use_pnp)
+                self.max_query_pts //= 2
+                if not ok:
+                    raise RuntimeError("moving the window failed twice")
+            if window_counter % joint_BA_interval == 0:
+                print("Running joint BA:")
+                self.joint_BA(0, end_idx, normalize=True)
+            window_counter += 1
+        print("Running joint BA for the entire sequence:")
+        self.joint_BA(0, T, normalize=True)
+        return self.table

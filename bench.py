@@ -259,6 +259,27 @@ def main():
             cpu = dict(value=s_cpu["num_iterations"] / tcpu, unit="LM-iterations/s", cores=int(OB.lib().bao_num_threads()),
                        kind="port", sample=f"full {S}x{N} workload, {s_cpu['num_iterations']} LM iterations "
                        f"(oracle/ba_oracle.c, OpenMP, includes the initial evaluation), {tcpu:.1f} s")
+        parity = None
+        if cpu is not None:
+            # "pose delta vs ref" half of BASELINE.json's metric: the same full solve (reference BA options: 50 iterations,
+            # tolerances x10) on the GPU and by the CPU port, on a workload the port finishes in seconds
+            from vggsfm_amd.utils.triangulation_helpers import prepare_ba_options
+            ps, pn = 50, 4000
+            psc = make_scene(ps, pn, "SIMPLE_PINHOLE", shared_camera=False, seed=5)
+            pe0, pK0, _, pp0 = perturb_for_ba(psc, seed=5)
+            gp, ge, gK, _, gs = BA.bundle_adjustment(D(pp0, dev), D(pe0, dev), D(pK0, dev), D(psc.tracks, dev), D(psc.mask, dev),
+                                                     None, None, False, "SIMPLE_PINHOLE", prepare_ba_options())
+            op, oe, oK, _, osum = OB.bundle_adjustment(pp0, pe0, pK0, psc.tracks, psc.mask, None, False, "SIMPLE_PINHOLE",
+                                                       OB.prepare_ba_options())
+            ge, gp, gK = ge.cpu().numpy(), gp.cpu().numpy(), gK.cpu().numpy()
+            rel = lambda a, b: float(np.max(np.linalg.norm((a - b).reshape(len(a), -1), axis=1)
+                                            / np.maximum(np.linalg.norm(b.reshape(len(b), -1), axis=1), 1e-12)))
+            parity = dict(workload=f"synthetic {ps} frames x {pn} tracks SIMPLE_PINHOLE, full solve with the reference's BA options",
+                          lm_iterations_gpu=int(gs["num_iterations"]), lm_iterations_port=int(osum["num_iterations"]),
+                          final_cost_rel_delta=abs(gs["final_cost"] - osum["final_cost"]) / osum["final_cost"],
+                          max_rel_rotation_delta=rel(ge[:, :, :3], oe[:, :, :3]), max_rel_translation_delta=rel(ge[1:, :, 3], oe[1:, :, 3]),
+                          max_rel_point_delta=rel(gp, op), max_rel_focal_delta=float(np.max(np.abs(gK[:, 0, 0] / oK[:, 0, 0] - 1))),
+                          tolerance=1e-4, reference="oracle/ba_oracle.c (Ceres/COLMAP restatement; unpinned vs pycolmap)")
         out = {
             "metric": "BA LM-iterations/sec",
             "value": args.steps * world / dt,
@@ -277,6 +298,7 @@ def main():
             "roofline": roof,
             "iteration_roofline": iteration,
             "cpu_baseline": cpu,
+            "pose_delta_vs_port": parity,
         }
         print(json.dumps(out))
     if dist:

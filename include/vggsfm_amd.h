@@ -238,6 +238,36 @@ int vgg_p3p_ransac(const double* points2D_normalized, const double* points3D, co
                    const double* max_error_sq, double* out_pose, int32_t* out_num_inliers, double* out_residual_sum,
                    int32_t* out_best, uint8_t* out_inlier_mask, void* workspace, void* stream);
 
+/* Two-view stage in front of the path: estimate_fundamental = 7-point RANSAC + 8-point local
+ * optimisation for all (query frame, other frame) pairs at once   vggsfm/two_view_geo/fundamental.py:43-183,
+ * two_view_geo/utils.py:63-298; caller estimate_preliminary.py:103-152 (-> fmat_inlier_mask).  PARITY UNPINNED vs the
+ * reference (kornia absent, float32 SVDs, numpy RNG, poselib by default -- oracle/fundamental.py); float64 here.
+ * points1 / points2 [num_pairs][num_points][2] f64 pixels; valid_mask [num_pairs][num_points] uint8 or NULL
+ * (matches with vis >= 0.05 and score >= 0.5, estimate_preliminary.py:118-126); matrices are 9 doubles row-major,
+ * unit Frobenius norm, x2^T F x1 = 0.
+ *  vgg_fmat_seven_point  samples [num_samples][7] int32 shared by all pairs (fundamental.py:67-75) ->
+ *                        out_fmat [num_pairs][num_samples][3][9], out_valid [..][3] (1..3 real roots of the cubic)
+ *  vgg_fmat_score        squared Sampson distance (utils.py:90-172) of every match under every hypothesis; inliers
+ *                        <= max_error_sq and valid; out_counts [num_pairs][num_hypotheses] (-1 for an invalid
+ *                        hypothesis), out_residual_sums = sum of the inlier residuals (-> the mean that breaks ties,
+ *                        utils.py:63-87)
+ *  vgg_fmat_eight_point  for each selected [num_pairs][num_selected] index into src_fmat [num_pairs][num_src][9]: the
+ *                        8-point fit (masked normalisation, smallest eigenvector of X^T X, rank 2; fundamental.py:261-334)
+ *                        on the inliers of that hypothesis, recomputed on the fly; selected entries whose src_counts is
+ *                        negative give an invalid result
+ *  vgg_fmat_residuals    fmat [num_pairs][9] -> out_residuals [num_pairs][num_points] (1e6 for invalid matches)
+ * The caller sorts the counts (stable, descending) to select the lo_num best hypotheses between the calls. */
+int vgg_fmat_seven_point(const double* points1, const double* points2, const int32_t* samples, int num_pairs, int num_points,
+                         int num_samples, double* out_fmat, uint8_t* out_valid, void* stream);
+int vgg_fmat_score(const double* points1, const double* points2, const uint8_t* valid_mask, const double* fmat,
+                   const uint8_t* fmat_valid, int num_pairs, int num_points, int num_hypotheses, double max_error_sq,
+                   int32_t* out_counts, double* out_residual_sums, void* stream);
+int vgg_fmat_eight_point(const double* points1, const double* points2, const uint8_t* valid_mask, const double* src_fmat,
+                         const int32_t* src_counts, const int32_t* selected, int num_pairs, int num_points, int num_src,
+                         int num_selected, double max_error_sq, double* out_fmat, uint8_t* out_valid, void* stream);
+int vgg_fmat_residuals(const double* points1, const double* points2, const uint8_t* valid_mask, const double* fmat, int num_pairs,
+                       int num_points, double* out_residuals, void* stream);
+
 /* Optional per-kernel timing (HIP events recorded on the launch stream around the dominant kernels).
  * kernel_id: 0 cam_pass<linearize> 1 point_pass 2 cam_pass<rhs> 3 schur_tile<off-diagonal tiles> 4 cholesky (all
  * launches of one solve) 5 point_step 6 schur_tile<diagonal tiles>.  vgg_ba_profile_read synchronises on the

@@ -1,0 +1,93 @@
+"""GPU: the two-view kernels (vgg_fmat_* through the C-ABI) against oracle/fundamental.py on the SAME samples -- the
+two mirror each other operation by operation (float64, no FMA contraction, fixed-order sums), so hypotheses, counts,
+winners and inlier masks must be identical -- plus the behaviour of ``estimate_preliminary_cameras`` on a synthetic
+sequence.  Parity with the reference's float32 / kornia implementation is unpinned (oracle/fundamental.py header)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fundamental as Fd
+from tests.test_oracle_fundamental import two_view
+from vggsfm_amd import _lib
+from vggsfm_amd.scene import make_scene
+from vggsfm_amd.two_view_geo import estimate_fundamental, estimate_preliminary_cameras
+
+pytestmark = pytest.mark.gpu
+
+
+def D(x):
+    return None if x is None else torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def _pairs(B, N, seed):
+    xs = [two_view(N, seed + b, outliers=0.2 + 0.05 * b) for b in range(B)]
+    x1, x2 = np.stack([x[0] for x in xs]), np.stack([x[1] for x in xs])
+    rng = np.random.default_rng(seed)
+    vm = rng.random((B, N)) < 0.92
+    return x1, x2, vm, xs
+
+
+def test_seven_point_and_score_match_oracle_bitwise():
+    B, N, H = 3, 900, 200
+    x1, x2, vm, _ = _pairs(B, N, 10)
+    rng = np.random.default_rng(1)
+    smp = np.stack([rng.choice(N, 7, replace=False) for _ in range(H)]).astype(np.int32)
+    L = _lib.lib()
+    d1, d2, ds, dm = D(x1), D(x2), D(smp), D(vm.astype(np.uint8))        # (kept alive across the raw-pointer calls)
+    F7 = torch.empty((B, H, 3, 9), dtype=torch.float64, device="cuda")
+    v7 = torch.empty((B, H, 3), dtype=torch.uint8, device="cuda")
+    _lib.check(L.vgg_fmat_seven_point(_lib.ptr(d1), _lib.ptr(d2), _lib.ptr(ds), B, N, H, _lib.ptr(F7), _lib.ptr(v7),
+                                      _lib.stream_ptr()), "seven")
+    cnt = torch.empty((B, 3 * H), dtype=torch.int32, device="cuda")
+    rs = torch.empty((B, 3 * H), dtype=torch.float64, device="cuda")
+    _lib.check(L.vgg_fmat_score(_lib.ptr(d1), _lib.ptr(d2), _lib.ptr(dm), _lib.ptr(F7), _lib.ptr(v7), B, N,
+                                3 * H, ctypes.c_double(1.0), _lib.ptr(cnt), _lib.ptr(rs), _lib.stream_ptr()), "score")
+    for b in range(B):
+        Fo, vo = Fd.seven_point(x1[b][smp], x2[b][smp])
+        np.testing.assert_array_equal(v7[b].cpu().numpy().astype(bool), vo)
+        np.testing.assert_array_equal(F7[b].cpu().numpy().reshape(H, 3, 3, 3), Fo)          # bit for bit
+        co, ro, _ = Fd.score(Fo.reshape(-1, 3, 3), vo.reshape(-1), x1[b], x2[b], vm[b], 1.0)
+        np.testing.assert_array_equal(cnt[b].cpu().numpy(), co)
+        np.testing.assert_array_equal(rs[b].cpu().numpy(), ro)
+
+
+@pytest.mark.parametrize("B,N,H,lo", [(2, 700, 128, 24), (1, 3000, 300, 50)])
+def test_estimate_fundamental_matches_oracle(B, N, H, lo):
+    x1, x2, vm, xs = _pairs(B, N, 20 + N)
+    rng = np.random.default_rng(2)
+    smp = np.stack([rng.choice(N, 7, replace=False) for _ in range(H)]).astype(np.int32)
+    F, num, mask, res = estimate_fundamental(D(x1), D(x2), max_error=1.0, lo_num=lo, valid_mask=D(vm), return_residuals=True,
+                                             samples=smp)
+    for b in range(B):
+        o = Fd.estimate_fundamental_pair(x1[b], x2[b], vm[b], smp, 1.0, lo_num=lo)
+        assert int(num[b]) == o["inlier_num"]
+        np.testing.assert_array_equal(mask[b].cpu().numpy(), o["inlier_mask"])
+        np.testing.assert_array_equal(F[b].cpu().numpy(), o["fmat"])
+        np.testing.assert_array_equal(res[b].cpu().numpy(), o["residuals"])
+        good = ~xs[b][2] & vm[b]
+        assert (o["inlier_mask"] & good).sum() >= 0.98 * good.sum()
+
+
+def test_estimate_preliminary_cameras_on_a_scene():
+    # the query frame against 7 others: clean matches are inliers, gross outliers are not, invisible matches never
+    S, N = 8, 2500
+    sc = make_scene(S, N, "SIMPLE_PINHOLE", seed=33, full_visibility=True, outlier_frac=0.15, noise_px=0.4)
+    vis = sc.vis.copy()
+    vis[:, ::17] = 0.0
+    np.random.seed(0)
+    _, pre = estimate_preliminary_cameras(D(sc.tracks)[None], D(vis)[None], 1024, 1024, tracks_score=D(sc.score)[None],
+                                          max_error=2.0, max_ransac_iters=512, lo_num=60)
+    m = pre["fmat_inlier_mask"][0].cpu().numpy()
+    assert m.shape == (S - 1, N) and pre["fmat"].shape == (1, S - 1, 3, 3) and pre["fmat_residuals"].shape == (1, S - 1, N)
+    assert not m[:, ::17].any()
+    clean = ~(sc.outlier[1:] | sc.outlier[0:1]) & (vis[1:] > 0)
+    assert (m & clean).sum() >= 0.97 * clean.sum()
+    gross = (sc.outlier[1:] | sc.outlier[0:1]) & (vis[1:] > 0)
+    assert (m & gross).sum() <= 0.15 * gross.sum()
+    # x2^T F x1 = 0 on the inliers, F scaled to F[2,2] = 1, rank 2
+    F = pre["fmat"][0].cpu().numpy()
+    assert np.allclose(F[:, 2, 2], 1.0) and np.abs(np.linalg.det(F / np.linalg.norm(F, axis=(1, 2), keepdims=True))).max() < 1e-10
+    with pytest.raises(ValueError):
+        estimate_fundamental(D(sc.tracks[0:1, :5].astype(np.float64)), D(sc.tracks[1:2, :5].astype(np.float64)))

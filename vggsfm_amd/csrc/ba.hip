@@ -728,8 +728,6 @@ __global__ __launch_bounds__(256, (BD == 6 ? (DIAG ? 4 : VGG_OFFDIAG_OCC) : 2)) 
   const int nsub = (e1 - e0 + kSub - 1) / kSub;
   const int nb = ((nsub - cj + cJ - 1) / cJ) * BPS;             // batches of this workgroup
   auto ebase = [&](int b) -> int { return e0 + ((b / BPS) * cJ + cj) * kSub + (b % BPS) * 4; };
-  constexpr bool diag = DIAG;
-  const int4* ent = reinterpret_cast<const int4*>(entries);
   f64x4_t acc[NH][NH];
 #pragma unroll
   for (int i = 0; i < NH; ++i)

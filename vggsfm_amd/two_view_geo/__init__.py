@@ -1,0 +1,5 @@
+"""Two-view stage in front of the hot path (vggsfm/two_view_geo/): fundamental matrices for all (query frame, other
+frame) pairs at once on the device.  SURVEY.md section 8(f).3; PARITY UNPINNED against the reference."""
+from .estimate_preliminary import estimate_preliminary_cameras  # noqa: F401
+from .fundamental import estimate_fundamental  # noqa: F401
+from .utils import generate_samples  # noqa: F401

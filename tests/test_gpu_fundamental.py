@@ -91,3 +91,34 @@ def test_estimate_preliminary_cameras_on_a_scene():
     assert np.allclose(F[:, 2, 2], 1.0) and np.abs(np.linalg.det(F / np.linalg.norm(F, axis=(1, 2), keepdims=True))).max() < 1e-10
     with pytest.raises(ValueError):
         estimate_fundamental(D(sc.tracks[0:1, :5].astype(np.float64)), D(sc.tracks[1:2, :5].astype(np.float64)))
+
+
+def test_two_view_stage_feeds_the_triangulator():
+    """Everything after the tracker on the device: estimate_preliminary_cameras -> Triangulator.forward
+    (vggsfm/runners/runner.py:467-515) on a synthetic scene with a noisy camera prior."""
+    import types
+
+    from vggsfm_amd.models import Triangulator
+    from vggsfm_amd.scene import perturb_for_ba, project
+    S, N, W = 10, 3000, 1024
+    sc = make_scene(S, N, "SIMPLE_PINHOLE", shared_camera=False, seed=77, full_visibility=True, outlier_frac=0.08)
+    ext0, K0, _, _ = perturb_for_ba(sc, seed=77, rot_deg=0.5, trans=0.02, focal_rel=0.02)
+    tracks, vis, score = D(sc.tracks)[None], D(sc.vis)[None], D(sc.score)[None]
+    np.random.seed(1)
+    _, prelim = estimate_preliminary_cameras(tracks, vis, W, W, tracks_score=score, max_error=4.0, max_ransac_iters=1024,
+                                             lo_num=100)
+    cams = types.SimpleNamespace(R=torch.from_numpy(ext0[:, :, :3]).float().cuda(), T=torch.from_numpy(ext0[:, :, 3]).float().cuda())
+    f = torch.from_numpy(K0[:, 0, 0] / (W / 2.0)).float().cuda()
+    cams.focal_length = torch.stack([f, f], -1)
+    torch.manual_seed(0)
+    out = Triangulator()(cams, tracks, vis, torch.rand(1, S, 3, W, W, device="cuda"), prelim, pred_score=score,
+                         shared_camera=False, camera_type="SIMPLE_PINHOLE", BA_iters=2, robust_refine=2)
+    ext, K, extra, pts, rgb, rec, valid_frames, valid_2D, valid_tracks = out
+    assert bool(valid_frames.all()) and float(valid_tracks.float().mean()) > 0.85
+    uv, _ = project(pts.cpu().numpy(), ext.cpu().numpy(), K.cpu().numpy(), None)
+    m = valid_2D[:, valid_tracks].cpu().numpy()
+    err = np.linalg.norm(uv - sc.tracks[:, valid_tracks.cpu().numpy()], axis=-1)[m]
+    assert np.median(err) < 1.0 and np.percentile(err, 95) < 2.5
+    # the outliers the two-view stage rejected never vote in the initial pair selection; the final model rejects them too
+    bad = sc.outlier[:, valid_tracks.cpu().numpy()]
+    assert (m & bad).sum() < 0.1 * bad.sum()

@@ -96,3 +96,43 @@ def test_tensor_to_pycolmap_drop_in_selection_rules():
     p, e, Kb, xp = pycolmap_to_batch_matrix(rec, device="cpu", camera_type="SIMPLE_RADIAL")
     assert p.shape == (len(valid), 3) and e.shape == (S, 3, 4) and Kb.shape == (S, 3, 3) and xp.shape == (S, 1)
     assert np.array_equal(p.numpy(), pts[valid])
+
+
+@pytest.mark.skipif(not ref_harness.available(), reason="reference tree not present (GPU box)")
+@pytest.mark.parametrize("shared", [False, True])
+def test_runner_edits_roundtrip(tmp_path, shared):
+    """The edits the runner applies after the solve (vggsfm/runners/runner.py:546-591, 1009-1054): original file names,
+    cameras back at the original resolution, shifted 2D points, a deregistered image, trackless extra points -- read back
+    with the reference's reader."""
+    sc, rec, colors = _model(tmp_path, "SIMPLE_RADIAL", shared)
+    names = [f"frame_{s:03d}.jpg" for s in range(5)]
+    crop = np.zeros((1, 5, 8))
+    crop[0, :, 0], crop[0, :, 1] = [1920, 1600, 1920, 1280, 1920], [1080, 1200, 1080, 960, 1080]       # real (w, h)
+    crop[0, :, 4], crop[0, :, 5] = -3.0, -100.0                                                         # padded top-left
+    K_before, tracks_before = rec.intrinsics.copy(), rec.tracks.copy()
+    rec.rename_and_rescale(names, crop, 1024, shift_point2d_to_original_res=True)
+    rec.deregister_image(3)
+    rec.add_points3D(np.array([[1.0, 2.0, 3.0], [4.0, 5.0, 6.0]]), np.array([[9, 8, 7], [1, 2, 3]]))
+    assert rec.num_points3D() == 42
+    rec.write(str(tmp_path))
+    ref_harness.install()
+    from vggsfm.datasets.imc_helper import read_model
+    cameras, images, points3D = read_model(str(tmp_path), ext=".bin")
+    assert len(images) == 4 and 3 not in images and len(points3D) == 42
+    assert sorted(im.name for im in images.values()) == [names[s] for s in (0, 1, 2, 4)]
+    ncam = 1 if shared else 5
+    assert len(cameras) == ncam
+    for c in range(ncam):
+        ratio = max(crop[0, c, 0], crop[0, c, 1]) / 1024.0
+        np.testing.assert_allclose(cameras[c].params[0], ratio * K_before[c, 0, 0])
+        assert (cameras[c].width, cameras[c].height) == (int(crop[0, c, 0]), int(crop[0, c, 1]))
+        assert tuple(cameras[c].params[1:3]) == (crop[0, c, 0] // 2, crop[0, c, 1] // 2)
+    for s in (0, 1, 2, 4):
+        ratio = max(crop[0, 0 if shared else s, 0], crop[0, 0 if shared else s, 1]) / 1024.0
+        pids = np.nonzero(sc.mask[s])[0]
+        np.testing.assert_allclose(images[s].xys, (tracks_before[s, pids] - np.array([3.0, 100.0])) * ratio)
+    assert points3D[41].xyz.tolist() == [1.0, 2.0, 3.0] and points3D[42].rgb.tolist() == [1, 2, 3]
+    assert len(points3D[41].image_ids) == 0
+    # observations of the deregistered image are gone from the tracks
+    for p in range(40):
+        assert 3 not in points3D[p + 1].image_ids.tolist()

@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=5)
+    ap.add_argument("--no-camera-split", action="store_true",
+                    help="keep the cameras in frame order (A/B of the side-by-side factorisation of decoupled camera blocks)")
     ap.add_argument("--overlap", action="store_true",
                     help="opt-in: 3 Schur tile batches, factorisation on a CU-masked stream beside the later ones "
                          "(ba.OVERLAP_FACTORIZATION; measured slower in round 1, DESIGN.md section 7)")
@@ -108,7 +110,8 @@ def main():
     ext0_c, K0_c, extra0_c, _ = perturb_for_ba(sc, seed=0)          # cameras identical on every rank
     prob, valid_idx, deleted = BA.compile_problem(D(pts0, dev), D(ext0_c, dev), D(K0_c, dev), D(sc.tracks, dev),
                                                   D(sc.mask, dev), D(extra0_c, dev), shared, cam_type,
-                                                  overlap=(world == 1 and args.overlap))
+                                                  overlap=(world == 1 and args.overlap), camera_split=not args.no_camera_split,
+                                                  adjacency_reduce=(lambda t: dist.all_reduce(t, op=dist.ReduceOp.MAX)) if dist else None)
     init = [t.clone() for t in (prob.cam_q, prob.cam_t, prob.intr, prob.pts)]
     L = _lib.lib()
     opts = BundleAdjustmentOptions()
@@ -293,6 +296,7 @@ def main():
                        "frames": S, "tracks_per_gpu": N, "observations_per_gpu": n_obs, "reduced_system": n_red,
                        "parallelism": f"points sharded x{world}, cameras replicated, RCCL all-reduce of the reduced system",
                        "episode_iterations": EPISODE,
+                       "camera_split_columns": list(prob.chol_split),   # block-diagonal leading part factorised side by side
                        "successful_steps_last_episode": int(fin["num_successful_steps"]),
                        "kernel_ms": kernel_ms},
             "roofline": roof,

@@ -146,6 +146,13 @@ typedef struct {
                                  ones (separate launches).  Column block g of the reduced system only receives sums
                                  from tiles with groupI <= g: it is complete once the batches up to that of group g
                                  are done, so the factorisation can start while later batches are being computed. */
+  int32_t chol_split_a;       /* Block-diagonal leading part of the reduced camera system, 0 = none.  If the cameras are */
+  int32_t chol_split_b;       /* ordered so that no point is seen both by one of the first chol_split_a / 6 cameras and by
+                                 one of the next chol_split_b / 6 (sliding-window / video-like visibility: the host side
+                                 checks this and orders the cameras, ba.py), the pose columns [0, a) and [a, a + b) of S
+                                 do not couple and their factorisations advance side by side in shared launches
+                                 (chol.hip); a must be a multiple of 64.  The caller guarantees the structure -- with
+                                 several GPUs for the SUM over ranks. */
 } vgg_ba_problem;
 
 typedef struct {
@@ -282,6 +289,10 @@ int vgg_ba_profile_read(int kernel_id, double* total_ms, int* launches, int rese
  * *device_fail (int32, device) is set non-zero on a non-positive pivot. */
 size_t vgg_cholesky_workspace_bytes(int n);
 int vgg_cholesky_solve(double* A, double* b, int n, void* workspace, int32_t* device_fail, void* stream);
+/* the same with a block-diagonal leading part: A[i][j] = 0 for split_a <= i < split_a + split_b, j < split_a (exposed
+ * for tests; see vgg_ba_problem.chol_split_a) */
+int vgg_cholesky_solve_split(double* A, double* b, int n, int split_a, int split_b, void* workspace, int32_t* device_fail,
+                             void* stream);
 
 #ifdef __cplusplus
 }

@@ -7,12 +7,15 @@
 #include "../../vggsfm_amd/csrc/chol.hip"
 int main(int argc, char** argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 1202;
+  // optional block-diagonal leading part (columns of A, columns of B): chol_bench 1202 384 288
+  const int split_a = argc > 3 ? atoi(argv[2]) : 0, split_b = argc > 3 ? atoi(argv[3]) : 0;
   const int reps = 20;
   std::vector<double> A((size_t)n * n + n), M((size_t)n * 8);
   srand(1);
   // SPD: banded-ish random + diagonal dominance
   for (size_t i = 0; i < A.size(); ++i) A[i] = 0;
   for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) { double v = (rand() / (double)RAND_MAX - 0.5) * 0.01; A[(size_t)i * n + j] = v; }
+  for (int i = split_a; i < split_a + split_b && i < n; ++i) for (int j = 0; j < split_a; ++j) A[(size_t)i * n + j] = 0.0;
   for (int i = 0; i < n; ++i) A[(size_t)i * n + i] = 1.0 + n * 0.01;
   for (int i = 0; i < n; ++i) A[(size_t)n * n + i] = rand() / (double)RAND_MAX;
   double *dA, *d0, *ws; int* fail;
@@ -29,7 +32,7 @@ int main(int argc, char** argv) {
         for (int k = 0; k < 4; ++k) hipMemsetAsync(ws, 0, 1 << 20, st);
       }
       hipEventRecord(e0, st);
-      vgg::cholesky_solve_enqueue(dA, dA + (size_t)n * n, n, ws, fail, nullptr, st);
+      vgg::cholesky_solve_enqueue(dA, dA + (size_t)n * n, n, ws, fail, nullptr, st, nullptr, split_a, split_b);
       hipEventRecord(e1, st);
       hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);

@@ -62,6 +62,60 @@ def test_cholesky_solve_fused_rhs_row(n):
     np.testing.assert_allclose(bt.cpu().numpy(), xr, rtol=1e-8, atol=1e-10 * np.abs(xr).max())
 
 
+@pytest.mark.parametrize("n,sa,sb", [(1202, 384, 336), (700, 192, 256), (520, 256, 128), (450, 64, 300), (300, 128, 64)])
+def test_cholesky_solve_split_matches_plain(n, sa, sb):
+    """Block-diagonal leading part (no coupling between the column sets [0, sa) and [sa, sa + sb)): the two
+    factorisations advance in shared panel launches.  Same L and same solution as LAPACK, and as the plain entry on the
+    same matrix to rounding (the trailing updates of the two blocks reach the shared rows in a different order)."""
+    rng = np.random.default_rng(n + sa)
+    Lt = np.tril(rng.normal(size=(n, n))) * 0.05                    # A = Lt Lt^T with Lt[B rows][A cols] = 0 => A[B][A] = 0 exactly
+    Lt[np.arange(n), np.arange(n)] = rng.uniform(1.0, 2.0, n)
+    Lt[sa:sa + sb, :sa] = 0.0
+    A = Lt @ Lt.T
+    A[sa:sa + sb, :sa] = 0.0                                        # (sums of exact zeros; spelled out)
+    A[:sa, sa:sa + sb] = 0.0
+    b = rng.normal(size=n)
+    out = []
+    for split in (True, False):
+        buf = D(np.concatenate([np.tril(A).ravel(), b]))
+        fail = torch.zeros(1, dtype=torch.int32, device="cuda")
+        At, bt = buf[:n * n], buf[n * n:]
+        if split:
+            rc = _lib.lib().vgg_cholesky_solve_split(_lib.ptr(At), _lib.ptr(bt), n, sa, sb, _lib.ptr(_chol_ws(n)), _lib.ptr(fail),
+                                                     _lib.stream_ptr())
+        else:
+            rc = _lib.lib().vgg_cholesky_solve(_lib.ptr(At), _lib.ptr(bt), n, _lib.ptr(_chol_ws(n)), _lib.ptr(fail), _lib.stream_ptr())
+        assert rc == 0 and int(fail.item()) == 0
+        out.append((np.tril(At.cpu().numpy().reshape(n, n)), bt.cpu().numpy()))
+    xr = np.linalg.solve(A, b)
+    np.testing.assert_allclose(out[0][1], xr, rtol=1e-8, atol=1e-10 * np.abs(xr).max())
+    np.testing.assert_allclose(out[0][0], np.linalg.cholesky(A), rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-10, atol=1e-13)
+
+
+def test_ba_camera_split_matches_unsplit(monkeypatch):
+    """Sliding-window visibility at 160 frames: bundle_adjustment orders the cameras [A, B, rest] and factorises A and B
+    side by side.  Against the same solve without the re-ordering: same trajectory to rounding (the summation order of
+    the reduced system changes), outputs in the order of the input frames."""
+    sc = make_scene(160, 8000, "SIMPLE_RADIAL", shared_camera=True, seed=13)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=13)
+    assert BA.find_camera_split(D(sc.mask))[0] is not None
+    opt = BundleAdjustmentOptions()
+    opt.solver_options.max_num_iterations = 12
+
+    def solve():
+        return BA.bundle_adjustment(D(pts0), D(ext0), D(K0), D(sc.tracks), D(sc.mask), None, D(extra0), True, "SIMPLE_RADIAL", opt)
+    a = solve()
+    monkeypatch.setattr(BA, "CAMERA_SPLIT_MIN_STEPS", 10 ** 6)
+    ref = solve()
+    assert a[4]["num_iterations"] == ref[4]["num_iterations"]
+    assert abs(a[4]["final_cost"] - ref[4]["final_cost"]) <= 1e-9 * ref[4]["final_cost"]
+    for x, y in zip(a[:4], ref[:4]):
+        np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-7, atol=1e-7)
+    np.testing.assert_array_equal(a[1][0].cpu().numpy(), ext0[0])             # the gauge frame is still frame 0
+
+
 def test_cholesky_flags_indefinite():
     A = np.eye(40)
     A[17, 17] = -1.0

@@ -194,3 +194,24 @@ def test_generate_combinations_matches_itertools_order():
         ref = np.array(list(itertools.combinations(np.arange(n), 2))).reshape(-1, 2)
         got = generate_combinations(n)
         assert got.dtype == ref.dtype and np.array_equal(got, ref)
+
+
+def test_find_camera_split_on_sliding_window_visibility():
+    """Video-like visibility (tracks span at most 40 % of the frames): the first and the last cameras share no point, the
+    ordering [A, B, rest] makes the leading part of the reduced system block diagonal, A's column count is a multiple of
+    64 and frames 0 / 1 (the gauge) stay in front.  All-to-all visibility: no split."""
+    sc = make_scene(200, 4000, "SIMPLE_RADIAL", shared_camera=True, seed=0)
+    m = T(sc.mask)
+    perm, (ca, cb) = BA.find_camera_split(m)
+    assert perm is not None and ca % 64 == 0 and ca > 0 and cb > 0 and min(ca, cb) // 64 >= BA.CAMERA_SPLIT_MIN_STEPS
+    assert sorted(perm.tolist()) == list(range(200)) and perm[:2].tolist() == [0, 1]
+    na, nb_ = ca // 6, cb // 6
+    mp = m[perm]
+    assert not bool((mp[:na].any(0) & mp[na:na + nb_].any(0)).any())          # no point seen from both A and B
+    assert (ca, cb) == (384, 288) and perm[-8:].tolist() == list(range(192, 200))     # groups 0-3 vs 9-11; the partial group last
+    # a reduce callback that adds a coupling (another rank sees a point from the first and the last group) kills it
+    def couple(adj):
+        adj[0, -1] = adj[-1, 0] = 1.0
+    assert BA.find_camera_split(m, adjacency_reduce=couple)[0] is None
+    full = torch.ones(200, 50, dtype=torch.bool)
+    assert BA.find_camera_split(full)[0] is None and BA.find_camera_split(m[:40])[0] is None

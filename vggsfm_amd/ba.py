@@ -104,6 +104,8 @@ class DeviceProblem:
     loss: int = 0
     loss_scale: float = 1.0
     batch_desc: Optional[torch.Tensor] = None   # (B,6) int32 on the HOST (build_schur_tiles); None = derive one batch
+    chol_split: tuple = (0, 0)        # (columns of A, columns of B): block-diagonal leading part of the reduced system
+    cam_perm: Optional[torch.Tensor] = None     # (S,) long: camera s of this problem is input frame cam_perm[s] (None = identity)
 
     @property
     def num_obs(self):
@@ -129,6 +131,7 @@ class DeviceProblem:
         P.tile_batches = self.batch_desc.data_ptr()   # host memory, kept alive by self
         P.num_tiles = self.tile_desc.shape[0]
         P.num_segments = self.num_segments
+        P.chol_split_a, P.chol_split_b = int(self.chol_split[0]), int(self.chol_split[1])
         return P
 
 
@@ -243,13 +246,58 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
             batch_desc.contiguous())
 
 
+CAMERA_SPLIT_MIN_STEPS = 2    # shared 64-column factorisation steps below which re-ordering the cameras is not worth it
+
+
+def find_camera_split(masks, group=GROUP, adjacency_reduce=None):
+    """Sliding-window visibility (video, ordered image sets): no point is seen both by the first cameras and by the
+    last ones, so the reduced camera system has a block-diagonal leading part once those two sets are ordered first --
+    and the factorisations of the two blocks can advance side by side (csrc/chol.hip).  masks (S,P) bool.
+    Returns (perm (S,) long new -> input frame | None, (columns of A, columns of B)).  A = the first `a` camera groups
+    (a even, so that A's 96 a columns are a multiple of 64), B = every FULL group behind the last one that shares a point
+    with A (a partial last group goes to the very end, so that the 16-camera groups of the tile kernels stay aligned);
+    the pair with the most shared 64-column steps wins.  `adjacency_reduce(t)`: in-place MAX all-reduce of the
+    (G,G) group adjacency -- with several ranks the structure must hold for the SUM of their systems."""
+    S = masks.shape[0]
+    G = (S + group - 1) // group
+    if G < 4:
+        return None, (0, 0)
+    pad = G * group - S
+    m = torch.cat([masks, masks.new_zeros((pad, masks.shape[1]))]) if pad else masks
+    V = m.reshape(G, group, -1).any(1).to(torch.float32)
+    adj = ((V @ V.t()) > 0).to(torch.float32)
+    if adjacency_reduce is not None:
+        adjacency_reduce(adj)
+    adj = adj.cpu() > 0
+    Gfull = S // group                              # B takes whole groups only: every group of the new order stays aligned
+    best = (0, 0, 0)
+    for a in range(2, Gfull - 1, 2):
+        reach = int(torch.nonzero(adj[:a].any(0)).max())               # last group that shares a point with A
+        b = max(reach + 1, a)
+        if b >= Gfull:
+            break
+        steps = min(6 * group * a, 6 * group * (Gfull - b)) // 64
+        if steps > best[0]:
+            best = (steps, a, b)
+    steps, a, b = best
+    if steps < CAMERA_SPLIT_MIN_STEPS:
+        return None, (0, 0)
+    dev = masks.device
+    perm = torch.cat([torch.arange(0, group * a, device=dev), torch.arange(group * b, group * Gfull, device=dev),
+                      torch.arange(group * a, group * b, device=dev), torch.arange(group * Gfull, S, device=dev)])
+    return perm, (6 * group * a, 6 * group * (Gfull - b))
+
+
 def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_params=None, shared_camera=False,
                     camera_type="SIMPLE_PINHOLE", max_points3D_val=3000, filter_negative_depth=True,
-                    gauge="colmap", overlap=None):
+                    gauge="colmap", overlap=None, camera_split=False, adjacency_reduce=None):
     """tensors (reference layout, on the GPU) -> DeviceProblem + bookkeeping.
     Returns (problem, valid_idx (P',) long, deleted (P',) bool).
     overlap: cut the Schur tiles into TILE_BATCHES batches so that a single-GPU solve can factorise beside the later
-    ones (default OVERLAP_FACTORIZATION; pass False for a multi-GPU shard, whose system is all-reduced first)."""
+    ones (default OVERLAP_FACTORIZATION; pass False for a multi-GPU shard, whose system is all-reduced first).
+    camera_split: look for a block-diagonal leading part (find_camera_split) and order the cameras accordingly --
+    problem.cam_perm then maps the problem's cameras to the input frames (cam_q / cam_t / per-camera intr / cam_const
+    are in THAT order).  With several ranks pass `adjacency_reduce` so that every rank orders alike."""
     if camera_type not in MODEL_ID:
         raise ValueError(f"Camera type {camera_type} is not supported yet")
     dev = tracks.device
@@ -257,6 +305,13 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
     ext = extrinsics.to(torch.float64)
     K = intrinsics.to(torch.float64)
     masks = masks.bool()
+    cam_perm, chol_split = (None, (0, 0))
+    if camera_split:
+        cam_perm, chol_split = find_camera_split(masks, adjacency_reduce=adjacency_reduce)
+    if cam_perm is not None:                        # (frames 0 and 1 -- the default gauge -- stay first: A is a prefix)
+        ext, K, masks, tracks = ext[cam_perm], K[cam_perm], masks[cam_perm], tracks[cam_perm]
+        if extra_params is not None:
+            extra_params = extra_params[cam_perm]
     length0 = masks.sum(0)
     valid_idx = torch.nonzero(length0 >= 2).squeeze(1)
     pts = points3d.to(torch.float64)[valid_idx].contiguous()
@@ -312,7 +367,7 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
         row_ptr, obs_cam, max_chunks=slots, num_batches=nb, later_scale=(cus - CHOL_CUS) / cus)
     prob = DeviceProblem(cam_q, cam_t, intr, pts, row_ptr, obs_cam, obs_uv, col_ptr, cobs_pt, cobs_uv, chunk_desc,
                          entries, tile_desc, obs_slot, nseg, MODEL_ID[camera_type], cam_const=cam_const,
-                         batch_desc=batch_desc)
+                         batch_desc=batch_desc, chol_split=chol_split, cam_perm=cam_perm)
     return prob, valid_idx, deleted
 
 
@@ -419,19 +474,28 @@ def bundle_adjustment(points3d, extrinsics, intrinsics, tracks, masks, image_siz
     _lib.require_gpu(points3d, extrinsics, intrinsics, tracks, masks)
     prob, valid_idx, deleted = compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_params,
                                                shared_camera, camera_type, filter_negative_depth=filter_negative_depth,
-                                               gauge="colmap" if constant_pose_frames is None else "config")
+                                               gauge="colmap" if constant_pose_frames is None else "config",
+                                               camera_split=True)
+    S = extrinsics.shape[0]
+    inv_perm = None
+    if prob.cam_perm is not None:
+        inv_perm = torch.empty_like(prob.cam_perm)
+        inv_perm[prob.cam_perm] = torch.arange(S, device=prob.cam_perm.device)
     if constant_pose_frames is not None:
-        prob.cam_const[torch.as_tensor(list(constant_pose_frames), dtype=torch.long, device=prob.cam_const.device)] = 1
+        cf = torch.as_tensor(list(constant_pose_frames), dtype=torch.long, device=prob.cam_const.device)
+        prob.cam_const[cf if inv_perm is None else inv_perm[cf]] = 1
     if constant_points is not None:
         prob.pt_const = constant_points.to(device=prob.pts.device)[valid_idx].to(torch.uint8).contiguous()
     summary, _ = solve(prob, options)
-    S = extrinsics.shape[0]
     ext = torch.cat([quat_to_rotmat(prob.cam_q), prob.cam_t[:, :, None]], -1)
+    if inv_perm is not None:
+        ext = ext[inv_perm]                           # back to the order of the input frames
     pts = prob.pts
     pts[deleted] = 0.0
     if normalize:
         ext, pts = normalize_reconstruction(ext, pts, ~deleted)
-    idx = torch.zeros(S, dtype=torch.long, device=pts.device) if shared_camera else torch.arange(S, device=pts.device)
+    idx = torch.zeros(S, dtype=torch.long, device=pts.device) if shared_camera else \
+        (torch.arange(S, device=pts.device) if inv_perm is None else inv_perm)
     K = torch.zeros((S, 3, 3), dtype=torch.float64, device=pts.device)
     K[:, 0, 0] = K[:, 1, 1] = prob.intr[idx, 0]
     K[:, 0, 2] = prob.intr[idx, 1]

@@ -30,7 +30,7 @@
 namespace vgg {
 
 int cholesky_solve_enqueue(double* A, double* b, int n, double* inv_blocks, int32_t* device_fail, const int32_t* skip_flag,
-                           hipStream_t st, const CholOverlap* overlap);
+                           hipStream_t st, const CholOverlap* overlap, int split_a, int split_b);
 size_t cholesky_workspace_bytes(int n);
 
 constexpr int kGroup = 16;       // cameras per Schur tile side
@@ -1275,6 +1275,7 @@ struct Launch {
   const int32_t* chunk_desc; const int32_t* entries; int num_chunks, num_segments;
   const int32_t* tile_desc; int num_tiles;
   const int32_t* batches; int num_batches;      // HOST table [num_batches][6], see vgg_ba_problem.tile_batches
+  int chol_split_a, chol_split_b;               // block-diagonal leading part of the reduced system (0 = none)
   double *cam_q, *cam_t, *intr, *pts;
 };
 
@@ -1423,13 +1424,14 @@ static int phase_step(const Launch& L) {
     }
     {
       ProfScope ps(kProfCholesky, oc->st_chol);
-      rc = cholesky_solve_enqueue(L.w.S, L.w.rhs, d.n_red, L.w.chol_inv, &L.w.ctl->linear_fail, &L.w.ctl->done, oc->st_chol, &ov);
+      rc = cholesky_solve_enqueue(L.w.S, L.w.rhs, d.n_red, L.w.chol_inv, &L.w.ctl->linear_fail, &L.w.ctl->done, oc->st_chol, &ov, 0, 0);
     }
     (void)hipEventRecord(oc->chol_done, oc->st_chol);
     (void)hipStreamWaitEvent(L.st, oc->chol_done, 0);
   } else {
     ProfScope ps(kProfCholesky, L.st);
-    rc = cholesky_solve_enqueue(L.w.S, L.w.rhs, d.n_red, L.w.chol_inv, &L.w.ctl->linear_fail, &L.w.ctl->done, L.st, nullptr);
+    rc = cholesky_solve_enqueue(L.w.S, L.w.rhs, d.n_red, L.w.chol_inv, &L.w.ctl->linear_fail, &L.w.ctl->done, L.st, nullptr,
+                                L.chol_split_a, L.chol_split_b);
   }
   if (rc != VGG_OK) return rc;
   cam_update_kernel<KD><<<div_up(d.C + 1, 64), 64, 0, L.st>>>(L.dp, L.w);
@@ -1467,6 +1469,10 @@ static int make_launch(const vgg_ba_problem* pb, const vgg_ba_options* opt, void
   L->chunk_desc = pb->chunk_desc; L->entries = pb->entries; L->num_chunks = pb->num_chunks;
   L->num_segments = pb->num_segments;
   L->batches = pb->tile_batches; L->num_batches = pb->num_tile_batches;
+  L->chol_split_a = pb->chol_split_a; L->chol_split_b = pb->chol_split_b;
+  if (pb->chol_split_a < 0 || pb->chol_split_b < 0 || pb->chol_split_a % 64 != 0 ||
+      pb->chol_split_a + pb->chol_split_b > 6 * pb->num_cams)
+    return VGG_ERR_INVALID_ARGUMENT;
   if (pb->num_chunks > 0) {
     if (!pb->tile_batches || pb->num_tile_batches < 1) return VGG_ERR_INVALID_ARGUMENT;
     int prev_c = 0, prev_t = 0, prev_g = 0;

@@ -163,11 +163,15 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
 // + one K = 64 trailing update instead of two of each (every launch has a ~4.5 us floor plus two dependent
 // memory round trips).  Requires k0 + 64 <= n.  Workgroup = 256 threads for the two 32x32 factorisations;
 // wavefront 0 owns 64 panel rows (one per lane, 64 registers), wavefront 1 solves the 32 rows of L21.
-__global__ __launch_bounds__(256) void chol_panel2_kernel(double* __restrict__ A, int n, int nrows, int k0,
+// blockIdx.y selects one of TWO independent panels (k0 or k0_second) of the same launch: when the leading part of the
+// matrix is block diagonal (column sets A and B with A[B rows][A cols] = 0, see cholesky_solve_enqueue) the panels of
+// the two blocks do not depend on each other and their ~40 us pivot chains run side by side.
+__global__ __launch_bounds__(256) void chol_panel2_kernel(double* __restrict__ A, int n, int nrows, int k0_first,
                                                           int32_t* fail, const int32_t* skip,
                                                           double* __restrict__ inv_blocks,
-                                                          const double* __restrict__ S2) {
+                                                          const double* __restrict__ S2, int k0_second) {
   constexpr int NB = 32, LD = NB + 1;
+  const int k0 = blockIdx.y ? k0_second : k0_first;
   __shared__ double D1[NB * LD], D2[NB * LD], L21[NB * LD];
   __shared__ double rd1[NB], rd2[NB];
   if (skip && *skip) return;
@@ -499,7 +503,7 @@ size_t cholesky_workspace_bytes(int n) {
 // perform the forward substitution for free and only L^T y = z is left.
 template <int NB>
 static int enqueue(double* A, double* b, int n, double* inv_blocks, int32_t* device_fail, const int32_t* skip,
-                   hipStream_t st, const CholOverlap* ov) {
+                   hipStream_t st, const CholOverlap* ov, int split_a, int split_b) {
   int next_wait = 0;
   // before the panel over columns [k0, k1): wait for the producers of those columns; S2 only where it can be non-zero
   auto panel_s2 = [&](int k1) -> const double* {
@@ -517,20 +521,38 @@ static int enqueue(double* A, double* b, int n, double* inv_blocks, int32_t* dev
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)back_lds) != hipSuccess)
       lds_backward = false;
   }
-  int k0 = 0;
-  if (NB == 32) {
-    // fused double steps: 64 columns per (panel2, update<64>) pair while at least 64 columns remain
-    for (; k0 + 64 <= n; k0 += 64) {
-      const int rows_panel = nrows - k0 - 64;
-      const double* S2 = panel_s2(k0 + 64);
-      chol_panel2_kernel<<<(rows_panel > 0 ? div_up(rows_panel, 64) : 1) + 1, 256, 0, st>>>(A, n, nrows, k0, device_fail,
-                                                                                           skip, inv_blocks, S2);
-      if (rows_panel > 0 && k0 + 64 < n) {
-        const int T = div_up(rows_panel, 32);
+  // one fused double step: 64 columns = one panel launch + one K = 64 trailing update
+  auto fused_step = [&](int k0, int k0_second) {
+    const int rows_panel = nrows - k0 - 64;
+    const double* S2 = panel_s2((k0_second >= 0 ? k0_second : k0) + 64);
+    const dim3 grid((rows_panel > 0 ? div_up(rows_panel, 64) : 1) + 1, k0_second >= 0 ? 2 : 1);
+    chol_panel2_kernel<<<grid, 256, 0, st>>>(A, n, nrows, k0, device_fail, skip, inv_blocks, S2, k0_second);
+    for (int which = 0; which < (k0_second >= 0 ? 2 : 1); ++which) {
+      const int k = which ? k0_second : k0;
+      const int rows_below = nrows - k - 64;
+      if (rows_below > 0 && k + 64 < n) {
+        const int T = div_up(rows_below, 32);
         const int tiles = T * (T + 1) / 2;
-        chol_update_kernel<64><<<div_up(tiles, 4), 256, 0, st>>>(A, n, nrows, k0, tiles, skip);
+        chol_update_kernel<64><<<div_up(tiles, 4), 256, 0, st>>>(A, n, nrows, k, tiles, skip);
       }
     }
+  };
+  int k0 = 0;
+  if (NB == 32) {
+    // Block-diagonal leading part (split_a, split_b > 0): the column sets A = [0, split_a) and B = [split_a, split_a +
+    // split_b) do not couple (A[B rows][A cols] = 0 -- the caller ordered the unknowns that way, ba.py), so panel s of A
+    // and panel s of B are independent: they share one launch and their pivot chains run side by side.  The trailing
+    // updates stay separate launches (an A panel has zeros in the rows of B, so its update leaves B's columns
+    // bit-for-bit untouched).  What is left of A, then of B, then everything else follows in the usual order.
+    int lock = 0;
+    if (!ov && split_a >= 64 && split_b >= 64 && split_a % 64 == 0 && split_a + split_b <= n) lock = min(split_a, split_b) / 64;
+    for (int s2 = 0; s2 < lock; ++s2) fused_step(64 * s2, split_a + 64 * s2);
+    if (lock > 0) {
+      for (k0 = 64 * lock; k0 + 64 <= split_a; k0 += 64) fused_step(k0, -1);     // the rest of A (a multiple of 64)
+      k0 = split_a + 64 * lock;                                                  // the rest of B and everything behind it
+    }
+    // fused double steps while at least 64 columns remain
+    for (; k0 + 64 <= n; k0 += 64) fused_step(k0, -1);
   }
   for (; k0 < n; k0 += NB) {
     const int nb = (n - k0 < NB) ? n - k0 : NB;
@@ -554,9 +576,9 @@ static int enqueue(double* A, double* b, int n, double* inv_blocks, int32_t* dev
 }
 
 int cholesky_solve_enqueue(double* A, double* b, int n, double* inv_blocks, int32_t* device_fail, const int32_t* skip,
-                           hipStream_t st, const CholOverlap* overlap) {
+                           hipStream_t st, const CholOverlap* overlap, int split_a, int split_b) {
   if (!inv_blocks) return VGG_ERR_INVALID_ARGUMENT;
-  return enqueue<32>(A, b, n, inv_blocks, device_fail, skip, st, overlap);
+  return enqueue<32>(A, b, n, inv_blocks, device_fail, skip, st, overlap, split_a, split_b);
 }
 
 }  // namespace vgg
@@ -566,6 +588,13 @@ size_t vgg_cholesky_workspace_bytes(int n) { return n > 0 ? vgg::cholesky_worksp
 
 int vgg_cholesky_solve(double* A, double* b, int n, void* workspace, int32_t* device_fail, void* stream) {
   if (n <= 0 || !A || !b || !workspace) return VGG_ERR_INVALID_ARGUMENT;
-  return vgg::cholesky_solve_enqueue(A, b, n, (double*)workspace, device_fail, nullptr, (hipStream_t)stream, nullptr);
+  return vgg::cholesky_solve_enqueue(A, b, n, (double*)workspace, device_fail, nullptr, (hipStream_t)stream, nullptr, 0, 0);
+}
+
+int vgg_cholesky_solve_split(double* A, double* b, int n, int split_a, int split_b, void* workspace, int32_t* device_fail,
+                             void* stream) {
+  if (n <= 0 || !A || !b || !workspace || split_a < 0 || split_b < 0 || split_a + split_b > n) return VGG_ERR_INVALID_ARGUMENT;
+  return vgg::cholesky_solve_enqueue(A, b, n, (double*)workspace, device_fail, nullptr, (hipStream_t)stream, nullptr, split_a,
+                                     split_b);
 }
 }

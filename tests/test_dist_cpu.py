@@ -107,3 +107,41 @@ def test_gloo_world2_sharded_camera_blocks_sum_to_global():
     np.testing.assert_allclose(buf[:-1].reshape(6, 8), g, rtol=1e-12, atol=1e-9)
     np.testing.assert_allclose(buf[-1], cost, rtol=1e-12)
     assert gmax <= np.abs(g).max() * 1.0000001 + 1e-12
+
+
+def _split_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # rank 0 sees sliding-window tracks; rank 1 additionally owns ONE track that joins the first and the last cameras
+    sc = make_scene(200, 1500, "SIMPLE_RADIAL", shared_camera=True, seed=3, track_seed=100 + rank)
+    mask = torch.from_numpy(sc.mask.copy())
+    if rank == 1:
+        mask[:, 0] = False
+        mask[[0, 199], 0] = True
+    alone = BA.find_camera_split(mask)
+    reduced = BA.find_camera_split(mask, adjacency_reduce=lambda t: dist.all_reduce(t, op=dist.ReduceOp.MAX))
+    out.put((rank, None if alone[0] is None else alone[0].tolist(), alone[1],
+             None if reduced[0] is None else reduced[0].tolist(), reduced[1]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_camera_split_is_agreed_between_ranks():
+    """The camera ordering [A, B, rest] must hold for the SUM of the ranks' reduced systems: every rank takes the
+    MAX-all-reduced group adjacency, so both end up with the same answer -- here "no split", because rank 1 owns a track
+    that couples the first and the last cameras, although rank 0 alone would have split."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_split_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, alone0, split0, red0, rsplit0), (_, alone1, split1, red1, rsplit1) = res
+    assert alone0 is not None and split0[0] % 64 == 0 and alone1 is None
+    assert red0 == red1 and rsplit0 == rsplit1 == (0, 0) and red0 is None

@@ -1,0 +1,71 @@
+"""CPU: small host-side mirrors checked against the REFERENCE's own functions, imported through the stub harness when
+/root/reference exists (this container; skipped on the GPU box): window / grid helpers of the runner
+(vggsfm/utils/utils.py:773-839) and the similarity alignment of the video path (vggsfm/utils/align.py:145-252)."""
+import pytest
+import torch
+
+from oracle import ref_harness
+from vggsfm_amd import video as V
+from vggsfm_amd.runners import generate_grid_samples, sample_subrange
+
+pytestmark = pytest.mark.skipif(not ref_harness.available(), reason="reference tree not present (GPU box)")
+
+
+def test_sample_subrange_and_grid_match_reference():
+    ref_harness.install()
+    from vggsfm.utils.utils import generate_grid_samples as ref_grid
+    from vggsfm.utils.utils import sample_subrange as ref_sub
+    for N in range(1, 40):
+        for L in range(1, 45):
+            for idx in range(N):
+                assert sample_subrange(N, idx, L) == ref_sub(N, idx, L), (N, idx, L)
+    for rect in ([[3.0, 7.0, 515.0, 300.0]], [[0.0, 0.0, 1024.0, 1024.0]], [[100.5, 20.25, 130.0, 700.0]]):
+        r = torch.tensor(rect)
+        for kw in (dict(N=500), dict(N=77), dict(N=2048), dict(pixel_interval=16), dict(pixel_interval=100), dict(pixel_interval=7)):
+            assert torch.equal(generate_grid_samples(r, **kw), ref_grid(r, **kw)), (rect, kw)
+
+
+def _rand_rot(n, g):
+    q = torch.randn(n, 4, generator=g, dtype=torch.float64)
+    w, x, y, z = (q / q.norm(dim=1, keepdim=True)).unbind(1)
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w),
+                        1 - 2 * (x * x + z * z), 2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w),
+                        1 - 2 * (x * x + y * y)], 1).reshape(n, 3, 3)
+
+
+def test_camera_alignment_matches_reference_bitwise():
+    ref_harness.install()
+    from vggsfm.utils.align import align_camera_extrinsics as ref_align
+    from vggsfm.utils.align import apply_transformation as ref_apply
+    g = torch.Generator().manual_seed(0)
+    for n in (2, 9, 17, 33):
+        src = torch.cat([_rand_rot(n, g), torch.randn(n, 3, 1, generator=g, dtype=torch.float64)], -1)
+        tgt = torch.cat([_rand_rot(n, g), torch.randn(n, 3, 1, generator=g, dtype=torch.float64)], -1)
+        a0, a1 = ref_align(src, tgt), V.align_camera_extrinsics(src, tgt)
+        for x, y in zip(a0, a1):
+            assert torch.equal(torch.as_tensor(x), torch.as_tensor(y))
+        assert torch.equal(ref_apply(src, *a0), V.apply_transformation(src, *a1))
+        for x, y in zip(ref_apply(src, *a0, return_extri=False), V.apply_transformation(src, *a1, return_extri=False)):
+            assert torch.equal(x, y)
+
+
+def test_get_EFP_and_sample_features4d_match_reference_bitwise():
+    """vggsfm/models/utils.py:38-72 (cameras -> [R t], K with the clamped one-dof focal) and :415-447 (bilinear colour
+    lookup) -- the two edge functions of the Triangulator drop-in."""
+    import types
+
+    ref_harness.install()
+    from vggsfm.models.utils import get_EFP as ref_efp
+    from vggsfm.models.utils import sample_features4d as ref_sample
+    from vggsfm_amd.models.utils import get_EFP, sample_features4d
+    g = torch.Generator().manual_seed(1)
+    for S, size in ((7, (1024.0, 768.0)), (3, (512.0, 512.0))):
+        cams = types.SimpleNamespace(R=torch.randn(S, 3, 3, generator=g), T=torch.randn(S, 3, generator=g),
+                                     focal_length=torch.rand(S, 2, generator=g) * 12 + 0.01)      # some hit the clamp
+        for default_focal in (False, True):
+            a = ref_efp(cams, torch.tensor(size), 1, S, default_focal=default_focal)
+            b = get_EFP(cams, torch.tensor(size), 1, S, default_focal=default_focal)
+            assert all(torch.equal(x, y) for x, y in zip(a, b))
+    img = torch.rand(2, 3, 40, 50, generator=g)
+    co = torch.rand(2, 30, 2, generator=g) * torch.tensor([49.0, 39.0])
+    assert torch.equal(ref_sample(img, co), sample_features4d(img, co))

@@ -247,8 +247,9 @@ int vgg_p3p_ransac(const double* points2D_normalized, const double* points3D, co
 
 /* Two-view stage in front of the path: estimate_fundamental = 7-point RANSAC + 8-point local
  * optimisation for all (query frame, other frame) pairs at once   vggsfm/two_view_geo/fundamental.py:43-183,
- * two_view_geo/utils.py:63-298; caller estimate_preliminary.py:103-152 (-> fmat_inlier_mask).  PARITY UNPINNED vs the
- * reference (kornia absent, float32 SVDs, numpy RNG, poselib by default -- oracle/fundamental.py); float64 here.
+ * two_view_geo/utils.py:63-298; caller estimate_preliminary.py:103-152 (-> fmat_inlier_mask).  PARITY PARTLY PINNED
+ * (oracle/fundamental.py: Sampson distance, 8-point fit and winner selection checked against the reference's own functions;
+ * the 7-point solver and the RNG are not -- kornia is absent); float64 here.
  * points1 / points2 [num_pairs][num_points][2] f64 pixels; valid_mask [num_pairs][num_points] uint8 or NULL
  * (matches with vis >= 0.05 and score >= 0.5, estimate_preliminary.py:118-126); matrices are 9 doubles row-major,
  * unit Frobenius norm, x2^T F x1 = 0.

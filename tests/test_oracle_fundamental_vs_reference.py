@@ -1,0 +1,99 @@
+"""CPU, only where /root/reference exists: the pieces of the two-view oracle that CAN be pinned against the reference's
+own code.  vggsfm/two_view_geo imports kornia at module level (absent here: the import harness fabricates it), so the
+reference functions run with kornia's five trivial helpers restated below (homogeneous padding, a 3x3 transform of
+points, division by F[2,2], and aliases of torch.cat / stack / ones_like / zeros / where); what is compared is the
+reference's OWN arithmetic:
+
+    sampson_epipolar_distance_batched (utils.py:90-172, float32)   vs  oracle sampson_sq
+    run_8point + normalize_points_masked (fundamental.py:261-334, utils.py:175-253)  vs  oracle eight_point
+    local_refinement's mask gathering (utils.py:256-298)            vs  the oracle's selection of inlier sets
+    calculate_residual_indicator + argmax (utils.py:63-87, fundamental.py:162-176)   vs  oracle _best
+
+Not pinnable: run_7point (needs kornia's solve_cubic / normalize_points) and the RNG."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fundamental as Fd
+from oracle import ref_harness
+from tests.test_oracle_fundamental import two_view
+
+pytestmark = pytest.mark.skipif(not ref_harness.available(), reason="reference tree not present (GPU box)")
+
+
+def _reference_modules():
+    ref_harness.install()
+    import vggsfm.two_view_geo.fundamental as rf
+    import vggsfm.two_view_geo.utils as ru
+
+    def to_h(p):
+        return torch.cat([p, torch.ones_like(p[..., :1])], -1)
+
+    def transform_points(T, p):                       # kornia.geometry.linalg.transform_points for affine 3x3 T
+        q = to_h(p) @ T.transpose(-2, -1)
+        return q[..., :2] / q[..., 2:]
+
+    def normalize_transformation(M, eps=1e-8):        # kornia.geometry.epipolar.normalize_transformation
+        nv = M[..., -1:, -1:]
+        return torch.where(nv.abs() > eps, M / (nv + eps), M)
+    for mod in (rf, ru):
+        mod.ones_like, mod.stack, mod.zeros, mod.where, mod.concatenate = torch.ones_like, torch.stack, torch.zeros, torch.where, torch.cat
+        mod.normalize_transformation = normalize_transformation
+        mod.Tensor = torch.Tensor                     # (kornia.core.Tensor is torch.Tensor)
+    ru.convert_points_to_homogeneous = to_h
+    ru.transform_points = transform_points
+    return rf, ru
+
+
+def _unit(F):
+    F = F / np.linalg.norm(F, axis=(-2, -1), keepdims=True)
+    return F * np.sign(F[..., 2, 2])[..., None, None]
+
+
+def test_sampson_distance_matches_reference():
+    rf, ru = _reference_modules()
+    x1, x2, _, Ft = two_view(500, 4)
+    rng = np.random.default_rng(0)
+    F = np.stack([Ft + 0.02 * rng.normal(size=(3, 3)) * np.abs(Ft).max() for _ in range(6)])
+    ref = ru.sampson_epipolar_distance_batched(torch.from_numpy(x1).float()[None], torch.from_numpy(x2).float()[None],
+                                               torch.from_numpy(F).float()[None], squared=True)[0].double().numpy()
+    mine = Fd.sampson_sq(F, x1, x2)
+    np.testing.assert_allclose(mine, ref, rtol=2e-2, atol=1e-3)                     # (the reference computes in float32)
+    assert np.median(np.abs(mine - ref) / (np.abs(ref) + 1e-6)) < 1e-4
+
+
+def test_eight_point_and_mask_gathering_match_reference():
+    rf, ru = _reference_modules()
+    x1, x2, out, Ft = two_view(800, 6)
+    rng = np.random.default_rng(1)
+    K, lo = 12, 5
+    inl = rng.random((K, 800)) < 0.7
+    inl[:, out] = False
+    order = Fd._order(inl.sum(1).astype(np.int64))                                   # stable descending, like torch.sort
+    t1, t2 = torch.from_numpy(x1)[None], torch.from_numpy(x2)[None]
+    ref = ru.local_refinement(rf.run_8point, t1, t2, torch.from_numpy(inl)[None], torch.from_numpy(order)[None], lo_num=lo)
+    ref = ref[0].numpy()                                                              # (lo,3,3), scaled to F[2,2] = 1
+    mine, ok = Fd.eight_point(x1, x2, inl[order[:lo]])
+    assert ok.all()
+    np.testing.assert_allclose(_unit(mine), _unit(ref), atol=2e-8)
+    # both enforce rank 2 and describe the scene
+    assert np.abs(np.linalg.det(_unit(ref))).max() < 1e-12 and np.abs(np.linalg.det(mine)).max() < 1e-12
+    assert np.abs(_unit(mine) - _unit(Ft[None])).max() < 5e-3
+
+
+def test_winner_selection_matches_reference():
+    rf, ru = _reference_modules()
+    rng = np.random.default_rng(2)
+    for trial in range(20):
+        B, K, N, thr = 3, 40, 60, 1.0
+        res = rng.uniform(0, 3, size=(B, K, N))
+        res[:, rng.integers(0, K, 5)] = 7.0                                          # hypotheses without inliers
+        res[:, 3] = res[:, 1]                                                        # an exact tie: the first wins
+        ind, num, mask = ru.calculate_residual_indicator(torch.from_numpy(res), thr)
+        ref_best = torch.argmax(ind, dim=1).numpy()
+        for b in range(B):
+            inl = res[b] <= thr
+            cnt = inl.sum(1).astype(np.int64)
+            rs = np.where(inl, res[b], 0.0).sum(1)
+            assert Fd._best(cnt, rs) == ref_best[b]
+            assert np.array_equal(num[b].numpy(), cnt) and np.array_equal(mask[b].numpy(), inl)

@@ -3,8 +3,8 @@
 // its helpers two_view_geo/utils.py:63-298, caller estimate_preliminary.py:103-152 (-> fmat_inlier_mask, the input
 // of the Triangulator).  SURVEY.md section 8(f).3.
 //
-// PARITY UNPINNED against the reference (oracle/fundamental.py header: kornia is absent, float32 SVDs, numpy RNG,
-// poselib by default); this file and oracle/fundamental.py agree bit for bit: float64, no FMA contraction
+// PARITY PARTLY PINNED (oracle/fundamental.py header: Sampson distance, 8-point fit and winner selection are checked
+// against the reference's own functions; the 7-point solver and the RNG are not); this file and the oracle agree bit for bit: float64, no FMA contraction
 // (-ffp-contract=off), no transcendental functions, every sum in a fixed order.
 //
 //   fmat7_kernel        one thread per (pair, 7-point sample): normalise, null space of the 7x9 system by Gauss-Jordan

@@ -8,8 +8,10 @@ Sampson residuals in float32 (``autocast``), draws its 7-point samples from nump
 (cfg.use_poselib) is not even used: poselib's LO-RANSAC runs on the CPU instead.  tests/test_oracle_fundamental_vs_reference.py
 runs the reference's OWN functions (with kornia's five trivial helpers restated) against this file: the Sampson
 distance, the 8-point fit with its masked normalisation, the gathering of the inlier sets for the local optimisation
-and the winner selection agree (2e-8 on the matrices in float64; the reference's float32 residuals to 1e-4).  NOT
-pinned: the 7-point solver (kornia's solve_cubic / normalize_points are needed to run the reference's) and the RNG.
+and the winner selection agree (2e-8 on the matrices in float64; the reference's float32 residuals to 1e-4); so does
+the 7-point stage -- null-space pencil, cubic coefficients, scaling, de-normalisation -- run in the reference's float32
+with kornia's normalize_points restated and its solve_cubic replaced by numpy.roots (median 1e-4 on unit-norm matrices).
+NOT pinned: kornia's own cubic solver and the RNG.
 What is restated is the algorithm as the reference states
 it, in float64:
 

@@ -97,3 +97,44 @@ def test_winner_selection_matches_reference():
             rs = np.where(inl, res[b], 0.0).sum(1)
             assert Fd._best(cnt, rs) == ref_best[b]
             assert np.array_equal(num[b].numpy(), cnt) and np.array_equal(mask[b].numpy(), inl)
+
+
+def test_seven_point_pencil_matches_reference_modulo_the_cubic_solver():
+    """run_7point (fundamental.py:339-469) with kornia's normalize_points restated and its solve_cubic replaced by
+    numpy.roots (real roots, zeros elsewhere): the null-space pencil, the cubic's coefficients, the F[2,2] = 1 scaling and
+    the de-normalisation are the reference's own arithmetic.  Every matrix the oracle reports must be one of the
+    reference's (the reference also emits a junk matrix per non-real root, which the oracle flags invalid instead)."""
+    rf, ru = _reference_modules()
+
+    def normalize_points(points, eps=1e-8):           # kornia.geometry.epipolar.normalize_points
+        mean = points.mean(-2, keepdim=True)
+        scale = (points - mean).norm(dim=-1, p=2).mean(-1)
+        scale = torch.sqrt(torch.tensor(2.0)) / (scale + eps)
+        o, z = torch.ones_like(scale), torch.zeros_like(scale)
+        T = torch.stack([scale, z, -scale * mean[..., 0, 0], z, scale, -scale * mean[..., 0, 1], z, z, o], -1).view(-1, 3, 3)
+        return ru.transform_points(T, points), T
+
+    def solve_cubic(coeffs):
+        out = torch.zeros(coeffs.shape[0], 3, dtype=coeffs.dtype)
+        for i, c in enumerate(coeffs.numpy()):
+            r = np.roots(c)
+            r = np.sort(r[np.abs(r.imag) < 1e-10].real)
+            out[i, :len(r)] = torch.from_numpy(r)
+        return out
+    rf.normalize_points, rf.solve_cubic = normalize_points, solve_cubic
+    rf.KORNIA_CHECK_SHAPE = lambda *a, **k: None
+    x1, x2, _, Ft = two_view(400, 8, outliers=0.0, noise=0.2)
+    rng = np.random.default_rng(3)
+    smp = np.stack([rng.choice(400, 7, replace=False) for _ in range(150)])
+    # (the reference's last assignment casts to float32, so the function only runs in float32)
+    ref = rf.run_7point(torch.from_numpy(x1[smp]).float(), torch.from_numpy(x2[smp]).float()).double().numpy()   # (150,3,3,3)
+    mine, ok = Fd.seven_point(x1[smp], x2[smp])
+    assert ok.any(1).all()
+    ru_ = _unit(ref)
+    dist = []
+    for h in range(150):
+        for s in range(3):
+            if ok[h, s]:
+                dist.append(np.abs(ru_[h] - _unit(mine[h, s])[None]).max((-1, -2)).min())
+    dist = np.array(dist)
+    assert len(dist) >= 150 and np.median(dist) < 1e-4 and (dist < 5e-3).mean() > 0.97, (np.median(dist), np.sort(dist)[-8:])

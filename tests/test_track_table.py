@@ -1,9 +1,11 @@
-"""vggsfm_amd.track_table.TrackTable against a literal restatement of the reference's dict bookkeeping
+"""vggsfm_amd.track_table.TrackTable against the reference's dict bookkeeping -- its own methods where the reference tree
+is present (this container), and a literal restatement of them everywhere
 (vggsfm/runners/video_runner.py:354-473 ``convert_pred_to_point_frame_dict`` / ``_update_points_to_dict``,
 543-605 ``dicts_to_reconstruction``, 607-638 ``reconstruction_to_dicts``)."""
 from collections import defaultdict
 
 import numpy as np
+import pytest
 import torch
 
 from vggsfm_amd.track_table import TrackTable
@@ -73,9 +75,40 @@ def _compare(tt, oracle):
             assert bool(tt.has_extri[f]) and torch.equal(tt.extri[f], fd["extri"].double())
 
 
-def test_track_table_matches_dict_bookkeeping():
+class ReferenceDicts:
+    """The reference's OWN ``VideoRunner.convert_pred_to_point_frame_dict`` / ``_update_points_to_dict`` bound to a bare
+    instance (no models, no config) -- available where /root/reference exists."""
+
+    def __init__(self):
+        from oracle import ref_harness
+        ref_harness.install()
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            from vggsfm.runners.video_runner import VideoRunner
+        self.vr = object.__new__(VideoRunner)
+        self.vr.point_dict, self.vr.frame_dict = {}, defaultdict(dict)
+
+    point_dict = property(lambda self: self.vr.point_dict)
+    frame_dict = property(lambda self: self.vr.frame_dict)
+
+    def convert_pred(self, pred, start_idx, end_idx):
+        self.vr.convert_pred_to_point_frame_dict(pred, start_idx, end_idx)
+
+    def update(self, start_idx, end_idx, valid_2D_mask, pred_track, pred_vis, points3D_idx, mapping=None):
+        self.vr._update_points_to_dict(start_idx, end_idx, valid_2D_mask, pred_track, pred_vis, points3D_idx,
+                                       point_to_track_mapping=mapping)
+
+
+def _oracles():
+    from oracle import ref_harness
+    return [DictOracle] + ([ReferenceDicts] if ref_harness.available() else [])
+
+
+@pytest.mark.parametrize("make_oracle", _oracles())
+def test_track_table_matches_dict_bookkeeping(make_oracle):
     gen = torch.Generator().manual_seed(0)
-    tt, oracle = TrackTable(device="cpu"), DictOracle()
+    tt, oracle = TrackTable(device="cpu"), make_oracle()
     # first window (frames 0..8): new points
     p0 = _pred(gen, 9, 60, 40)
     tt.add_window_prediction(p0, 0, 9)
@@ -104,9 +137,10 @@ def test_track_table_matches_dict_bookkeeping():
     _compare(tt, oracle)
 
 
-def test_window_tensors_and_reset():
+@pytest.mark.parametrize("make_oracle", _oracles())
+def test_window_tensors_and_reset(make_oracle):
     gen = torch.Generator().manual_seed(1)
-    tt, oracle = TrackTable(device="cpu"), DictOracle()
+    tt, oracle = TrackTable(device="cpu"), make_oracle()
     p0 = _pred(gen, 6, 30, 30)
     tt.add_window_prediction(p0, 2, 8)
     oracle.convert_pred(p0, 2, 8)

@@ -96,13 +96,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")
-    dev = torch.device("cuda", local_rank)
+    # VGGSFM_BENCH_BACKEND=gloo: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (ranks share
+    # devices, collectives go through the host) -- for checking the flow, not for numbers
+    backend = os.environ.get("VGGSFM_BENCH_BACKEND", "nccl")
+    dev = torch.device("cuda", local_rank if backend == "nccl" else local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     S, N, cam_type, shared = WORKLOADS[args.workload]
     sc = make_scene(S, N, cam_type, shared_camera=shared, seed=0, track_seed=1000 + rank)

@@ -67,6 +67,13 @@ def main():
     tri, helpers, dist = ref_harness.load()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    only = sys.argv[1:]                 # e.g. `python -m oracle.gen_golden s200_chunked s400_chunked`: just those LO-RANSAC cases
+    if not only:
+        geometry_goldens(tri, helpers)
+    triangulation_goldens(tri, helpers, only)
+
+
+def geometry_goldens(tri, helpers):
 
     # ---------------- projection / normalisation / filter ----------------
     for name, cam_type, S, N in [("pinhole", "SIMPLE_PINHOLE", 8, 256), ("radial", "SIMPLE_RADIAL", 12, 200)]:
@@ -100,6 +107,9 @@ def main():
                         points=p3.numpy(), cheirality=che.numpy(), angle=ang.numpy())
     print("wrote tri_by_pair")
 
+
+
+def triangulation_goldens(tri, helpers, only=()):
     # ---------------- triangulate_tracks (LO-RANSAC) ----------------
     cases = [
         # name, S, N, camera, max_ransac_iters, max_tri_points_num, seed
@@ -107,8 +117,14 @@ def main():
         ("s30_randperm", 30, 160, "SIMPLE_PINHOLE", 256, 819200, 12),      # 435 pairs -> 256 sampled
         ("s30_it128", 30, 96, "SIMPLE_RADIAL", 128, 819200, 13),           # iterative_global_BA setting
         ("s24_chunked", 24, 200, "SIMPLE_PINHOLE", 256, 2000, 14),         # 3 chunks, one randperm each
+        # the view counts of BASELINE configs[2] / [3] (the kernel's large-S regime: 2 wavefronts/SIMD, wave-uniform view
+        # loops, several reference chunks in one launch); ~1-3 min of reference CPU time each
+        ("s200_chunked", 200, 480, "SIMPLE_RADIAL", 256, 200 * 160, 15),   # 3 chunks of 160 tracks
+        ("s400_chunked", 400, 320, "SIMPLE_RADIAL", 256, 400 * 160, 16),   # 2 chunks of 160 tracks
     ]
     for name, S, N, cam_type, iters, max_pts, seed in cases:
+        if only and name not in only:
+            continue
         sc = make_scene(S, N, cam_type, shared_camera=(cam_type == "SIMPLE_RADIAL"), seed=seed,
                         outlier_frac=0.10)
         ext, K, extra, _ = perturb_for_ba(sc, seed=seed, rot_deg=0.1, trans=0.005, focal_rel=0.002)

@@ -33,7 +33,19 @@ CASES = {
     # S >= 24: C(S,2) > 256, so every triangulate_tracks call draws one torch.randperm from the global CPU RNG
     # (vggsfm/utils/triangulation.py:804-813); the drop-in must consume the same draws in the same order
     "radial_s26_randperm": (26, 400, "SIMPLE_RADIAL", False, 34, dict(BA_iters=2, robust_refine=1)),
+    # BASELINE configs[1] at full size (50 frames x 20k tracks, per-frame SIMPLE_PINHOLE): ~40 min of reference CPU time.
+    # Stored COMPACT: the inputs are regenerated from the seed by inputs() (a sha256 of them is kept), only outputs are saved.
+    "pinhole_s50_c2": (50, 20000, "SIMPLE_PINHOLE", False, 35, dict(BA_iters=1, robust_refine=1)),
 }
+COMPACT = {"pinhole_s50_c2"}
+
+
+def input_digest(inp):
+    import hashlib
+    h = hashlib.sha256()
+    for k in sorted(inp):
+        h.update(np.ascontiguousarray(inp[k]).tobytes())
+    return h.hexdigest()
 
 
 def inputs(S, N, cam, shared, seed, W=1024):
@@ -81,9 +93,11 @@ def main():
         ext, K, extra, pts, rgb, rec, vframes, v2d, vtracks = out
         print(name, "valid tracks", int(vtracks.sum()), "of", N, "solver calls", len(pycolmap_shim.CALLS),
               [c[1]["num_iterations"] for c in pycolmap_shim.CALLS if c[0] == "bundle_adjustment"])
+        stored = dict(S=np.int64(S), N=np.int64(N), seed=np.int64(seed), input_sha256=input_digest(inp), W=inp["W"]) \
+            if name in COMPACT else inp
         np.savez_compressed(
             os.path.join(OUT, f"triangulator_{name}.npz"), camera_type=cam, shared=shared,
-            kw_keys=np.array(list(kw.keys())), kw_vals=np.array(list(kw.values())), **inp,
+            kw_keys=np.array(list(kw.keys())), kw_vals=np.array(list(kw.values())), **stored,
             out_extrinsics=ext.numpy(), out_intrinsics=K.numpy(),
             out_extra=np.zeros((0,)) if extra is None else extra.numpy(), out_points3D=pts.numpy(),
             out_rgb=rgb.numpy(), out_valid_frames=vframes.numpy(), out_valid_2D=v2d.numpy(),

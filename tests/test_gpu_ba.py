@@ -136,14 +136,27 @@ CASES = [
     (50, 2000, "SIMPLE_PINHOLE", False, "prep"),
     (70, 1200, "SIMPLE_RADIAL", True, "prep"),
     (2, 200, "SIMPLE_PINHOLE", False, "prep"),       # init_BA shape: two frames
+    # BASELINE configs[1] at FULL size (50 frames x 20k tracks, per-frame SIMPLE_PINHOLE, n = 350) and the camera
+    # configuration of configs[2] (200 frames, shared SIMPLE_RADIAL, n = 1202) at 10k tracks: 12 LM iterations each
+    # (the CPU port needs ~1 s per iteration here)
+    (50, 20000, "SIMPLE_PINHOLE", False, "prep12"),
+    (200, 10000, "SIMPLE_RADIAL", True, "prep12"),
 ]
 
 
 def _oracle_opts(kind):
+    if kind == "prep12":
+        o = OB.prepare_ba_options()
+        o.max_num_iterations = 12
+        return o
     return OB.prepare_ba_options() if kind == "prep" else OB.ceres_options()
 
 
 def _gpu_opts(kind):
+    if kind == "prep12":
+        o = prepare_ba_options()
+        o.solver_options.max_num_iterations = 12
+        return o
     return prepare_ba_options() if kind == "prep" else BundleAdjustmentOptions()
 
 

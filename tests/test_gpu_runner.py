@@ -96,6 +96,10 @@ def test_sparse_reconstruct_from_tracks_with_extra_points(tmp_path):
     np.testing.assert_allclose(Ko[:, 0, 0], 2.0 * K[:, 0, 0], rtol=0.03)
     assert (Ko[:, 0, 2] == 1024).all() and (Ko[:, 1, 2] == 768).all()
     rec = pred["reconstruction"]
-    assert rec.image_names == names and tuple(rec.camera_sizes[0]) == (2048, 1536)
+    assert [rec.images[i].name for i in range(S)] == names and (rec.cameras[0].width, rec.cameras[0].height) == (2048, 1536)
     rec.write(str(tmp_path))
-    assert (tmp_path / "points3D.bin").stat().st_size > 0
+    from vggsfm_amd.pycolmap_compat import Reconstruction
+    back = Reconstruction(str(tmp_path))                                           # COLMAP .bin reader
+    assert back.num_points3D() == rec.num_points3D() == n_sfm + n_add and back.num_reg_images() == S
+    assert all(back.points3D[p].track.length() == 0 for p in (n_sfm + 1, n_sfm + n_add))
+    assert np.array_equal(back.images[2].points2D._xy, rec.images[2].points2D._xy)

@@ -1,4 +1,4 @@
-"""COLMAP binary model writer (vggsfm_amd/reconstruction.py) vs the reference's own reader
+"""COLMAP binary model writer (vggsfm_amd/pycolmap_compat.py: Reconstruction.write) vs the reference's own reader
 (vggsfm/datasets/imc_helper.py, imported through the stub harness when /root/reference exists) and vs a
 minimal independent parser of the documented layout.  CPU only."""
 import os
@@ -15,8 +15,8 @@ from vggsfm_amd.scene import make_scene
 def _model(tmp_path, cam, shared):
     sc = make_scene(5, 40, cam, shared_camera=shared, seed=3)
     colors = (np.arange(40 * 3) % 255).reshape(40, 3).astype(np.uint8)
-    rec = Reconstruction(sc.points3D, sc.extrinsics, sc.intrinsics, sc.tracks, sc.mask, [1024, 1024], shared, cam,
-                         sc.extra_params, colors)
+    rec = Reconstruction.from_arrays(sc.points3D, sc.extrinsics, sc.intrinsics, sc.tracks, sc.mask, [1024, 1024],
+                                     shared_camera=shared, camera_type=cam, extra_params=sc.extra_params, colors=colors)
     rec.write(str(tmp_path))
     return sc, rec, colors
 
@@ -91,8 +91,9 @@ def test_tensor_to_pycolmap_drop_in_selection_rules():
     assert rec.num_points3D() == len(valid) and rec.num_images() == S
     assert sorted(rec.point3D_ids()) == list(range(1, len(valid) + 1))
     k3 = int(np.nonzero(valid == 3)[0][0])
-    assert not rec.masks[:, k3].any()                      # point 3 lies beyond max_points3D_val: no Point2D refers to it
-    assert (rec.intrinsics[:, 0, 0] == 500.0).all()        # shared camera = frame 0's
+    assert rec.points3D[k3 + 1].track.length() == 0        # point 3 lies beyond max_points3D_val: no Point2D refers to it
+    assert all((im.points2D._pid != k3 + 1).all() for im in rec.images.values())
+    assert len(rec.cameras) == 1 and rec.cameras[0].params[0] == 500.0        # shared camera = frame 0's
     p, e, Kb, xp = pycolmap_to_batch_matrix(rec, device="cpu", camera_type="SIMPLE_RADIAL")
     assert p.shape == (len(valid), 3) and e.shape == (S, 3, 4) and Kb.shape == (S, 3, 3) and xp.shape == (S, 1)
     assert np.array_equal(p.numpy(), pts[valid])
@@ -109,30 +110,37 @@ def test_runner_edits_roundtrip(tmp_path, shared):
     crop = np.zeros((1, 5, 8))
     crop[0, :, 0], crop[0, :, 1] = [1920, 1600, 1920, 1280, 1920], [1080, 1200, 1080, 960, 1080]       # real (w, h)
     crop[0, :, 4], crop[0, :, 5] = -3.0, -100.0                                                         # padded top-left
-    K_before, tracks_before = rec.intrinsics.copy(), rec.tracks.copy()
-    rec.rename_and_rescale(names, crop, 1024, shift_point2d_to_original_res=True)
+    from vggsfm_amd.runners import rename_colmap_recons_and_rescale_camera
+    f_before = {c: rec.cameras[c].params[0] for c in rec.cameras}
+    xy_before = {s: rec.images[s].points2D._xy.copy() for s in rec.images}
+    rename_colmap_recons_and_rescale_camera(rec, names, crop, 1024, shift_point2d_to_original_res=True, shared_camera=shared)
+    short = {p for p in range(40) if sc.mask[3, p] and sc.mask[:, p].sum() <= 2}   # these go with image 3 (COLMAP DeleteObservation)
     rec.deregister_image(3)
     rec.add_points3D(np.array([[1.0, 2.0, 3.0], [4.0, 5.0, 6.0]]), np.array([[9, 8, 7], [1, 2, 3]]))
-    assert rec.num_points3D() == 42
+    assert rec.num_points3D() == 42 - len(short)
     rec.write(str(tmp_path))
     ref_harness.install()
     from vggsfm.datasets.imc_helper import read_model
     cameras, images, points3D = read_model(str(tmp_path), ext=".bin")
-    assert len(images) == 4 and 3 not in images and len(points3D) == 42
+    assert len(images) == 4 and 3 not in images and len(points3D) == 42 - len(short)
     assert sorted(im.name for im in images.values()) == [names[s] for s in (0, 1, 2, 4)]
     ncam = 1 if shared else 5
     assert len(cameras) == ncam
     for c in range(ncam):
         ratio = max(crop[0, c, 0], crop[0, c, 1]) / 1024.0
-        np.testing.assert_allclose(cameras[c].params[0], ratio * K_before[c, 0, 0])
+        np.testing.assert_allclose(cameras[c].params[0], ratio * f_before[c])
         assert (cameras[c].width, cameras[c].height) == (int(crop[0, c, 0]), int(crop[0, c, 1]))
         assert tuple(cameras[c].params[1:3]) == (crop[0, c, 0] // 2, crop[0, c, 1] // 2)
     for s in (0, 1, 2, 4):
         ratio = max(crop[0, 0 if shared else s, 0], crop[0, 0 if shared else s, 1]) / 1024.0
+        np.testing.assert_allclose(images[s].xys, (xy_before[s] - np.array([3.0, 100.0])) * ratio)
         pids = np.nonzero(sc.mask[s])[0]
-        np.testing.assert_allclose(images[s].xys, (tracks_before[s, pids] - np.array([3.0, 100.0])) * ratio)
+        expect = np.array([-1 if p in short else p + 1 for p in pids])
+        assert np.array_equal(images[s].point3D_ids, expect)
     assert points3D[41].xyz.tolist() == [1.0, 2.0, 3.0] and points3D[42].rgb.tolist() == [1, 2, 3]
     assert len(points3D[41].image_ids) == 0
     # observations of the deregistered image are gone from the tracks
     for p in range(40):
-        assert 3 not in points3D[p + 1].image_ids.tolist()
+        if p not in short:
+            assert 3 not in points3D[p + 1].image_ids.tolist()
+            assert len(points3D[p + 1].image_ids) == int(sc.mask[:, p].sum()) - int(sc.mask[3, p])

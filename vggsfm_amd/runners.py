@@ -69,6 +69,36 @@ def sample_subrange(N, idx, L):
     return start, end
 
 
+def rename_colmap_recons_and_rescale_camera(reconstruction, image_paths, crop_params, img_size,
+                                            shift_point2d_to_original_res=False, shared_camera=False):
+    """``VGGSfMRunner.rename_colmap_recons_and_rescale_camera`` (runner.py:1009-1054) over the pycolmap object surface:
+    images get their file names; cameras go back to the original resolution -- focal x max(real size) / img_size,
+    principal point = real size // 2, width / height = real size (only the first camera met when `shared_camera`,
+    whose ratio then serves every image, as in the reference); optionally the 2D points too:
+    (xy - |crop top-left|) x ratio, one array operation per image.  crop_params (1,S,>=4) tensor:
+    [..., :2] real (w, h), [..., -4:-2] crop top-left."""
+    cp = crop_params.detach().cpu().numpy().astype(np.float64) if torch.is_tensor(crop_params) else np.asarray(crop_params, np.float64)
+    rescale_camera, resize_ratio = True, None
+    for image_id in reconstruction.images:
+        image = reconstruction.images[image_id]
+        camera = reconstruction.cameras[image.camera_id]
+        image.name = image_paths[image_id]
+        if rescale_camera:
+            real = cp[0, image_id, :2]
+            resize_ratio = float(real.max() / img_size)
+            params = camera.params.copy()
+            params[0] = resize_ratio * params[0]
+            params[1:3] = real // 2
+            camera.params = params
+            camera.width, camera.height = real[0], real[1]
+        if shift_point2d_to_original_res:
+            top_left = np.abs(cp[0, image_id, -4:-2])
+            image.points2D._xy[:] = (image.points2D._xy - top_left[None]) * resize_ratio
+        if shared_camera:
+            rescale_camera = False
+    return reconstruction
+
+
 class GeometryRunner:
     def __init__(self, cfg=None, triangulator=None):
         self.cfg = cfg or GeometryConfig()
@@ -125,7 +155,7 @@ class GeometryRunner:
             add_rgb = torch.cat([additional_points_dict[n]["points3D_rgb"] for n in image_paths], dim=0)
             additional_points_dict["sfm_points_num"] = len(points3D)
             additional_points_dict["additional_points_num"] = len(add_xyz)
-            if cfg.concat_extra_points:
+            if cfg.concat_extra_points:              # runner.py:549-559, all points at once (empty tracks)
                 reconstruction.add_points3D(add_xyz.cpu().numpy(), (add_rgb * 255).long().cpu().numpy())
                 points3D = torch.cat([points3D, add_xyz.to(points3D.dtype)], dim=0)
                 points3D_rgb = torch.cat([points3D_rgb, add_rgb.to(points3D_rgb.dtype)], dim=0)
@@ -149,12 +179,14 @@ class GeometryRunner:
         if back_to_original_resolution:
             if crop_params is None:
                 raise ValueError("back_to_original_resolution needs crop_params")
-            reconstruction.rename_and_rescale(image_paths, crop_params.cpu().numpy(), img_size,
-                                              shift_point2d_to_original_res=cfg.shift_point2d_to_original_res)
-            # intrinsics at the original resolution, in the order of the sorted image paths (runner.py:593-604)
-            name_to_id = {n: i for i, n in enumerate(reconstruction.image_names)}
-            K = np.stack([reconstruction.intrinsics[name_to_id[n]] for n in sorted(image_paths)])
-            intrinsics_opencv = torch.from_numpy(K).to(device)
+            reconstruction = rename_colmap_recons_and_rescale_camera(
+                reconstruction, image_paths, crop_params, img_size, shared_camera=cfg.shared_camera,
+                shift_point2d_to_original_res=cfg.shift_point2d_to_original_res)
+            # intrinsics at the original resolution, in the order of the sorted image paths (runner.py:593-608)
+            fname_to_id = {reconstruction.images[i].name: i for i in reconstruction.images}
+            K = [reconstruction.cameras[reconstruction.images[fname_to_id[n]].camera_id].calibration_matrix()
+                 for n in sorted(image_paths)]
+            intrinsics_opencv = torch.from_numpy(np.stack(K)).to(device)
         predictions.update(extrinsics_opencv=extrinsics_opencv, intrinsics_opencv=intrinsics_opencv, points3D=points3D,
                            points3D_rgb=points3D_rgb, reconstruction=reconstruction, extra_params=extra_params,
                            unproj_dense_points3D=None, valid_2D_mask=valid_2D_mask, pred_track=pred_track, pred_vis=pred_vis,

@@ -113,6 +113,25 @@ def triangulate_window_tracks(pred_track, pred_vis, pred_score, extrinsics, intr
     return fp, ft, fm, pred_vis[:, valid]
 
 
+def observation_filter(points3D, extrinsics, intrinsics, extra_params, tracks, masks, max_reproj_error, min_tri_angle):
+    """``ObservationManager.filter_all_points3D(max_reproj_error, min_tri_angle)`` +
+    ``filter_observations_with_negative_depth`` on dense tensors [COLMAP 3.10, observation_manager.cc]: an observation
+    is dropped when its squared reprojection error exceeds max^2 or its depth is not positive; a point is dropped when
+    fewer than 2 observations remain or when no pair of its remaining views subtends at least `min_tri_angle`
+    degrees.  points3D (P,3), cameras of the S frames, tracks (S,P,2), masks (S,P) -> (inlier (S,P) bool, keep (P,))."""
+    mk = masks.bool()
+    # per-observation reprojection / depth test (`detail`), then the triangulation-angle test over the survivors
+    _, detail = filter_all_points3D(points3D, tracks, extrinsics, intrinsics, extra_params,
+                                    max_reproj_error=max_reproj_error, check_triangle=False, return_detail=True,
+                                    hard_max=-1)
+    inl = mk & detail
+    keep, _ = filter_all_points3D(points3D, torch.where(inl[..., None], tracks, torch.full_like(tracks, 1e9)), extrinsics,
+                                  intrinsics, extra_params, max_reproj_error=max_reproj_error,
+                                  min_tri_angle=min_tri_angle, check_triangle=True, hard_max=-1)
+    keep = keep & (inl.sum(0) >= 2)
+    return inl & keep[None], keep
+
+
 def joint_bundle_adjustment(points3d, extrinsics, intrinsics, tracks, masks, extra_params=None,
                             camera_type="SIMPLE_RADIAL", reproj_error=2.0, tri_angle=1.5, normalize=True, options=None):
     """video_runner.py:494-541 on tensors: [normalize] -> pycolmap.bundle_adjustment (default options, shared camera)
@@ -132,15 +151,8 @@ def joint_bundle_adjustment(points3d, extrinsics, intrinsics, tracks, masks, ext
     p_opt, e_opt, K_opt, x_opt, summ = _ba.bundle_adjustment(pts, ext, K, tracks, masks, None, ep, True, camera_type,
                                                              options or BundleAdjustmentOptions())
     vi, deleted = summ["valid_idx"], summ["deleted"]
-    tr, mk = tracks[:, vi], masks[:, vi].bool()
-    # per-observation reprojection / depth test (`detail`), then the triangulation-angle test over the survivors
-    _, detail = filter_all_points3D(p_opt, tr, e_opt, K_opt, x_opt, max_reproj_error=reproj_error, check_triangle=False,
-                                    return_detail=True, hard_max=-1)
-    inl = mk & detail
-    keep, _ = filter_all_points3D(p_opt, torch.where(inl[..., None], tr, torch.full_like(tr, 1e9)), e_opt, K_opt, x_opt,
-                                  max_reproj_error=reproj_error, min_tri_angle=tri_angle, check_triangle=True,
-                                  hard_max=-1)
-    keep = keep & (inl.sum(0) >= 2) & ~deleted
+    inl, keep = observation_filter(p_opt, e_opt, K_opt, x_opt, tracks[:, vi], masks[:, vi], reproj_error, tri_angle)
+    keep = keep & ~deleted
     inl = inl & keep[None]
     if normalize:
         e_opt, p_opt = _ba.normalize_reconstruction(e_opt, p_opt, keep)

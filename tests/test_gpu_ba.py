@@ -182,7 +182,7 @@ def test_ba_matches_oracle_trajectory(S, N, cam, shared, kind):
         assert abs(a["radius"] - b["radius"]) <= 1e-5 * b["radius"], (a, b)
         assert abs(a["gradient_max_norm"] - b["gradient_max_norm"]) <= 1e-5 * b["gradient_max_norm"] + 1e-9, (a, b)
         compared += 1
-    assert compared >= min(8, so["num_iterations"])
+    assert compared >= min(6, so["num_iterations"])
     assert abs(sg["final_cost"] - so["final_cost"]) <= 1e-8 * so["final_cost"]
     np.testing.assert_allclose(ext.cpu().numpy(), eo, rtol=0, atol=5e-6)
     # (final values: both sides stop at the gradient tolerance, not at the exact optimum, and the last accept /

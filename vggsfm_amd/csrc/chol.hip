@@ -77,6 +77,67 @@ __device__ __forceinline__ void factor_diag_lds(double* D, double* rdiag, int32_
   __syncthreads();
 }
 
+// One double of lane `src` (compile-time constant after unrolling) as a wave-uniform value: two v_readlane_b32.
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// The same factorisation by ONE wavefront with the block in registers: lane i < 32 holds row i of the (symmetric) block,
+// no LDS round trip and no barrier per pivot column -- the multipliers of a column are broadcast with v_readlane.
+// Per column j: d_j = lane j's x[j]; m = x[j] / d_j (every lane: lane c now holds the multiplier of column c);
+// x[c] -= x[j] * m_c for c > j.  Arithmetic and order are those of factor_diag_lds (non-normalised outer product,
+// one Newton step on the pivot reciprocal, columns scaled by 1/sqrt(d_c) at the end): the factor is bit-identical.
+// (Opt-in experiment, see FACTOR_DIAG below: it measured no faster than the LDS version.)
+// D: LDS block (ld = NB + 1), lower triangle valid on entry, factor on exit; rdiag[j] = 1 / L_jj.
+// Must be called by all 64 lanes of one wavefront; the caller synchronises the workgroup afterwards.
+template <int NB>
+__device__ __forceinline__ void factor_diag_wave(double* D, double* rdiag, int32_t* fail_flag) {
+  static_assert(NB == 32, "one row per lane, lanes 0..31");
+  constexpr int LD = NB + 1;
+  const int lane = threadIdx.x & 63;
+  const int i = lane & (NB - 1);
+  double x[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) x[c] = D[(c <= i ? i * LD + c : c * LD + i)];      // full symmetric row
+  bool bad = false;
+  double myd = 1.0;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const double dj = readlane_f64(x[j], j);
+    if (!(dj > 0.0) || !(dj < 1.7976931348623157e308)) bad = true;
+    if (i == j) myd = x[j];
+    if (j < NB - 1) {
+      const double inv = fast_rcp<1>((dj > 0.0) ? dj : 1.0);
+      const double m = x[j] * inv;
+      // all multipliers of the column first (distinct scalar registers), then the FMAs: back-to-back v_readlane pipeline,
+      // whereas readlane -> fma pairs through one scalar pair wait for the scalar write every time
+      double sc[NB];
+#pragma unroll
+      for (int c = j + 1; c < NB; ++c) sc[c] = readlane_f64(m, c);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = j + 1; c < NB; ++c) x[c] -= x[j] * sc[c];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // scale column c by 1/sqrt(d_c): lane c knows d_c; broadcast the 32 scales through LDS (rdiag doubles as staging)
+  const double sd = sqrt((myd > 0.0) ? myd : 1.0);
+  const double rs = 1.0 / sd;
+  if (lane < NB) rdiag[lane] = rs;
+  __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the ds_write above is visible to this wave's reads below
+  __builtin_amdgcn_wave_barrier();
+  if (lane < NB) {
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      if (c < i) D[i * LD + c] = x[c] * rdiag[c];
+      else if (c == i) D[i * LD + c] = sd;
+    }
+  }
+  if (bad && lane == 0 && fail_flag) *fail_flag = 1;
+}
+
 // x <- x L_kk^-T for one row held in registers.  Column-oriented substitution: once x_k is final it is
 // eliminated from all later columns with independent FMAs, so the dependent chain is one multiply + one FMA
 // per column (an fp64 FMA has a 32-cycle dependent latency on gfx950) instead of an NB(NB+1)/2-long chain.
@@ -90,6 +151,24 @@ __device__ __forceinline__ void substitute_row(double (&x)[NB], const double* D,
     for (int c = k + 1; c < NB; ++c) x[c] -= x[k] * D[c * LD + k];
   }
 }
+
+// Diagonal-block factorisation used by the panel kernels: the 256-thread LDS version.  -DVGG_CHOL_WAVE_FACTOR selects the
+// single-wavefront register version (wavefront 2 factors, the workgroup waits) -- built and measured in round 2
+// (scripts/ubench/chol_bench, n = 1202): 1.047 ms against 1.057 ms, i.e. no gain: ~1000 v_readlane_b32 per 32 x 32 block
+// cost what the 32 barrier + LDS round trips cost.
+#ifndef VGG_CHOL_WAVE_FACTOR
+#define FACTOR_DIAG(Dp, rdp, failp) factor_diag_lds<NB>(Dp, rdp, failp)
+#else
+#define FACTOR_DIAG(Dp, rdp, failp)                                          \
+  do {                                                                       \
+    __syncthreads();                                                         \
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 2) {             \
+      if constexpr (NB == 32) factor_diag_wave<32>(Dp, rdp, failp);          \
+    }                                                                        \
+    if constexpr (NB != 32) factor_diag_lds<NB>(Dp, rdp, failp);             \
+    __syncthreads();                                                         \
+  } while (0)
+#endif
 
 template <int NB>
 __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A, int n, int nrows, int k0,
@@ -125,7 +204,7 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
     const size_t o = (size_t)(k0 + i) * n + k0 + c;
     D[i * LD + c] = (i < nb && c <= i) ? A[o] + (S2 ? S2[o] : 0.0) : ((i == c) ? 1.0 : 0.0);
   }
-  factor_diag_lds<NB>(D, rdiag, (blockIdx.x == 0) ? fail : nullptr);
+  FACTOR_DIAG(D, rdiag, (blockIdx.x == 0) ? fail : nullptr);
   if (blockIdx.x == 0) {
     for (int e = tid; e < NB * NB; e += 256) {
       const int i = e / NB, c = e % NB;
@@ -213,7 +292,7 @@ __global__ __launch_bounds__(256) void chol_panel2_kernel(double* __restrict__ A
     D1[i * LD + c] = (c <= i) ? A[o1] + (S2 ? S2[o1] : 0.0) : 0.0;
     D2[i * LD + c] = (c <= i) ? A[o2] + (S2 ? S2[o2] : 0.0) : 0.0;
   }
-  factor_diag_lds<NB>(D1, rd1, (blockIdx.x == 0) ? fail : nullptr);
+  FACTOR_DIAG(D1, rd1, (blockIdx.x == 0) ? fail : nullptr);
   // first block column: panel rows (wave 0) and the 32 rows of L21 (wave 1) through L11
   if (wave <= 1) {
     double (&x1)[NB] = reinterpret_cast<double (&)[NB]>(x);
@@ -234,7 +313,7 @@ __global__ __launch_bounds__(256) void chol_panel2_kernel(double* __restrict__ A
       D2[i * LD + c] -= s0 + s1;
     }
   }
-  factor_diag_lds<NB>(D2, rd2, (blockIdx.x == 0) ? fail : nullptr);
+  FACTOR_DIAG(D2, rd2, (blockIdx.x == 0) ? fail : nullptr);
   if (blockIdx.x == 0) {
     for (int e = tid; e < NB * NB; e += 256) {
       const int i = e / NB, c = e % NB;

@@ -75,7 +75,9 @@ int vgg_cam_from_img(const void* tracks, int tracks_are_f64, const double* intri
  * the track axis into ceil(S*N/819200) chunks, each with its own torch.randperm draw and its own chunk-global
  * residual-indicator threshold).  pairs [num_chunks,H,2] int32: the hypothesis pairs of every chunk, drawn by the
  * caller in chunk order; chunk c = tracks [c*chunk_size, min(N,(c+1)*chunk_size)).  thresholds_io: host array
- * [num_chunks], semantics of threshold_io above, per chunk.  One stream synchronisation. */
+ * [num_chunks], semantics of threshold_io above, per chunk.  One stream synchronisation.
+ * Limits (both entries): 1 <= H <= 256 hypotheses per track, 1 <= lo_num <= 64 local-optimisation candidates;
+ * VGG_ERR_INVALID_ARGUMENT beyond (the reference calls with H = 256 or 128 and lo_num = 50). */
 size_t vgg_triangulate_chunks_workspace_bytes(int S, int num_chunks);
 int vgg_triangulate_tracks_chunks(const double* extrinsics, const double* tracks_t, const uint8_t* invalid_vis_conf_t,
                                   const int32_t* pairs, int S, int N, int H, int num_chunks, int chunk_size, int lo_num,

@@ -353,8 +353,10 @@ def estimate_fundamental_pair(x1, x2, vmask, samples, max_error, lo_num=300, sec
     allF, allc, allr, alli = [Fa, F8], [cnt, c8], [rs, r8], [inl, i8]
     if second_refine:
         lo2 = min(lo_num // 2, len(c8))
-        top2 = _order(c8)[:lo2]
-        F9, v9 = eight_point(x1, x2, i8[top2] & (c8[top2] >= 0)[:, None])
+        # fundamental.py:126-152: the second round ranks and refits on residuals_lo BEFORE valid_mask is applied
+        c8u, _, i8u = score(F8, v8, x1, x2, np.ones_like(vmask), thr)
+        top2 = _order(c8u)[:lo2]
+        F9, v9 = eight_point(x1, x2, i8u[top2] & (c8u[top2] >= 0)[:, None])
         c9, r9, i9 = score(F9, v9, x1, x2, vmask, thr)
         allF.append(F9); allc.append(c9); allr.append(r9); alli.append(i9)      # noqa: E702
     Fall, call, rall, iall = np.concatenate(allF), np.concatenate(allc), np.concatenate(allr), np.concatenate(alli)

@@ -1,6 +1,7 @@
 """CPU: small host-side mirrors checked against the REFERENCE's own functions, imported through the stub harness when
 /root/reference exists (this container; skipped on the GPU box): window / grid helpers of the runner
 (vggsfm/utils/utils.py:773-839) and the similarity alignment of the video path (vggsfm/utils/align.py:145-252)."""
+import numpy as np
 import pytest
 import torch
 
@@ -69,3 +70,44 @@ def test_get_EFP_and_sample_features4d_match_reference_bitwise():
     img = torch.rand(2, 3, 40, 50, generator=g)
     co = torch.rand(2, 30, 2, generator=g) * torch.tensor([49.0, 39.0])
     assert torch.equal(ref_sample(img, co), sample_features4d(img, co))
+
+
+@pytest.mark.skipif(not ref_harness.available(), reason="reference tree not present (GPU box)")
+def test_average_camera_prediction_matches_reference():
+    """vggsfm_amd.utils.utils.average_camera_prediction (torch ops, scipy's quaternion conventions restated) against the
+    reference's own function (vggsfm/utils/utils.py:25-164, scipy on the host) with the same fake predictor."""
+    import types
+    import warnings
+    ref_harness.install()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        from vggsfm.utils import utils as RU
+    from scipy.spatial.transform import Rotation
+    from vggsfm_amd.utils import utils as U
+    S = 9
+    rng = np.random.default_rng(4)
+
+    def predictor(images, batch_size=1):
+        # poses that depend on the ORDER of the frames (as a learned predictor's do): frame ids are encoded in the images
+        ids = images[:, 0, 0, 0].round().long()
+        rot = Rotation.from_rotvec(0.35 * np.stack([np.sin(ids.numpy() * 1.3), np.cos(ids.numpy() * 0.7), 0.1 * np.arange(len(ids))], 1))
+        R = torch.from_numpy(rot.as_matrix()).float()
+        T = torch.stack([ids.float() * 0.1, torch.arange(len(ids)).float() * 0.05, torch.ones(len(ids))], 1)
+        f = torch.stack([1.5 + 0.01 * ids.float(), 1.5 + 0.02 * torch.arange(len(ids)).float()], 1)
+        return {"pred_cameras": types.SimpleNamespace(R=R, T=T, focal_length=f)}
+
+    images = torch.arange(S).float()[:, None, None, None].expand(S, 3, 4, 4).contiguous()
+    for q in ([0, S // 2, S - 1], [0, 3], None):
+        import random
+        random.seed(7)
+        a = RU.average_camera_prediction(predictor, images, 1, query_indices=None if q is None else list(q))
+        random.seed(7)
+        b = U.average_camera_prediction(predictor, images, 1, query_indices=None if q is None else list(q))
+        np.testing.assert_allclose(b.R.numpy(), np.asarray(a.R), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(b.T.numpy(), np.asarray(a.T), rtol=0, atol=1e-7)
+        np.testing.assert_allclose(b.focal_length.numpy(), np.asarray(a.focal_length), rtol=0, atol=1e-7)
+    # the quaternion restatement itself, sign included, on rotations of every branch
+    M = Rotation.random(500, random_state=1).as_matrix()
+    q = U.matrix_to_quaternion_scipy(torch.from_numpy(M)).numpy()
+    np.testing.assert_allclose(q, Rotation.from_matrix(M).as_quat(), rtol=0, atol=1e-14)
+    np.testing.assert_allclose(U.quaternion_to_matrix_scipy(torch.from_numpy(q)).numpy(), M, rtol=0, atol=1e-14)

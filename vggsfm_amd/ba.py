@@ -13,6 +13,7 @@ copies -- the problem is compiled into flat device arrays with torch ops and han
 * image 0 pose constant, image 1 x-translation constant; TRIVIAL loss; focal / extra refined,
   principal point constant; one camera per frame or one shared camera.
 """
+import copy
 import ctypes
 from dataclasses import dataclass
 from typing import Optional
@@ -377,7 +378,7 @@ def window_bundle_adjustment(points3d, extrinsics, intrinsics, tracks, masks, nu
     frame of the previous one) keeps its pose, the first `num_existing_points` VALID points (the ones carried
     over from earlier windows) are constant, the newly triangulated ones are variable, focal length and
     distortion are not refined (``ba_options.refine_focal_length = refine_extra_params = False``)."""
-    options = options or BundleAdjustmentOptions()
+    options = copy.deepcopy(options) if options is not None else BundleAdjustmentOptions()   # (the caller's object stays as it is)
     options.refine_focal_length = False
     options.refine_extra_params = False
     valid = masks.bool().sum(0) >= 2

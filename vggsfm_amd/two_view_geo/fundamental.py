@@ -67,7 +67,14 @@ def estimate_fundamental(points1, points2, max_ransac_iters=4096, max_error=1, l
     c8, r8 = _score(L, p1, p2, vm, F8, v8, thr)
     allF, allc, allr = [Fa, F8], [cnt, c8], [rs, r8]
     if second_refine:
-        F9, v9 = _eight_point(L, p1, p2, vm, F8, c8, lo_num // 2, thr)
+        # the reference ranks and refits the second round on residuals_lo BEFORE its valid mask is applied
+        # (fundamental.py:126-152): invalid matches take part there, and only there
+        if vm is not None and not bool(vm.all()):
+            ones = torch.ones_like(vm)
+            c8u, _ = _score(L, p1, p2, ones, F8, v8, thr)
+            F9, v9 = _eight_point(L, p1, p2, ones, F8, c8u, lo_num // 2, thr)
+        else:
+            F9, v9 = _eight_point(L, p1, p2, vm, F8, c8, lo_num // 2, thr)
         c9, r9 = _score(L, p1, p2, vm, F9, v9, thr)
         allF.append(F9); allc.append(c9); allr.append(r9)                       # noqa: E702
     Fall, call, rall = torch.cat(allF, 1), torch.cat(allc, 1).long(), torch.cat(allr, 1)

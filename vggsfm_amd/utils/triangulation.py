@@ -73,7 +73,12 @@ def triangulate_tracks(extrinsics, tracks_normalized, max_ransac_iters=256, lo_n
     The reference splits the track axis into ceil(S*N/max_tri_points_num) chunks (torch.chunk), each with its own
     randperm draw and its own chunk-global indicator threshold.  Both are reproduced -- the draws are made up
     front, in chunk order, from the same global CPU RNG -- but all chunks run in ONE launch
-    (`vgg_triangulate_tracks_chunks`): the kernel has no memory reason to chunk."""
+    (`vgg_triangulate_tracks_chunks`): the kernel has no memory reason to chunk.
+    Kernel limits (include/vggsfm_amd.h): max_ransac_iters <= 256 hypotheses per track, lo_num <= 64 (the reference's
+    call sites use 256 / 128 and 50)."""
+    if max_ransac_iters > 256 or lo_num > 64 or max_ransac_iters < 1 or lo_num < 1:
+        raise ValueError(f"triangulate_tracks: max_ransac_iters={max_ransac_iters} (1..256) / lo_num={lo_num} (1..64) are outside "
+                         "what vgg_triangulate_tracks_chunks supports (the reference calls it with 256 or 128, and 50)")
     _lib.require_gpu(extrinsics, tracks_normalized)
     L = _lib.lib()
     S, N = tracks_normalized.shape[0], tracks_normalized.shape[1]
@@ -261,7 +266,12 @@ def refine_pose(extrinsics, intrinsics, extra_params, inlier, points3D, tracks, 
     """Reference: triangulation.py:260-479.  Inliers = given mask AND reprojection error <= 12 px with
     positive depth; frames with > 100 such inliers are refined.  With `force_estimate` the other frames (and frames
     refined to a focal length outside [0.1, 30] x image size) go through ``absolute_pose_estimation_batch`` -- the
-    device restatement of pycolmap.absolute_pose_estimation (P3P RANSAC + refinement; random, parity unpinned)."""
+    device restatement of pycolmap.absolute_pose_estimation (P3P RANSAC + refinement; random, parity unpinned).
+    `shared_camera` semantics of that fallback: the focal length estimated for a frame stays with that frame (row) of
+    the returned intrinsics; only frame 0 refines intrinsics afterwards and the next shared-camera BA reads row 0 alone
+    (tensor_to_pycolmap.py:76-107), exactly as in the reference.  (The reference mutates ONE pycolmap camera object
+    frame after frame, so there a frame's estimate also becomes the starting focal of the frames processed after it;
+    here all frames are estimated concurrently from the same starting intrinsics.)"""
     _check_camera_type(camera_type)
     S = extrinsics.shape[0]
     P = tracks.shape[1]

@@ -40,6 +40,8 @@ def project_3D_points(points3D, extrinsics, intrinsics=None, extra_params=None, 
                       default=0, only_points_cam=False):
     """Reference: triangulation_helpers.py:311-355.  points3D (P,3), extrinsics (S,3,4), intrinsics (S,3,3)
     -> (S,P,2) [, (S,3,P)]."""
+    if default != 0:
+        raise NotImplementedError("only default=0 is used by the reference")
     _lib.require_gpu(points3D, extrinsics)
     L = _lib.lib()
     pts = _f64c(points3D)
@@ -57,8 +59,6 @@ def project_3D_points(points3D, extrinsics, intrinsics=None, extra_params=None, 
     out_uv = torch.empty((S, P, 2), dtype=torch.float64, device=dev)
     _lib.check(L.vgg_project_points(_lib.ptr(pts), P, _lib.ptr(ext), _lib.ptr(K), _lib.ptr(ep), k, S,
                                     _lib.ptr(out_uv), _lib.ptr(out_cam), _lib.stream_ptr()), "vgg_project_points")
-    if default != 0:
-        raise NotImplementedError("only default=0 is used by the reference")
     if return_points_cam:
         return out_uv, out_cam
     return out_uv

@@ -177,8 +177,15 @@ class VideoGeometry:
     normalisation -- runs here, on the device, with the kernels of the batch path."""
 
     def __init__(self, intrinsics, extra_params=None, camera_type="SIMPLE_RADIAL", max_query_pts=1024, device="cuda",
-                 generator=None):
+                 generator=None, camera_predictor=None, images=None):
+        """`camera_predictor` + `images` (1,S,3,H,W): the default ``camera_prior`` = the reference's own recipe,
+        ``average_camera_prediction`` over (last window, next window) with the query frames (first, middle, last)
+        (video_runner.py:655-667; ``vggsfm_amd.utils.utils.camera_prior_from_predictor``)."""
         from .track_table import TrackTable
+        from .utils.utils import camera_prior_from_predictor
+        self.camera_prior = None if camera_predictor is None else camera_prior_from_predictor(camera_predictor, images)
+        if generator is not None and torch.device(generator.device).type != torch.device(device).type:
+            raise ValueError(f"generator lives on {generator.device}, the tables on {device}: pass a generator of the same device")
         self.device = torch.device(device)
         self.intrinsics = intrinsics[0:1].to(self.device).clone()                       # 1x3x3 (video_runner.py:149)
         if extra_params is None and camera_type == "SIMPLE_RADIAL":
@@ -216,6 +223,9 @@ class VideoGeometry:
         last_start_idx, start_idx = start_idx, end_idx
         end_idx = start_idx + window_size
         print(f"Processing window from {start_idx} to {end_idx}")
+        camera_prior = camera_prior or self.camera_prior
+        if camera_prior is None:
+            raise ValueError("no camera_prior: pass one, or construct VideoGeometry with camera_predictor and images")
         # predicted cameras of (last window, next window), aligned to the last window's reconstruction
         pred_extri = camera_prior(last_start_idx, end_idx).to(self.device, torch.float64)
         last_extri = t.extri[last_start_idx:start_idx].to(torch.float64)

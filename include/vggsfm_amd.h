@@ -212,6 +212,11 @@ int vgg_ba_reduce_buffer(const vgg_ba_problem* problem, const vgg_ba_options* op
                          double** device_ptr, size_t* count);
 int vgg_ba_finish(const vgg_ba_problem* problem, const vgg_ba_options* options, void* workspace,
                   vgg_ba_summary* summary, vgg_ba_iteration* log, int log_cap, void* stream);
+/* Has the solve terminated?  Copies the 4-byte device flag and synchronises the stream (what vgg_ba_solve does every
+ * 8 iterations): a phase-driven caller uses it to stop enqueuing iterations -- and, with several ranks, their
+ * collectives -- once the (rank-identical) device-side decision has ended the solve. */
+int vgg_ba_poll_done(const vgg_ba_problem* problem, const vgg_ba_options* options, void* workspace, int32_t* done_host,
+                     void* stream);
 
 /* pycolmap.pose_refinement for a batch of frames   vggsfm/utils/triangulation.py:387,590 (loops :341-441, :542-608)
  * = COLMAP RefineAbsolutePose: points constant, robust loss (reference: Cauchy, scale 1), unknowns pose

@@ -82,3 +82,30 @@ def test_sharded_equals_single_rank(cam, shared, world):
         np.testing.assert_allclose(pr.intr.cpu().numpy(), prob.intr.cpu().numpy(), rtol=1e-10)
     got = torch.cat([pr.pts for pr in problems]).cpu().numpy()
     np.testing.assert_allclose(got, prob.pts.cpu().numpy(), atol=1e-8)
+
+
+def test_sharded_solve_stops_enqueuing_after_termination():
+    """ShardedBA.solve polls the device-side `done` flag every POLL iterations (vgg_ba_poll_done), like vgg_ba_solve: a
+    solve that converges after a dozen iterations must not enqueue the remaining ~90 (with several ranks: their
+    all-reduces) -- and must return exactly what the single-call solver returns."""
+    sc = make_scene(16, 1200, "SIMPLE_RADIAL", shared_camera=True, seed=23, outlier_frac=0.0)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=23)
+    from vggsfm_amd.ba_options import BundleAdjustmentOptions
+    opts = BundleAdjustmentOptions()                       # 100 iterations, gradient tolerance 1e-4
+    prob, _, _ = BA.compile_problem(D(pts0), D(ext0), D(K0), D(sc.tracks), D(sc.mask), D(extra0), True, "SIMPLE_RADIAL")
+    ref, _ = BA.solve(prob, opts)
+    prob2, _, _ = BA.compile_problem(D(pts0), D(ext0), D(K0), D(sc.tracks), D(sc.mask), D(extra0), True, "SIMPLE_RADIAL")
+    s = ShardedBA(prob2, opts)
+    calls = [0]
+    inner = s.iteration
+
+    def counted():
+        calls[0] += 1
+        inner()
+    s.iteration = counted
+    out = s.solve()
+    assert ref["num_iterations"] < 40 and ref["termination"] != 0
+    assert out["num_iterations"] == ref["num_iterations"] and out["termination"] == ref["termination"]
+    assert out["final_cost"] == ref["final_cost"]
+    assert calls[0] <= ref["num_iterations"] + 1 + ShardedBA.POLL
+    assert torch.equal(prob.pts, prob2.pts) and torch.equal(prob.cam_t, prob2.cam_t)

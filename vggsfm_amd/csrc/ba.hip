@@ -1625,6 +1625,19 @@ int vgg_ba_finish(const vgg_ba_problem* problem, const vgg_ba_options* options, 
   return finish(L, options->max_num_iterations, summary, log, log_cap);
 }
 
+int vgg_ba_poll_done(const vgg_ba_problem* problem, const vgg_ba_options* options, void* workspace, int32_t* done_host,
+                     void* stream) {
+  if (!done_host) return VGG_ERR_INVALID_ARGUMENT;
+  Launch L;
+  int rc = make_launch(problem, options, workspace, (hipStream_t)stream, &L);
+  if (rc != VGG_OK) return rc;
+  int32_t done = 0;
+  VGG_HIP_CHECK(hipMemcpyAsync(&done, &L.w.ctl->done, sizeof(done), hipMemcpyDeviceToHost, L.st));
+  VGG_HIP_CHECK(hipStreamSynchronize(L.st));
+  *done_host = done;
+  return VGG_OK;
+}
+
 int vgg_ba_solve(const vgg_ba_problem* problem, const vgg_ba_options* options, void* workspace,
                  size_t workspace_bytes, vgg_ba_summary* summary, vgg_ba_iteration* log, int log_cap, void* stream) {
   int rc = vgg_ba_begin(problem, options, workspace, workspace_bytes, 0, 1, stream);

@@ -77,6 +77,120 @@ __device__ __forceinline__ void factor_diag_lds(double* D, double* rdiag, int32_
   __syncthreads();
 }
 
+// The same factorisation FOUR pivot columns per synchronisation.  The pivot chain of the column-at-a-time version costs
+// a barrier + an LDS round trip + a reciprocal per column (~280 ns); here every thread factors the 4 x 4 pivot block
+// redundantly in registers (broadcast LDS reads, four dependent reciprocals), one thread per row pushes its 4 panel
+// entries through it (u_r0..u_r3, the unnormalised multipliers, and their products with the pivot reciprocals) into a
+// small LDS panel, and the trailing update of an element is one rank-4 step: three barriers per four columns.
+// Arithmetic is that of factor_diag_lds, operation for operation (a_ic -= a_ij (a_cj / d_j), j ascending, columns scaled
+// by 1 / sqrt(d_c) at the end): the factor is bit-identical.
+// WITH_T: the rows of the identity in Tl (LDS, ld = NB + 1) receive the same column operations, so that Tl ends up as
+// L^-T (what the panel product and the backward substitution need) without a second, dependent pass.
+// scratch: 2 * (WITH_T ? 2 : 1) * NB * 4 doubles of LDS.
+template <int NB, bool WITH_T>
+__device__ __forceinline__ void factor_diag_lds4(double* D, double* Tl, double* rdiag, double* scratch, int32_t* fail_flag) {
+  static_assert(NB % 4 == 0 && 256 % NB == 0, "block of 4-column steps, 256 threads");
+  constexpr int LD = NB + 1, STRIDE = 256 / NB, CNT = NB / STRIDE, ROWS = WITH_T ? 2 * NB : NB;
+  double* U = scratch;                     // [ROWS][4] unnormalised panel entries u_rt
+  double* V = scratch + ROWS * 4;          // [ROWS][4] u_rt / d_t
+  const int tid = threadIdx.x;
+  const int c = tid % NB, i0 = tid / NB;
+  bool bad = false;
+  if (WITH_T) {
+    for (int e = tid; e < NB * NB; e += 256) Tl[(e / NB) * LD + (e % NB)] = (e / NB == e % NB) ? 1.0 : 0.0;
+  }
+  for (int j0 = 0; j0 < NB; j0 += 4) {
+    __syncthreads();
+    // 4 x 4 pivot block, every thread (same addresses: LDS broadcast)
+    const double* P = D + j0 * LD + j0;
+    const double d0 = P[0];
+    const double u10 = P[LD], p11 = P[LD + 1];
+    const double u20 = P[2 * LD], p21 = P[2 * LD + 1], p22 = P[2 * LD + 2];
+    const double u30 = P[3 * LD], p31 = P[3 * LD + 1], p32 = P[3 * LD + 2], p33 = P[3 * LD + 3];
+    const double r0 = fast_rcp<1>((d0 > 0.0) ? d0 : 1.0);
+    const double m10 = u10 * r0, m20 = u20 * r0, m30 = u30 * r0;        // multipliers a_cj / d_j
+    const double d1 = p11 - u10 * m10;
+    const double u21 = p21 - u20 * m10, u31 = p31 - u30 * m10;
+    const double r1 = fast_rcp<1>((d1 > 0.0) ? d1 : 1.0);
+    const double m21 = u21 * r1, m31 = u31 * r1;
+    const double d2 = (p22 - u20 * m20) - u21 * m21;
+    const double u32 = (p32 - u30 * m20) - u31 * m21;
+    const double r2 = fast_rcp<1>((d2 > 0.0) ? d2 : 1.0);
+    const double m32 = u32 * r2;
+    const double d3 = ((p33 - u30 * m30) - u31 * m31) - u32 * m32;
+    const double r3 = fast_rcp<1>((d3 > 0.0) ? d3 : 1.0);
+    constexpr double HUGE_ = 1.7976931348623157e308;
+    if (!(d0 > 0.0) || !(d0 < HUGE_) || !(d1 > 0.0) || !(d1 < HUGE_) || !(d2 > 0.0) || !(d2 < HUGE_) || !(d3 > 0.0) || !(d3 < HUGE_))
+      bad = true;
+    // one thread per row: the row's four panel entries through the pivot block
+    if (tid < ROWS) {
+      const bool trow = WITH_T && tid >= NB;
+      const int r = trow ? tid - NB : tid;
+      const double* X = (trow ? Tl : D) + r * LD + j0;
+      const bool live = trow ? (r < j0 + 4) : (r >= j0 + 4);      // rows that have entries in (or below) this panel
+      double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
+      if (live) {
+        x0 = X[0];
+        x1 = X[1] - x0 * m10;
+        x2 = (X[2] - x0 * m20) - x1 * m21;
+        x3 = ((X[3] - x0 * m30) - x1 * m31) - x2 * m32;
+      }
+      double* Ur = U + tid * 4;
+      double* Vr = V + tid * 4;
+      Ur[0] = x0; Ur[1] = x1; Ur[2] = x2; Ur[3] = x3;
+      Vr[0] = x0 * r0; Vr[1] = x1 * r1; Vr[2] = x2 * r2; Vr[3] = x3 * r3;
+    }
+    __syncthreads();
+    // rank-4 trailing update (columns beyond the panel): D lower triangle, and every live row of Tl
+    if (c >= j0 + 4) {
+      const double v0 = V[c * 4], v1 = V[c * 4 + 1], v2 = V[c * 4 + 2], v3 = V[c * 4 + 3];
+#pragma unroll
+      for (int m = 0; m < CNT; ++m) {
+        const int i = i0 + STRIDE * m;
+        if (i >= c) {
+          const double* Ui = U + i * 4;
+          double a = D[i * LD + c];
+          a -= Ui[0] * v0; a -= Ui[1] * v1; a -= Ui[2] * v2; a -= Ui[3] * v3;
+          D[i * LD + c] = a;
+        }
+        if (WITH_T && i < j0 + 4) {
+          const double* Ui = U + (NB + i) * 4;
+          double a = Tl[i * LD + c];
+          a -= Ui[0] * v0; a -= Ui[1] * v1; a -= Ui[2] * v2; a -= Ui[3] * v3;
+          Tl[i * LD + c] = a;
+        }
+      }
+    }
+    // the panel columns themselves: rows below the pivot block get u_rt; the pivot block its own entries
+    if (tid < ROWS) {
+      const bool trow = WITH_T && tid >= NB;
+      const int r = trow ? tid - NB : tid;
+      double* X = (trow ? Tl : D) + r * LD + j0;
+      const double* Ur = U + tid * 4;
+      if (trow ? (r < j0 + 4) : (r >= j0 + 4)) { X[0] = Ur[0]; X[1] = Ur[1]; X[2] = Ur[2]; X[3] = Ur[3]; }
+    }
+    if (tid == 0) {
+      double* Pw = D + j0 * LD + j0;
+      Pw[LD + 1] = d1; Pw[2 * LD + 1] = u21; Pw[2 * LD + 2] = d2; Pw[3 * LD + 1] = u31; Pw[3 * LD + 2] = u32; Pw[3 * LD + 3] = d3;
+    }
+  }
+  __syncthreads();
+  // scale column c by 1/sqrt(d_c)
+  const double dc = D[c * LD + c];
+  const double sd = sqrt((dc > 0.0) ? dc : 1.0);
+  const double rs = 1.0 / sd;
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < CNT; ++m) {
+    const int i = i0 + STRIDE * m;
+    if (i > c) D[i * LD + c] *= rs;
+    else if (i == c) { D[i * LD + c] = sd; rdiag[c] = rs; }
+    if (WITH_T && i <= c) Tl[i * LD + c] *= rs;
+  }
+  if (bad && tid == 0 && fail_flag) *fail_flag = 1;
+  __syncthreads();
+}
+
 // One double of lane `src` (compile-time constant after unrolling) as a wave-uniform value: two v_readlane_b32.
 __device__ __forceinline__ double readlane_f64(double v, int src) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -156,8 +270,10 @@ __device__ __forceinline__ void substitute_row(double (&x)[NB], const double* D,
 // single-wavefront register version (wavefront 2 factors, the workgroup waits) -- built and measured in round 2
 // (scripts/ubench/chol_bench, n = 1202): 1.047 ms against 1.057 ms, i.e. no gain: ~1000 v_readlane_b32 per 32 x 32 block
 // cost what the 32 barrier + LDS round trips cost.
-#ifndef VGG_CHOL_WAVE_FACTOR
+#if defined(VGG_CHOL_COLUMN_FACTOR)
 #define FACTOR_DIAG(Dp, rdp, failp) factor_diag_lds<NB>(Dp, rdp, failp)
+#elif !defined(VGG_CHOL_WAVE_FACTOR)
+#define FACTOR_DIAG(Dp, rdp, failp) factor_diag_lds4<NB, false>(Dp, nullptr, rdp, fscr, failp)
 #else
 #define FACTOR_DIAG(Dp, rdp, failp)                                          \
   do {                                                                       \
@@ -178,6 +294,7 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
   constexpr int LD = NB + 1;
   __shared__ double D[NB * LD];
   __shared__ double rdiag[NB];
+  __shared__ double fscr[8 * NB];
   if (skip && *skip) return;
   const int nb = min(NB, n - k0);
   const int tid = threadIdx.x;
@@ -253,6 +370,7 @@ __global__ __launch_bounds__(256) void chol_panel2_kernel(double* __restrict__ A
   const int k0 = blockIdx.y ? k0_second : k0_first;
   __shared__ double D1[NB * LD], D2[NB * LD], L21[NB * LD];
   __shared__ double rd1[NB], rd2[NB];
+  __shared__ double fscr[8 * NB];
   if (skip && *skip) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const bool extra_wg = blockIdx.x == gridDim.x - 1;

@@ -112,9 +112,24 @@ class ShardedBA:
                                         log if log_cap else None, log_cap, _lib.stream_ptr()), "vgg_ba_finish")
         return BA._summary_dict(summ, log, summ.num_log if log_cap else 0)
 
+    POLL = 8
+
+    def done(self):
+        """Has the device-side control flow ended the solve?  (4-byte copy + stream synchronisation.)"""
+        flag = ctypes.c_int32(0)
+        _lib.check(self.L.vgg_ba_poll_done(ctypes.byref(self.cp), ctypes.byref(self.co), _lib.ptr(self.ws), ctypes.byref(flag),
+                                           _lib.stream_ptr()), "vgg_ba_poll_done")
+        return bool(flag.value)
+
     def solve(self):
-        """Whole solve: device-side termination makes the trailing iterations no-ops."""
+        """Whole solve.  Termination is decided on the device and identically on every rank (the decision inputs are
+        all-reduced); iterations enqueued after it are no-ops but still cost their launches and collectives, so the host
+        reads the `done` flag every POLL iterations -- every rank at the same iteration, hence the same answer -- and
+        stops enqueuing (what ``vgg_ba_solve`` does for the single-GPU path)."""
         self.begin()
-        for _ in range(self.options.solver_options.max_num_iterations + 1):
+        cap = self.options.solver_options.max_num_iterations
+        for it in range(cap + 1):
             self.iteration()
-        return self.finish(self.options.solver_options.max_num_iterations + 2)
+            if it % self.POLL == self.POLL - 1 and it < cap and self.done():
+                break
+        return self.finish(cap + 2)

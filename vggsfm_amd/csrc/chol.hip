@@ -16,6 +16,8 @@
 // The right-hand side is stored as row n of the (n+1) x n array, so the factorisation performs the
 // forward substitution on the way; the backward substitution is a sequence of NB x NB mat-vecs with T_k.
 // Only the lower triangle (row-major, ld = n) is read or written.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace vgg {
@@ -87,10 +89,10 @@ __device__ __forceinline__ void factor_diag_lds(double* D, double* rdiag, int32_
 // WITH_T: the rows of the identity in Tl (LDS, ld = NB + 1) receive the same column operations, so that Tl ends up as
 // L^-T (what the panel product and the backward substitution need) without a second, dependent pass.
 // scratch: 2 * (WITH_T ? 2 : 1) * NB * 4 doubles of LDS.
-template <int NB, bool WITH_T>
+template <int NB, bool WITH_T, int LD = NB + 1>
 __device__ __forceinline__ void factor_diag_lds4(double* D, double* Tl, double* rdiag, double* scratch, int32_t* fail_flag) {
   static_assert(NB % 4 == 0 && 256 % NB == 0, "block of 4-column steps, 256 threads");
-  constexpr int LD = NB + 1, STRIDE = 256 / NB, CNT = NB / STRIDE, ROWS = WITH_T ? 2 * NB : NB;
+  constexpr int STRIDE = 256 / NB, CNT = NB / STRIDE, ROWS = WITH_T ? 2 * NB : NB;
   double* U = scratch;                     // [ROWS][4] unnormalised panel entries u_rt
   double* V = scratch + ROWS * 4;          // [ROWS][4] u_rt / d_t
   const int tid = threadIdx.x;
@@ -687,12 +689,313 @@ __global__ __launch_bounds__(kBackThreads) void chol_backward_kernel(const doubl
   for (int i = tid; i < n; i += kBackThreads) b[i] = y[i];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Dataflow factorisation: ONE launch, one workgroup per 64 x 64 tile of the lower triangle (+ one tile row for the
+// appended rhs), ordered by (block column, block row).  A tile's workgroup loads its block of A into MFMA accumulators,
+// applies the updates of the block columns to its left AS THEIR FACTOR TILES BECOME AVAILABLE (left-looking, per-tile
+// flags), then finishes: a diagonal tile factors itself (factor_diag_lds4 with the inverse T = L^-T as a by-product),
+// an off-diagonal tile multiplies by T of its column.  Nothing but the true dependences orders the work: the trailing
+// update of step k overlaps the pivot chain of steps k+1.., decoupled leading blocks (camera split, band structure:
+// first_blk) factor concurrently without any special casing, and ~40 dependent launches become one.
+// Progress: a workgroup waits only for tiles EARLIER in the launch order; workgroups are dispatched in order per XCD
+// (MI355X_MICROARCH.md, "Workgroup dispatch"), so the earliest unfinished tile is always resident and never waits on
+// an undispatched one.  Every spin is bounded all the same (fail flag 2 instead of a hang).
+// Hand-offs follow the {8-byte agent-scope atomics on both sides} form of the guide: published tiles are written
+// with relaxed agent-scope stores (write-through), drained (s_waitcnt vmcnt(0)), then the flag is stored; readers poll
+// the flag with relaxed agent-scope loads and read the payload with agent-scope loads (L1 bypassed) -- no fences.
+constexpr int DFB = 64;                       // tile edge
+constexpr int kSpinLimit = 1 << 22;
+
+__device__ __forceinline__ void st_agent(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// all threads: wait until *flag != 0 (set by another workgroup of this launch)
+__device__ __forceinline__ void df_wait(const int32_t* flag, int32_t* fail) {
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > kSpinLimit) { if (fail) *fail = 2; break; }
+    }
+  }
+  __syncthreads();
+}
+// all threads: every store of this workgroup has left the CU, then raise the flag
+__device__ __forceinline__ void df_publish(int32_t* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#ifdef VGG_CHOL_TRACE
+__device__ unsigned long long* g_chol_trace = nullptr;      // [tiles][8] wall-clock stamps (100 MHz), scripts/ubench/chol_bench
+#define DF_STAMP(slot) do { if (g_chol_trace && threadIdx.x == 0) g_chol_trace[(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define DF_STAMP(slot) do { } while (0)
+#endif
+
+// 32 x 32 x 32 product on the matrix cores by the four wavefronts of a workgroup, operands read from LDS through
+// accessors: out(i, j) <- sum_k opA(i, k) * opB(j, k); wavefront w owns the 16 x 16 tile (w >> 1, w & 1).
+template <class FA, class FB, class FO>
+__device__ __forceinline__ void mm32_lds(FA opA, FB opB, FO out) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ti = wave >> 1, tj = wave & 1;
+  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(opA(16 * ti + li, 4 * s + lk), opB(16 * tj + li, 4 * s + lk), acc, 0, 0, 0);
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) out(16 * ti + lk + 4 * reg, 16 * tj + li, acc[reg]);
+}
+
+// 64 x 64 diagonal block (LDS, ld = 65, lower triangle valid) -> its factor in place and T = L^-T (upper triangular) in
+// Tl, as two 32 x 32 factorisations (factor_diag_lds4) glued by four small matrix-core products:
+//   L21 = D21 T11,  D22 -= L21 L21^T,  T12 = -T11 (L21^T T22).
+// (One 64-wide factor_diag_lds4 was measured at 40 us: its rank-4 trailing updates are LDS-issue bound.)
+__device__ __forceinline__ void factor64(double* D, double* Tl, double* rd, double* scr, int32_t* fail) {
+  constexpr int LD = DFB + 1, H = 32;
+  const int tid = threadIdx.x;
+  factor_diag_lds4<H, true, LD>(D, Tl, rd, scr, fail);
+  double v[4];
+  int vi[4], vj[4], cnt = 0;
+  mm32_lds([&](int i, int k) { return D[(H + i) * LD + k]; }, [&](int j, int k) { return Tl[k * LD + j]; },
+           [&](int i, int j, double x) { v[cnt] = x; vi[cnt] = i; vj[cnt] = j; ++cnt; });
+  __syncthreads();                                       // every wavefront has read D21 before anyone overwrites it
+#pragma unroll
+  for (int q = 0; q < 4; ++q) D[(H + vi[q]) * LD + vj[q]] = v[q];
+  for (int e = tid; e < H * H; e += 256) Tl[(H + e / H) * LD + e % H] = 0.0;           // T21 = 0
+  __syncthreads();
+  mm32_lds([&](int i, int k) { return D[(H + i) * LD + k]; }, [&](int j, int k) { return D[(H + j) * LD + k]; },
+           [&](int i, int j, double x) { if (j <= i) D[(H + i) * LD + H + j] -= x; });
+  factor_diag_lds4<H, true, LD>(D + H * LD + H, Tl + H * LD + H, rd + H, scr, fail);
+  double* W = scr;                                       // 32 x 32
+  mm32_lds([&](int i, int k) { return D[(H + k) * LD + i]; }, [&](int j, int k) { return Tl[(H + k) * LD + H + j]; },
+           [&](int i, int j, double x) { W[i * H + j] = x; });
+  __syncthreads();
+  mm32_lds([&](int i, int k) { return Tl[i * LD + k]; }, [&](int j, int k) { return W[k * H + j]; },
+           [&](int i, int j, double x) { Tl[i * LD + H + j] = -x; });
+  __syncthreads();
+}
+
+struct DfShared {
+  double D[DFB * (DFB + 1)];
+  double T[DFB * (DFB + 1)];
+  double scr[2 * 2 * DFB * 4];
+  double rd[DFB];
+};
+
+// flags: ready[(nbk + 1) * nbk] (tile (r, c) final), then tready[nbk]; all zero on entry.
+__global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__ A, int n, int nbk, double* __restrict__ Tinv,
+                                                            int32_t* __restrict__ flags, int32_t* fail, const int32_t* skip,
+                                                            int split_a, int split_b) {
+  extern __shared__ double df_smem[];
+  DfShared& sh = *reinterpret_cast<DfShared*>(df_smem);
+  constexpr int LD = DFB + 1;
+  if (skip && *skip) return;
+  // tile of this workgroup: column c holds rows c .. nbk-1 and the rhs row block nbk
+  int c = 0, t = blockIdx.x;
+  while (t >= nbk - c + 1) { t -= nbk - c + 1; ++c; }
+  const int r = c + t;                                  // r == nbk: the appended right-hand side (one row)
+  auto first_of = [&](int br) { return (split_b > 0 && br < nbk && DFB * br >= split_a && DFB * (br + 1) <= split_a + split_b) ? split_a / DFB : 0; };
+  if (c < first_of(r)) return;                          // structurally zero tile (block-diagonal leading part)
+  const int kfirst = max(first_of(r), first_of(c));
+  int32_t* ready = flags;
+  int32_t* tready = flags + (size_t)(nbk + 1) * nbk;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wy = wave >> 1, wx = wave & 1, li = lane & 15, lk = lane >> 4;
+  const int r0 = (r == nbk) ? n : DFB * r, c0 = DFB * c;
+  const int vr = (r == nbk) ? 1 : min(DFB, n - r0), vc = min(DFB, n - c0);
+  const bool diag = (r == c);
+  DF_STAMP(0);
+
+  // the tile of A (C layout: row = 32 wy + 16 m + lk + 4 reg, col = 32 wx + 16 q + li) and the product accumulators
+  f64x4 acc[2][2], a0[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int i = 32 * wy + 16 * m + lk + 4 * reg, j = 32 * wx + 16 * q + li;
+        a0[m][q][reg] = (i < vr && j < vc && (!diag || j <= i)) ? A[(size_t)(r0 + i) * n + c0 + j] : 0.0;
+        acc[m][q][reg] = 0.0;
+      }
+
+  // left-looking updates: acc -= L[r][k] L[c][k]^T.  k-index permutation of the MFMA steps: lane group lk supplies the 16
+  // consecutive columns 16 lk .. 16 lk + 15 of the operand row (same permutation for both operands)
+  for (int k = kfirst; k < c; ++k) {
+    df_wait(&ready[(size_t)r * nbk + k], fail);
+    if (!diag) df_wait(&ready[(size_t)c * nbk + k], fail);
+    const int k0 = DFB * k;
+    // stage the two operand tiles through LDS: coalesced row reads (one 512-byte row per wavefront instruction)
+    double* bufA = sh.D;
+    double* bufB = diag ? sh.D : sh.T;
+    {
+      double va[16], vb[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = (tid >> 6) + 4 * q, col = lane;
+        va[q] = (row < vr) ? ld_agent(&A[(size_t)(r0 + row) * n + k0 + col]) : 0.0;
+        if (!diag) vb[q] = (row < vc) ? ld_agent(&A[(size_t)(c0 + row) * n + k0 + col]) : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = (tid >> 6) + 4 * q, col = lane;
+        bufA[row * LD + col] = va[q];
+        if (!diag) bufB[row * LD + col] = vb[q];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      double a[2][8], b[2][8];
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) {
+        const int kk = 4 * (8 * half + s8) + lk;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          a[m][s8] = bufA[(32 * wy + 16 * m + li) * LD + kk];
+          b[m][s8] = bufB[(32 * wx + 16 * m + li) * LD + kk];
+        }
+      }
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            acc[m][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][s8], b[q][s8], acc[m][q], 0, 0, 0);
+    }
+    __syncthreads();                                     // operands consumed: the buffers may be refilled
+  }
+
+  DF_STAMP(1);                                           // all updates applied
+  // tile value = A - sum: into LDS, row-major (the diagonal tile factors there; the others need it as an MFMA operand)
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int i = 32 * wy + 16 * m + lk + 4 * reg, j = 32 * wx + 16 * q + li;
+        double v = a0[m][q][reg] - acc[m][q][reg];
+        if (diag && (i >= vc || j >= vc)) v = (i == j) ? 1.0 : 0.0;       // ragged last block: identity padding
+        sh.D[i * LD + j] = v;
+      }
+  __syncthreads();
+
+  if (diag) {
+    factor64(sh.D, sh.T, sh.rd, sh.scr, fail);
+    DF_STAMP(2);                                         // factored
+    for (int e = tid; e < DFB * DFB; e += 256) {
+      const int i = e / DFB, j = e % DFB;
+      if (j <= i && i < vc) st_agent(&A[(size_t)(c0 + i) * n + c0 + j], sh.D[i * LD + j]);
+      st_agent(&Tinv[(size_t)c * DFB * DFB + e], (j >= i) ? sh.T[i * LD + j] : 0.0);
+    }
+    df_publish(&tready[c]);
+    DF_STAMP(3);                                         // published
+    // (ready[c][c] is never waited for: L_cc only matters through T_c)
+    return;
+  }
+
+  // off-diagonal (and rhs) tile: X = tile * T_c, T_c = L_cc^-T;  X[i][j] = sum_k tile[i][k] T[k][j]
+  df_wait(&tready[c], fail);
+  DF_STAMP(2);                                           // T of the column arrived
+  f64x4 x[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) x[m][q] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  const double* Tc = Tinv + (size_t)c * DFB * DFB;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    double a[2][8], b[2][8];
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+      const int kk = 4 * (8 * half + s8) + lk;             // MFMA step s supplies k = 4 s + lk (plain order)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        a[m][s8] = sh.D[(32 * wy + 16 * m + li) * LD + kk];
+        b[m][s8] = ld_agent(Tc + (size_t)kk * DFB + 32 * wx + 16 * m + li);
+      }
+    }
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          x[m][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][s8], b[q][s8], x[m][q], 0, 0, 0);
+  }
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int i = 32 * wy + 16 * m + lk + 4 * reg, j = 32 * wx + 16 * q + li;
+        if (i < vr && j < vc) st_agent(&A[(size_t)(r0 + i) * n + c0 + j], x[m][q][reg]);
+      }
+  DF_STAMP(4);                                           // product done, stores issued
+  df_publish(&ready[(size_t)r * nbk + c]);
+  DF_STAMP(3);
+}
+
+static size_t dataflow_flag_count(int n) {
+  const int nbk = div_up(n, DFB);
+  return (size_t)(nbk + 1) * nbk + nbk;
+}
+static size_t dataflow_workspace_bytes(int n) {
+  return (size_t)div_up(n, DFB) * DFB * DFB * sizeof(double) + dataflow_flag_count(n) * sizeof(int32_t) + 256;
+}
+
 static inline int block_size_for(int n) { (void)n; return 32; }
 
 // workspace = the inverted diagonal blocks T_j = L_jj^-T, NB x NB doubles each
 size_t cholesky_workspace_bytes(int n) {
   const int nb = block_size_for(n);
-  return (size_t)div_up(n, nb) * nb * nb * sizeof(double) + 256;
+  const size_t legacy = (size_t)div_up(n, nb) * nb * nb * sizeof(double) + 256;
+  const size_t df = dataflow_workspace_bytes(n);
+  return legacy > df ? legacy : df;
+}
+
+// VGG_CHOL_LEGACY=1 in the environment selects the multi-launch path (A/B measurements)
+static bool use_dataflow(int n) {
+  static const bool legacy = [] { const char* e = getenv("VGG_CHOL_LEGACY"); return e && e[0] == '1'; }();
+  return !legacy && n >= 2 * DFB;
+}
+
+static int enqueue_dataflow(double* A, double* b, int n, double* ws, int32_t* device_fail, const int32_t* skip, hipStream_t st,
+                            int split_a, int split_b) {
+  const int nbk = div_up(n, DFB);
+  double* Tinv = ws;
+  int32_t* flags = reinterpret_cast<int32_t*>(ws + (size_t)nbk * DFB * DFB);
+  if (hipMemsetAsync(flags, 0, dataflow_flag_count(n) * sizeof(int32_t), st) != hipSuccess) return VGG_ERR_HIP;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_dataflow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sizeof(DfShared)) != hipSuccess) return VGG_ERR_HIP;
+    attr_set = true;
+  }
+  if (!(split_a >= DFB && split_b >= DFB && split_a % DFB == 0 && split_a + split_b <= n)) split_a = split_b = 0;
+  const int tiles = nbk * (nbk + 1) / 2 + nbk;
+  chol_dataflow_kernel<<<tiles, 256, sizeof(DfShared), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b);
+  const size_t back_lds = ((size_t)nbk * DFB + DFB * (DFB + 1) + DFB) * sizeof(double);
+  if (back_lds <= 150 * 1024) {
+    if (back_lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_backward_kernel<DFB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)back_lds) != hipSuccess) return VGG_ERR_HIP;
+    chol_backward_kernel<DFB><<<1, kBackThreads, back_lds, st>>>(A, b, n, Tinv, skip);
+  } else {
+    chol_solve_kernel<32><<<1, 256, 0, st>>>(A, b, n, 0, 1, skip);
+  }
+  if (hipGetLastError() != hipSuccess) return VGG_ERR_HIP;
+  return VGG_OK;
 }
 
 // If b is stored directly behind A (b == A + n*n, i.e. "row n" of an (n+1) x n matrix) the right-hand side
@@ -775,6 +1078,8 @@ static int enqueue(double* A, double* b, int n, double* inv_blocks, int32_t* dev
 int cholesky_solve_enqueue(double* A, double* b, int n, double* inv_blocks, int32_t* device_fail, const int32_t* skip,
                            hipStream_t st, const CholOverlap* overlap, int split_a, int split_b) {
   if (!inv_blocks) return VGG_ERR_INVALID_ARGUMENT;
+  if (!overlap && b == A + (size_t)n * n && use_dataflow(n))
+    return enqueue_dataflow(A, b, n, inv_blocks, device_fail, skip, st, split_a, split_b);
   return enqueue<32>(A, b, n, inv_blocks, device_fail, skip, st, overlap, split_a, split_b);
 }
 

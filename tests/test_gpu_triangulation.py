@@ -24,7 +24,9 @@ def _load(golden_dir, name):
     return dict(np.load(os.path.join(golden_dir, name), allow_pickle=False))
 
 
-@pytest.mark.parametrize("name", ["s8_all_pairs", "s30_randperm", "s30_it128", "s24_chunked"])
+# s200_chunked / s400_chunked: the view counts of BASELINE configs[2] / [3] -- the kernel's large-S regime (2 wavefronts per
+# SIMD, wave-uniform view loops, several reference chunks in one launch) -- against the reference's own output
+@pytest.mark.parametrize("name", ["s8_all_pairs", "s30_randperm", "s30_it128", "s24_chunked", "s200_chunked", "s400_chunked"])
 def test_triangulate_tracks_golden(golden_dir, name):
     g = _load(golden_dir, f"tri_tracks_{name}.npz")
     torch.manual_seed(int(g["seed"]))           # same host RNG stream as the reference run

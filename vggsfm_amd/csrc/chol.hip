@@ -892,13 +892,22 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
   if (diag) {
     factor64(sh.D, sh.T, sh.rd, sh.scr, fail);
     DF_STAMP(2);                                         // factored
+    // T_c first -- the tiles of this column wait for it -- then the flag, then L_cc (which nobody waits for: it only
+    // matters through T_c and as output)
     for (int e = tid; e < DFB * DFB; e += 256) {
       const int i = e / DFB, j = e % DFB;
-      if (j <= i && i < vc) st_agent(&A[(size_t)(c0 + i) * n + c0 + j], sh.D[i * LD + j]);
       st_agent(&Tinv[(size_t)c * DFB * DFB + e], (j >= i) ? sh.T[i * LD + j] : 0.0);
     }
     df_publish(&tready[c]);
     DF_STAMP(3);                                         // published
+    for (int e = tid; e < DFB * DFB; e += 256) {
+      const int i = e / DFB, j = e % DFB;
+#ifdef VGG_DF_L_AGENT
+      if (j <= i && i < vc) st_agent(&A[(size_t)(c0 + i) * n + c0 + j], sh.D[i * LD + j]);
+#else
+      if (j <= i && i < vc) A[(size_t)(c0 + i) * n + c0 + j] = sh.D[i * LD + j];
+#endif
+    }
     // (ready[c][c] is never waited for: L_cc only matters through T_c)
     return;
   }

@@ -159,3 +159,43 @@ def perturb_for_ba(scene, seed=0, rot_deg=0.5, trans=0.02, focal_rel=0.02, point
     extra = None if scene.extra_params is None else scene.extra_params.copy()
     pts = scene.points3D + point * rng.normal(size=scene.points3D.shape)
     return ext, K, extra, pts
+
+
+def make_scene_device(S, N, camera_type="SIMPLE_PINHOLE", shared_camera=False, seed=0, noise_px=0.5, outlier_frac=0.05,
+                      track_seed=None, device="cuda", point_noise=0.02):
+    """The same scene model drawn with torch on the device (the dense (S,N) random fields of ``make_scene`` cost ~25 s of
+    numpy per 100k tracks at 400 frames): cameras from ``make_cameras`` (identical), points / visibility windows /
+    pixel noise / outliers from a torch generator -- the same distributions, a DIFFERENT random stream, so this is
+    for throughput workloads (bench.py's 400-frame configurations), not for parity fixtures.
+    Returns a namespace: extrinsics / intrinsics / extra_params (numpy, ground truth), points3D (N,3) f64, tracks (S,N,2)
+    f32, mask (S,N) bool, points3D_init (N,3) f64 = ground truth + N(0, point_noise) -- tensors on `device`."""
+    import types
+
+    import torch
+    ext, K, extra = make_cameras(S, camera_type, shared_camera, seed)
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed + 1 if track_seed is None else track_seed))
+    dev = torch.device(device)
+    U = lambda *shape: torch.rand(*shape, generator=g, device=dev, dtype=torch.float64)
+    pts = torch.tensor([0.0, 0.0, 4.0], device=dev, dtype=torch.float64) + (2.0 * U(N, 3) - 1.0)
+    lo = max(3, int(np.ceil(0.1 * S)))
+    hi = max(lo, int(np.ceil(0.4 * S)))
+    length = torch.randint(lo, hi + 1, (N,), generator=g, device=dev)
+    start = (U(N) * (S - length + 1).double()).long()
+    frames = torch.arange(S, device=dev)[:, None]
+    mask = (frames >= start[None]) & (frames < (start + length)[None])
+    E, Kt = torch.from_numpy(ext).to(dev), torch.from_numpy(K).to(dev)
+    Xc = torch.einsum("sij,nj->sni", E[:, :, :3], pts) + E[:, None, :, 3]
+    u, v = Xc[..., 0] / Xc[..., 2], Xc[..., 1] / Xc[..., 2]
+    if extra is not None:
+        d = 1.0 + torch.from_numpy(extra).to(dev)[:, 0][:, None] * (u * u + v * v)
+        u, v = u * d, v * d
+    uv = torch.stack([Kt[:, 0, 0][:, None] * u + Kt[:, 0, 2][:, None], Kt[:, 1, 1][:, None] * v + Kt[:, 1, 2][:, None]], -1)
+    del Xc, u, v
+    uv += noise_px * torch.randn(uv.shape, generator=g, device=dev, dtype=torch.float32)
+    outlier = (torch.rand(mask.shape, generator=g, device=dev) < outlier_frac) & mask
+    uv += outlier[..., None] * (100.0 * torch.rand(uv.shape, generator=g, device=dev, dtype=torch.float32) - 50.0)
+    init = pts + point_noise * torch.randn(pts.shape, generator=g, device=dev, dtype=torch.float64)
+    return types.SimpleNamespace(extrinsics=ext, intrinsics=K, extra_params=extra, points3D=pts, points3D_init=init,
+                                 tracks=uv.to(torch.float32), mask=mask, camera_type=camera_type, shared_camera=shared_camera,
+                                 S=S, N=N)

@@ -155,6 +155,14 @@ typedef struct {
                                  do not couple and their factorisations advance side by side in shared launches
                                  (chol.hip); a must be a multiple of 64.  The caller guarantees the structure -- with
                                  several GPUs for the SUM over ranks. */
+  const int32_t* chol_first_blk; /* device, optional: ROW ENVELOPE of the reduced system in 64-column blocks.  Entry r (r = 0 ..
+                                 ceil(n / 64) - 1) = the first block column in which block row r (rows 64 r .. 64 r + 63 of S) can
+                                 hold a non-zero; the Cholesky factor keeps the row envelope of the matrix, so the dataflow
+                                 factorisation (chol.hip) skips the tiles left of it and drops their dependences: camera
+                                 blocks that do not couple factor concurrently, whatever their number (ba.py:
+                                 find_camera_order -- nested-dissection order of sliding-window / video visibility).  NULL =
+                                 dense (then chol_split_a / b, if set, describe a two-block leading part).  The caller
+                                 guarantees the structure, with several ranks for the SUM of their systems. */
 } vgg_ba_problem;
 
 typedef struct {
@@ -301,6 +309,11 @@ int vgg_cholesky_solve(double* A, double* b, int n, void* workspace, int32_t* de
  * for tests; see vgg_ba_problem.chol_split_a) */
 int vgg_cholesky_solve_split(double* A, double* b, int n, int split_a, int split_b, void* workspace, int32_t* device_fail,
                              void* stream);
+/* the same with a row envelope: first_blk[r] (device, ceil(n / 64) entries) = first 64-column block in which rows
+ * 64 r .. 64 r + 63 of A can be non-zero (see vgg_ba_problem.chol_first_blk); b must be stored directly behind A
+ * (b == A + n * n) and n >= 128 for the envelope to be used (exposed for tests) */
+int vgg_cholesky_solve_envelope(double* A, double* b, int n, const int32_t* first_blk, void* workspace, int32_t* device_fail,
+                                void* stream);
 
 #ifdef __cplusplus
 }

@@ -159,6 +159,39 @@ def main():
     torch.cuda.synchronize()
     total = time.perf_counter() - t0
 
+    # kernel breakdown of one LM iteration of the final joint problem (HIP events, as in bench.py)
+    import ctypes
+    from vggsfm_amd import _lib
+    from vggsfm_amd.ba_options import BundleAdjustmentOptions
+    from vggsfm_amd.dist import ShardedBA
+    xyz, e_all, trk, msk, _ = table.window_tensors(0, T)
+    prob, _, _ = BA.compile_problem(xyz, e_all, vg.intrinsics.double().expand(T, -1, -1), trk, msk,
+                                    vg.extra_params.double().expand(T, -1), True, "SIMPLE_RADIAL", camera_split=True)
+    o = BundleAdjustmentOptions()
+    o.solver_options.max_num_iterations = 12
+    o.solver_options.function_tolerance = o.solver_options.gradient_tolerance = o.solver_options.parameter_tolerance = -1.0
+    sb = ShardedBA(prob, o)
+    sb.begin()
+    for _ in range(2):
+        sb.iteration()
+    L = _lib.lib()
+    L.vgg_ba_profile(1, 64)
+    torch.cuda.synchronize()
+    tk = time.perf_counter()
+    for _ in range(8):
+        sb.iteration()
+    torch.cuda.synchronize()
+    it_ms = 1e3 * (time.perf_counter() - tk) / 8
+    names = ["cam_pass<linearize>", "point_pass", "cam_pass<rhs>", "schur_tile<offdiag>", "cholesky", "point_step", "schur_tile<diag>"]
+    kernel_ms = {}
+    for kid, nm in enumerate(names):
+        tot, cnt = ctypes.c_double(), ctypes.c_int()
+        L.vgg_ba_profile_read(kid, ctypes.byref(tot), ctypes.byref(cnt), 1)
+        kernel_ms[nm] = tot.value / 8
+    L.vgg_ba_profile(0, 0)
+    order_info = dict(k_way_envelope=prob.chol_first_blk is not None, chol_split=list(prob.chol_split),
+                      envelope_blocks=None if prob.chol_first_blk is None else prob.chol_first_blk.cpu().tolist())
+
     est = table.extri[:T]
     aR, aT, a_s = V.align_camera_extrinsics(est, E)
     al = V.apply_transformation(est, aR, aT, a_s)
@@ -178,6 +211,7 @@ def main():
                final_joint_ba=dict(frames=last["frames"], points=last["points"], observations=last["observations"],
                                    n_reduced=last["n_reduced"], iterations=last["iterations"], ms=last["ms"],
                                    ms_per_iteration=last["ms"] / max(last["iterations"], 1)),
+               final_joint_problem_iteration_ms=it_ms, final_joint_problem_kernel_ms=kernel_ms, camera_order=order_info,
                table_points=int(table.num_points), table_observations=int(table.num_observations),
                max_rotation_error_rad=float(ang.max()), max_centre_error=float((c_est - c_gt).norm(dim=1).max()), path_length=path,
                focal=float(vg.intrinsics[0, 0, 0]), k1=float(vg.extra_params[0, 0]))

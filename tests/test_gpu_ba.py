@@ -22,8 +22,15 @@ def D(x):
     return None if x is None else torch.from_numpy(np.ascontiguousarray(x)).cuda()
 
 
+_KEEP = []        # workspaces handed to asynchronous launches stay referenced (a temporary would be freed -- and could be
+#                   re-used by the next allocation -- before the kernels have run)
+
+
 def _chol_ws(n):
-    return torch.empty(int(_lib.lib().vgg_cholesky_workspace_bytes(n)), dtype=torch.uint8, device="cuda")
+    ws = torch.empty(int(_lib.lib().vgg_cholesky_workspace_bytes(n)), dtype=torch.uint8, device="cuda")
+    _KEEP.append(ws)
+    del _KEEP[:-4]
+    return ws
 
 
 @pytest.mark.parametrize("n", [1, 5, 32, 33, 100, 256, 257, 350, 384, 1202])
@@ -92,6 +99,79 @@ def test_cholesky_solve_split_matches_plain(n, sa, sb):
     np.testing.assert_allclose(out[0][0], np.linalg.cholesky(A), rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-11, atol=1e-13)
     np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-10, atol=1e-13)
+
+
+@pytest.mark.parametrize("n,band,arrow", [(1202, 300, 2), (2000, 200, 130), (900, 100, 0), (6002, 384, 2)])
+def test_cholesky_envelope_matches_lapack(n, band, arrow):
+    """Dataflow factorisation with a row envelope (vgg_ba_problem.chol_first_blk): banded matrix + dense last rows
+    (the shared-intrinsics arrow) in a NESTED-DISSECTION order -- interior runs first, separators last -- so that the
+    envelope has several independent leading blocks.  Same factor and solution as LAPACK on the full matrix."""
+    rng = np.random.default_rng(n)
+    nb = n - arrow
+    M = np.zeros((n, n))
+    for i in range(nb):
+        lo = max(0, i - band)
+        M[i, lo:i] = rng.normal(size=i - lo) * 0.05
+    if arrow:
+        M[nb:, :] = np.tril(rng.normal(size=(arrow, n)) * 0.05)
+    A = M + M.T
+    A[np.arange(n), np.arange(n)] = np.abs(A).sum(1) + 1.0
+    k = max(2, min(5, nb // (3 * band)))
+    rem = nb - (k - 1) * band
+    sizes = [rem // k + (1 if j < rem % k else 0) for j in range(k)]
+    interiors, seps, pos = [], [], 0
+    for j in range(k):
+        interiors += list(range(pos, pos + sizes[j]))
+        pos += sizes[j]
+        if j < k - 1:
+            seps += list(range(pos, pos + band))
+            pos += band
+    order = np.array(interiors + seps + list(range(nb, n)))
+    Ap = A[order][:, order]
+    first_col = np.array([np.nonzero(Ap[i, :i + 1])[0][0] for i in range(n)])
+    nbk = (n + 63) // 64
+    fc = np.concatenate([first_col, np.full(nbk * 64 - n, n)])
+    first_blk = (fc.reshape(nbk, 64).min(1) // 64).astype(np.int32)
+    assert (first_blk[1:nbk - 1] > 0).any()                         # the envelope is not trivially dense
+    b = rng.normal(size=n)
+    buf = D(np.concatenate([np.tril(Ap).ravel(), b]))
+    fail = torch.zeros(1, dtype=torch.int32, device="cuda")
+    At, bt = buf[:n * n], buf[n * n:]
+    fb_dev, ws = D(first_blk), _chol_ws(n)           # (kept alive until the launches have run: the call is asynchronous)
+    rc = _lib.lib().vgg_cholesky_solve_envelope(_lib.ptr(At), _lib.ptr(bt), n, _lib.ptr(fb_dev), _lib.ptr(ws),
+                                                _lib.ptr(fail), _lib.stream_ptr())
+    assert rc == 0 and int(fail.item()) == 0
+    xr = np.linalg.solve(Ap, b)
+    np.testing.assert_allclose(bt.cpu().numpy(), xr, rtol=1e-8, atol=1e-10 * np.abs(xr).max())
+    np.testing.assert_allclose(np.tril(At.cpu().numpy().reshape(n, n)), np.linalg.cholesky(Ap), rtol=1e-9, atol=1e-11)
+
+
+def test_ba_kway_camera_order_matches_frame_order(monkeypatch):
+    """Video-like visibility (tracks of at most 30 of 640 frames): compile_problem orders the cameras [interior runs,
+    separators] (ba.find_camera_order) and hands the row envelope to the dataflow factorisation.  Same trajectory as
+    the solve in frame order, outputs in the order of the input frames."""
+    sc = make_scene(640, 14000, "SIMPLE_RADIAL", shared_camera=True, seed=29)
+    first = np.argmax(sc.mask, axis=0)
+    cut = np.arange(640)[:, None] >= (first + 30)[None]
+    sc.mask[cut] = False
+    sc.vis[cut] = 0.0
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=29)
+    perm, fg = BA.find_camera_order(D(sc.mask))
+    assert perm is not None and int((fg == torch.arange(len(fg))).sum()) >= 3          # >= 3 independent leading blocks
+    opt = BundleAdjustmentOptions()
+    opt.solver_options.max_num_iterations = 10
+
+    def solve():
+        return BA.bundle_adjustment(D(pts0), D(ext0), D(K0), D(sc.tracks), D(sc.mask), None, D(extra0), True, "SIMPLE_RADIAL", opt)
+    a = solve()
+    monkeypatch.setattr(BA, "find_camera_order", lambda *x, **k: (None, None))
+    monkeypatch.setattr(BA, "CAMERA_SPLIT_MIN_STEPS", 10 ** 6)
+    ref = solve()
+    assert a[4]["num_iterations"] == ref[4]["num_iterations"]
+    assert abs(a[4]["final_cost"] - ref[4]["final_cost"]) <= 1e-9 * ref[4]["final_cost"]
+    for x, y in zip(a[:4], ref[:4]):
+        np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-7, atol=1e-7)
+    np.testing.assert_array_equal(a[1][0].cpu().numpy(), ext0[0])
 
 
 @pytest.mark.parametrize("shared,N", [(True, 8000), (False, 5000)])

@@ -29,7 +29,7 @@ class BAProblem(ctypes.Structure):
                 ("chunk_desc", ctypes.c_void_p),
                 ("entries", ctypes.c_void_p), ("num_segments", ctypes.c_int32), ("obs_slot", ctypes.c_void_p),
                 ("num_tiles", ctypes.c_int32), ("tile_desc", ctypes.c_void_p), ("tile_batches", ctypes.c_void_p),
-                ("chol_split_a", ctypes.c_int32), ("chol_split_b", ctypes.c_int32)]
+                ("chol_split_a", ctypes.c_int32), ("chol_split_b", ctypes.c_int32), ("chol_first_blk", ctypes.c_void_p)]
 
 
 class BAOptions(ctypes.Structure):
@@ -63,7 +63,7 @@ EXPORTED = ["vgg_build_arch", "vgg_abi_version", "vgg_project_points", "vgg_filt
             "vgg_ba_begin", "vgg_ba_phase", "vgg_ba_reduce_buffer", "vgg_ba_finish", "vgg_cholesky_solve",
             "vgg_ba_profile", "vgg_ba_profile_read", "vgg_cholesky_workspace_bytes", "vgg_pose_refine",
             "vgg_p3p_ransac_workspace_bytes", "vgg_p3p_ransac", "vgg_fmat_seven_point", "vgg_fmat_score",
-            "vgg_fmat_eight_point", "vgg_fmat_residuals", "vgg_cholesky_solve_split", "vgg_ba_poll_done"]
+            "vgg_fmat_eight_point", "vgg_fmat_residuals", "vgg_cholesky_solve_split", "vgg_ba_poll_done", "vgg_cholesky_solve_envelope"]
 
 _lib = None
 

@@ -107,6 +107,7 @@ class DeviceProblem:
     batch_desc: Optional[torch.Tensor] = None   # (B,6) int32 on the HOST (build_schur_tiles); None = derive one batch
     chol_split: tuple = (0, 0)        # (columns of A, columns of B): block-diagonal leading part of the reduced system
     cam_perm: Optional[torch.Tensor] = None     # (S,) long: camera s of this problem is input frame cam_perm[s] (None = identity)
+    chol_first_blk: Optional[torch.Tensor] = None   # (ceil(n / 64),) int32 device: row envelope of the reduced system (None = dense)
 
     @property
     def num_obs(self):
@@ -133,6 +134,7 @@ class DeviceProblem:
         P.num_tiles = self.tile_desc.shape[0]
         P.num_segments = self.num_segments
         P.chol_split_a, P.chol_split_b = int(self.chol_split[0]), int(self.chol_split[1])
+        P.chol_first_blk = None if self.chol_first_blk is None else self.chol_first_blk.data_ptr()
         return P
 
 
@@ -289,6 +291,83 @@ def find_camera_split(masks, group=GROUP, adjacency_reduce=None):
     return perm, (6 * group * a, 6 * group * (Gfull - b))
 
 
+def _group_adjacency(masks, group, adjacency_reduce):
+    S = masks.shape[0]
+    G = (S + group - 1) // group
+    pad = G * group - S
+    m = torch.cat([masks, masks.new_zeros((pad, masks.shape[1]))]) if pad else masks
+    V = m.reshape(G, group, -1).any(1).to(torch.float32)
+    adj = ((V @ V.t()) > 0).to(torch.float32)
+    if adjacency_reduce is not None:
+        adjacency_reduce(adj)
+    return adj.cpu() > 0
+
+
+CAMERA_ORDER_MIN_GAIN = 0.8     # use the k-way order when its pivot chain is at most this fraction of the 2-way one
+
+
+def find_camera_order(masks, group=GROUP, adjacency_reduce=None):
+    """k-way generalisation of :func:`find_camera_split` for banded visibility (video: a track spans a few dozen of a
+    thousand frames).  With a band of w camera groups, k interior runs of groups separated by k - 1 separators of w
+    groups do not couple with each other; ordered [interior_1 .. interior_k, separator_1 .. separator_{k-1}, partial last
+    group] the reduced system has k independent leading blocks, and what is left -- the separators -- is block
+    tridiagonal.  The dataflow factorisation needs no special casing for this: it is told the ROW ENVELOPE of the
+    permuted matrix (``chol_first_blk``) and factors whatever does not depend on each other concurrently; the pivot
+    chain shrinks from all G groups to (interior + all separators).
+    Returns (perm (S,) long new -> input frame, first_group (G,) long: for the group at new position p the first new
+    position it couples with) or (None, None) when the order would not pay."""
+    S = masks.shape[0]
+    G = (S + group - 1) // group
+    Gfull = S // group
+    if Gfull < 6:
+        return None, None
+    adj = _group_adjacency(masks, group, adjacency_reduce)
+    ii, jj = torch.nonzero(adj[:Gfull, :Gfull], as_tuple=True)
+    w = int((ii - jj).abs().max()) if ii.numel() else 0          # band half-width in groups
+    if w < 1 or 2 * w + 2 > Gfull:
+        return None, None
+    best = None
+    for k in range(2, Gfull):
+        sep = (k - 1) * w
+        rem = Gfull - sep
+        if rem < k:
+            break
+        chain = -(-rem // k) + sep                                # longest interior + every separator
+        if best is None or chain < best[0]:
+            best = (chain, k)
+    two_way = -(-(Gfull - w) // 2) + w
+    if best is None or best[1] <= 2 or best[0] > CAMERA_ORDER_MIN_GAIN * two_way:
+        return None, None
+    chain, k = best
+    rem = Gfull - (k - 1) * w
+    sizes = [rem // k + (1 if j < rem % k else 0) for j in range(k)]
+    interiors, separators, pos = [], [], 0
+    for j in range(k):
+        interiors.append(list(range(pos, pos + sizes[j])))
+        pos += sizes[j]
+        if j < k - 1:
+            separators.append(list(range(pos, pos + w)))
+            pos += w
+    order = [g for run in interiors for g in run] + [g for run in separators for g in run] + list(range(Gfull, G))
+    order_t = torch.tensor(order)
+    adjp = adj[order_t][:, order_t]
+    first_group = torch.tensor([int(torch.nonzero(adjp[p, :p + 1])[0]) if bool(adjp[p, :p + 1].any()) else p for p in range(G)])
+    dev = masks.device
+    perm = torch.cat([torch.arange(group * g, min(group * (g + 1), S), device=dev) for g in order])
+    return perm, first_group
+
+
+def envelope_blocks(first_group, num_cams, n_reduced, group=GROUP, block=64):
+    """Row envelope of the reduced system in `block`-column blocks from the camera-group structure: pose rows of the
+    cameras of the group at position p start at column 6 * group * first_group[p]; the intrinsics rows behind the 6 C
+    pose columns (and the appended right-hand side) are dense.  -> (ceil(n / block),) int32."""
+    nbk = (n_reduced + block - 1) // block
+    rows = torch.arange(nbk * block)
+    cam = torch.clamp(rows // 6, max=num_cams - 1)
+    first_col = torch.where(rows < 6 * num_cams, 6 * group * first_group[cam // group], torch.zeros_like(rows))
+    return (first_col.reshape(nbk, block).min(1).values // block).to(torch.int32)
+
+
 def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_params=None, shared_camera=False,
                     camera_type="SIMPLE_PINHOLE", max_points3D_val=3000, filter_negative_depth=True,
                     gauge="colmap", overlap=None, camera_split=False, adjacency_reduce=None):
@@ -306,9 +385,11 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
     ext = extrinsics.to(torch.float64)
     K = intrinsics.to(torch.float64)
     masks = masks.bool()
-    cam_perm, chol_split = (None, (0, 0))
+    cam_perm, chol_split, first_group = (None, (0, 0), None)
     if camera_split:
-        cam_perm, chol_split = find_camera_split(masks, adjacency_reduce=adjacency_reduce)
+        cam_perm, first_group = find_camera_order(masks, adjacency_reduce=adjacency_reduce)       # k > 2 interior runs
+        if cam_perm is None:
+            cam_perm, chol_split = find_camera_split(masks, adjacency_reduce=adjacency_reduce)   # two leading blocks
     if cam_perm is not None:                        # (frames 0 and 1 -- the default gauge -- stay first: A is a prefix)
         ext, K, masks, tracks = ext[cam_perm], K[cam_perm], masks[cam_perm], tracks[cam_perm]
         if extra_params is not None:
@@ -369,6 +450,9 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
     prob = DeviceProblem(cam_q, cam_t, intr, pts, row_ptr, obs_cam, obs_uv, col_ptr, cobs_pt, cobs_uv, chunk_desc,
                          entries, tile_desc, obs_slot, nseg, MODEL_ID[camera_type], cam_const=cam_const,
                          batch_desc=batch_desc, chol_split=chol_split, cam_perm=cam_perm)
+    if first_group is not None:
+        kd = 2 if camera_type == "SIMPLE_RADIAL" else 1              # upper bound of the intrinsics unknowns per block
+        prob.chol_first_blk = envelope_blocks(first_group, S, 6 * S + kd * n_intr).to(dev)
     return prob, valid_idx, deleted
 
 

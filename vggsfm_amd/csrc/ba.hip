@@ -30,7 +30,7 @@
 namespace vgg {
 
 int cholesky_solve_enqueue(double* A, double* b, int n, double* inv_blocks, int32_t* device_fail, const int32_t* skip_flag,
-                           hipStream_t st, const CholOverlap* overlap, int split_a, int split_b);
+                           hipStream_t st, const CholOverlap* overlap, int split_a, int split_b, const int32_t* first_blk);
 size_t cholesky_workspace_bytes(int n);
 
 constexpr int kGroup = 16;       // cameras per Schur tile side
@@ -1276,6 +1276,7 @@ struct Launch {
   const int32_t* tile_desc; int num_tiles;
   const int32_t* batches; int num_batches;      // HOST table [num_batches][6], see vgg_ba_problem.tile_batches
   int chol_split_a, chol_split_b;               // block-diagonal leading part of the reduced system (0 = none)
+  const int32_t* chol_first_blk;                // row envelope of the reduced system in 64-column blocks (device) or NULL
   double *cam_q, *cam_t, *intr, *pts;
 };
 
@@ -1424,14 +1425,14 @@ static int phase_step(const Launch& L) {
     }
     {
       ProfScope ps(kProfCholesky, oc->st_chol);
-      rc = cholesky_solve_enqueue(L.w.S, L.w.rhs, d.n_red, L.w.chol_inv, &L.w.ctl->linear_fail, &L.w.ctl->done, oc->st_chol, &ov, 0, 0);
+      rc = cholesky_solve_enqueue(L.w.S, L.w.rhs, d.n_red, L.w.chol_inv, &L.w.ctl->linear_fail, &L.w.ctl->done, oc->st_chol, &ov, 0, 0, nullptr);
     }
     (void)hipEventRecord(oc->chol_done, oc->st_chol);
     (void)hipStreamWaitEvent(L.st, oc->chol_done, 0);
   } else {
     ProfScope ps(kProfCholesky, L.st);
     rc = cholesky_solve_enqueue(L.w.S, L.w.rhs, d.n_red, L.w.chol_inv, &L.w.ctl->linear_fail, &L.w.ctl->done, L.st, nullptr,
-                                L.chol_split_a, L.chol_split_b);
+                                L.chol_split_a, L.chol_split_b, L.chol_first_blk);
   }
   if (rc != VGG_OK) return rc;
   cam_update_kernel<KD><<<div_up(d.C + 1, 64), 64, 0, L.st>>>(L.dp, L.w);
@@ -1470,6 +1471,7 @@ static int make_launch(const vgg_ba_problem* pb, const vgg_ba_options* opt, void
   L->num_segments = pb->num_segments;
   L->batches = pb->tile_batches; L->num_batches = pb->num_tile_batches;
   L->chol_split_a = pb->chol_split_a; L->chol_split_b = pb->chol_split_b;
+  L->chol_first_blk = pb->chol_first_blk;
   if (pb->chol_split_a < 0 || pb->chol_split_b < 0 || pb->chol_split_a % 64 != 0 ||
       pb->chol_split_a + pb->chol_split_b > 6 * pb->num_cams)
     return VGG_ERR_INVALID_ARGUMENT;

@@ -791,7 +791,7 @@ struct DfShared {
 // flags: ready[(nbk + 1) * nbk] (tile (r, c) final), then tready[nbk]; all zero on entry.
 __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__ A, int n, int nbk, double* __restrict__ Tinv,
                                                             int32_t* __restrict__ flags, int32_t* fail, const int32_t* skip,
-                                                            int split_a, int split_b) {
+                                                            int split_a, int split_b, const int32_t* __restrict__ first_blk) {
   extern __shared__ double df_smem[];
   DfShared& sh = *reinterpret_cast<DfShared*>(df_smem);
   constexpr int LD = DFB + 1;
@@ -800,7 +800,10 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
   int c = 0, t = blockIdx.x;
   while (t >= nbk - c + 1) { t -= nbk - c + 1; ++c; }
   const int r = c + t;                                  // r == nbk: the appended right-hand side (one row)
-  auto first_of = [&](int br) { return (split_b > 0 && br < nbk && DFB * br >= split_a && DFB * (br + 1) <= split_a + split_b) ? split_a / DFB : 0; };
+  auto first_of = [&](int br) {
+    if (first_blk) return (br < nbk) ? first_blk[br] : 0;                  // row envelope given by the caller
+    return (split_b > 0 && br < nbk && DFB * br >= split_a && DFB * (br + 1) <= split_a + split_b) ? split_a / DFB : 0;
+  };
   if (c < first_of(r)) return;                          // structurally zero tile (block-diagonal leading part)
   const int kfirst = max(first_of(r), first_of(c));
   int32_t* ready = flags;
@@ -955,9 +958,75 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
   DF_STAMP(3);
 }
 
+// Backward substitution L^T x = z in dataflow form: one workgroup per 64-column block c (launched last block first, so
+// that a workgroup only waits for EARLIER ones).  Workgroup c accumulates sum_r L[r][c]^T x_r over the block rows r > c
+// inside the envelope as their x_r are published (fixed order r = last .. c + 1: deterministic), then x_c = T_c (z_c - sum)
+// with T_c = L_cc^-T from the factorisation.  The tile L[r][c] is fetched BEFORE the wait for x_r, so the step on the
+// critical path is one 64 x 64 mat-vec + the T mat-vec + a 512-byte hand-off.  (The single-workgroup kernel above reads
+// the whole factor through one CU: 0.14 ms at n = 1202, ~3.5 ms at n = 6002.)
+__global__ __launch_bounds__(256) void chol_backward_dataflow_kernel(const double* __restrict__ L, double* __restrict__ b, int n,
+                                                                     int nbk, const double* __restrict__ Tinv,
+                                                                     int32_t* __restrict__ xready, int32_t* fail,
+                                                                     const int32_t* skip, int split_a, int split_b,
+                                                                     const int32_t* __restrict__ first_blk) {
+  constexpr int LD = DFB + 1;
+  __shared__ double Ts[DFB * LD];
+  __shared__ double xs[DFB], part[4][DFB], w[DFB];
+  if (skip && *skip) return;
+  const int c = nbk - 1 - (int)blockIdx.x, c0 = DFB * c, vc = min(DFB, n - c0);
+  const int tid = threadIdx.x, j = tid & 63, q = tid >> 6;          // thread: column j of the tile, rows 16 q .. 16 q + 15
+  auto first_of = [&](int br) {
+    if (first_blk) return first_blk[br];
+    return (split_b > 0 && DFB * br >= split_a && DFB * (br + 1) <= split_a + split_b) ? split_a / DFB : 0;
+  };
+  for (int e = tid; e < DFB * DFB; e += 256) Ts[(e / DFB) * LD + e % DFB] = Tinv[(size_t)c * DFB * DFB + e];
+  double acc = 0.0;
+  auto load_tile = [&](int r, double (&t)[16]) {
+    const int r0 = DFB * r, vr = min(DFB, n - r0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = 16 * q + i;
+      t[i] = (row < vr && j < vc) ? L[(size_t)(r0 + row) * n + c0 + j] : 0.0;
+    }
+  };
+  int r = nbk - 1;
+  while (r > c && first_of(r) > c) --r;
+  double cur[16], nxt[16];
+  if (r > c) load_tile(r, cur);
+  while (r > c) {
+    int rn = r - 1;
+    while (rn > c && first_of(rn) > c) --rn;
+    if (rn > c) load_tile(rn, nxt);                       // in flight while this workgroup waits for x_r
+    df_wait(&xready[r], fail);
+    if (tid < DFB) xs[tid] = (DFB * r + tid < n) ? ld_agent(&b[DFB * r + tid]) : 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc += cur[i] * xs[16 * q + i];
+    __syncthreads();                                      // xs consumed
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cur[i] = nxt[i];
+    r = rn;
+  }
+  part[q][j] = acc;
+  __syncthreads();
+  if (tid < DFB) w[tid] = ((tid < vc) ? b[c0 + tid] : 0.0) - (((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid]);
+  __syncthreads();
+  // x_c[i] = sum_{j >= i} T[i][j] w[j]: thread (i = tid & 63, quarter q of the columns)
+  {
+    const int i = tid & 63;
+    double s0 = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) s0 += Ts[i * LD + 16 * q + jj] * w[16 * q + jj];
+    part[q][i] = s0;
+  }
+  __syncthreads();
+  if (tid < vc) st_agent(&b[c0 + tid], ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid]);
+  df_publish(&xready[c]);
+}
+
 static size_t dataflow_flag_count(int n) {
   const int nbk = div_up(n, DFB);
-  return (size_t)(nbk + 1) * nbk + nbk;
+  return (size_t)(nbk + 1) * nbk + 2 * (size_t)nbk;        // ready[(nbk + 1) nbk], tready[nbk], xready[nbk]
 }
 static size_t dataflow_workspace_bytes(int n) {
   return (size_t)div_up(n, DFB) * DFB * DFB * sizeof(double) + dataflow_flag_count(n) * sizeof(int32_t) + 256;
@@ -980,7 +1049,7 @@ static bool use_dataflow(int n) {
 }
 
 static int enqueue_dataflow(double* A, double* b, int n, double* ws, int32_t* device_fail, const int32_t* skip, hipStream_t st,
-                            int split_a, int split_b) {
+                            int split_a, int split_b, const int32_t* first_blk) {
   const int nbk = div_up(n, DFB);
   double* Tinv = ws;
   int32_t* flags = reinterpret_cast<int32_t*>(ws + (size_t)nbk * DFB * DFB);
@@ -993,16 +1062,9 @@ static int enqueue_dataflow(double* A, double* b, int n, double* ws, int32_t* de
   }
   if (!(split_a >= DFB && split_b >= DFB && split_a % DFB == 0 && split_a + split_b <= n)) split_a = split_b = 0;
   const int tiles = nbk * (nbk + 1) / 2 + nbk;
-  chol_dataflow_kernel<<<tiles, 256, sizeof(DfShared), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b);
-  const size_t back_lds = ((size_t)nbk * DFB + DFB * (DFB + 1) + DFB) * sizeof(double);
-  if (back_lds <= 150 * 1024) {
-    if (back_lds > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_backward_kernel<DFB>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)back_lds) != hipSuccess) return VGG_ERR_HIP;
-    chol_backward_kernel<DFB><<<1, kBackThreads, back_lds, st>>>(A, b, n, Tinv, skip);
-  } else {
-    chol_solve_kernel<32><<<1, 256, 0, st>>>(A, b, n, 0, 1, skip);
-  }
+  chol_dataflow_kernel<<<tiles, 256, sizeof(DfShared), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b, first_blk);
+  int32_t* xready = flags + (size_t)(nbk + 1) * nbk + nbk;
+  chol_backward_dataflow_kernel<<<nbk, 256, 0, st>>>(A, b, n, nbk, Tinv, xready, device_fail, skip, split_a, split_b, first_blk);
   if (hipGetLastError() != hipSuccess) return VGG_ERR_HIP;
   return VGG_OK;
 }
@@ -1085,10 +1147,10 @@ static int enqueue(double* A, double* b, int n, double* inv_blocks, int32_t* dev
 }
 
 int cholesky_solve_enqueue(double* A, double* b, int n, double* inv_blocks, int32_t* device_fail, const int32_t* skip,
-                           hipStream_t st, const CholOverlap* overlap, int split_a, int split_b) {
+                           hipStream_t st, const CholOverlap* overlap, int split_a, int split_b, const int32_t* first_blk) {
   if (!inv_blocks) return VGG_ERR_INVALID_ARGUMENT;
   if (!overlap && b == A + (size_t)n * n && use_dataflow(n))
-    return enqueue_dataflow(A, b, n, inv_blocks, device_fail, skip, st, split_a, split_b);
+    return enqueue_dataflow(A, b, n, inv_blocks, device_fail, skip, st, split_a, split_b, first_blk);
   return enqueue<32>(A, b, n, inv_blocks, device_fail, skip, st, overlap, split_a, split_b);
 }
 
@@ -1099,13 +1161,19 @@ size_t vgg_cholesky_workspace_bytes(int n) { return n > 0 ? vgg::cholesky_worksp
 
 int vgg_cholesky_solve(double* A, double* b, int n, void* workspace, int32_t* device_fail, void* stream) {
   if (n <= 0 || !A || !b || !workspace) return VGG_ERR_INVALID_ARGUMENT;
-  return vgg::cholesky_solve_enqueue(A, b, n, (double*)workspace, device_fail, nullptr, (hipStream_t)stream, nullptr, 0, 0);
+  return vgg::cholesky_solve_enqueue(A, b, n, (double*)workspace, device_fail, nullptr, (hipStream_t)stream, nullptr, 0, 0, nullptr);
+}
+
+int vgg_cholesky_solve_envelope(double* A, double* b, int n, const int32_t* first_blk, void* workspace, int32_t* device_fail,
+                                void* stream) {
+  if (n <= 0 || !A || !b || !workspace || !first_blk) return VGG_ERR_INVALID_ARGUMENT;
+  return vgg::cholesky_solve_enqueue(A, b, n, (double*)workspace, device_fail, nullptr, (hipStream_t)stream, nullptr, 0, 0, first_blk);
 }
 
 int vgg_cholesky_solve_split(double* A, double* b, int n, int split_a, int split_b, void* workspace, int32_t* device_fail,
                              void* stream) {
   if (n <= 0 || !A || !b || !workspace || split_a < 0 || split_b < 0 || split_a + split_b > n) return VGG_ERR_INVALID_ARGUMENT;
   return vgg::cholesky_solve_enqueue(A, b, n, (double*)workspace, device_fail, nullptr, (hipStream_t)stream, nullptr, split_a,
-                                     split_b);
+                                     split_b, nullptr);
 }
 }

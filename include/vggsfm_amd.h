@@ -163,6 +163,12 @@ typedef struct {
                                  find_camera_order -- nested-dissection order of sliding-window / video visibility).  NULL =
                                  dense (then chol_split_a / b, if set, describe a two-block leading part).  The caller
                                  guarantees the structure, with several ranks for the SUM of their systems. */
+  const int32_t* block_chunk;    /* device, optional [num_chunks]: launch position -> chunk.  Workgroup b of a tile launch runs
+                                 on XCD b % 8 (private L2 each); the host side cuts the point range into 8 parts, chunks every
+                                 tile per part and places the chunks of part x at the positions = x (mod 8) of their launch
+                                 range, so that all tiles stage a given point's segments on ONE XCD (ba.py:
+                                 build_schur_tiles).  A permutation inside every [chunk_begin, first_diagonal_chunk) and
+                                 [first_diagonal_chunk, chunk_end) range of tile_batches.  NULL = identity. */
 } vgg_ba_problem;
 
 typedef struct {

@@ -144,9 +144,10 @@ def test_normalize_matches_oracle():
     np.testing.assert_allclose(p1.numpy(), p2, rtol=1e-13, atol=1e-13)
 
 
+@pytest.mark.parametrize("xcds", [1, 8])
 @pytest.mark.parametrize("num_batches", [1, 2, 3])
 @pytest.mark.parametrize("max_chunks", [1, 7, 40, 100000])
-def test_schur_chunks_adaptive_cover(max_chunks, num_batches):
+def test_schur_chunks_adaptive_cover(max_chunks, num_batches, xcds):
     """Adaptive chunk size: every entry belongs to exactly one workgroup's strided sub-chunks and the
     workgroup count respects the device capacity (or is one per tile when there are more tiles than slots).
     Batches: consecutive chunk / tile ranges, off-diagonal chunks before the diagonal ones inside each batch,
@@ -159,15 +160,29 @@ def test_schur_chunks_adaptive_cover(max_chunks, num_batches):
     obs_cam = pm[:, 1].to(torch.int32)
     row_ptr = torch.zeros(P + 1, dtype=torch.int32)
     row_ptr[1:] = torch.cumsum(m.sum(0), 0).to(torch.int32)
-    desc, ent, tiles, slot, nseg, batches = BA.build_schur_tiles(row_ptr, obs_cam, max_chunks=max_chunks,
-                                                                 num_batches=num_batches, later_scale=0.875)
+    desc, ent, tiles, slot, nseg, batches, block_chunk = BA.build_schur_tiles(row_ptr, obs_cam, max_chunks=max_chunks,
+                                                                              num_batches=num_batches, later_scale=0.875, xcds=xcds)
     seen = np.zeros(len(ent), int)
     for gI, gJ, tb, te, j, J in desc.numpy():
         for s0 in range(tb + j * BA.SUB, te, J * BA.SUB):
             seen[s0:min(s0 + BA.SUB, te)] += 1
     assert (seen == 1).all()
-    assert len(desc) <= max(2 * max_chunks * num_batches, len(tiles))
+    assert len(desc) <= max(2 * max_chunks * num_batches, xcds * len(tiles))
     td, cd, bd = tiles.numpy(), desc.numpy(), batches.numpy()
+    # XCD placement: a permutation inside every launch range; a chunk's entries belong to ONE point-range part, and the
+    # chunks at the positions = x (mod 8) of a range are those of part x as long as part x has any left
+    bc = block_chunk.numpy()
+    pts = ent.numpy()[:, 0]
+    cuts = np.unique(np.concatenate([[pts[tb:te].min(), pts[tb:te].max()] for _, _, tb, te, _, _ in cd]))
+    for c0, cm, c1 in bd[:, :3]:
+        for lo, hi in ((c0, cm), (cm, c1)):
+            assert sorted(bc[lo:hi].tolist()) == list(range(lo, hi))
+    # every point's entries live in chunks of one part: the point ranges of different parts do not overlap
+    part_range = {}
+    for ci, (_, _, tb, te, _, _) in enumerate(cd):
+        part_range.setdefault((int(pts[tb:te].min()), int(pts[tb:te].max())), []).append(ci)
+    ranges = sorted(part_range)
+    assert len(ranges) <= xcds * max(1, num_batches) * 2 * len(td)
     assert td[0, 2] == 0 and td[-1, 3] == len(desc) and (td[1:, 2] == td[:-1, 3]).all()
     assert not batches.is_cuda and bd.shape == (num_batches, 6)
     assert bd[0, 0] == 0 and bd[-1, 2] == len(cd) and bd[0, 3] == 0 and bd[-1, 4] == len(td)

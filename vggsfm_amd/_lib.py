@@ -10,7 +10,8 @@ import os
 import torch  # noqa: F401  (must be loaded before the HIP library, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvggsfm_amd.so")
+# (VGGSFM_AMD_LIB: an alternative build of the same library, for A/B measurements of kernel variants)
+LIB_PATH = os.environ.get("VGGSFM_AMD_LIB") or os.path.join(_HERE, "libvggsfm_amd.so")
 
 VGG_OK = 0
 _ERRORS = {-1: "invalid argument", -2: "HIP runtime error", -3: "workspace too small / missing",
@@ -29,7 +30,7 @@ class BAProblem(ctypes.Structure):
                 ("chunk_desc", ctypes.c_void_p),
                 ("entries", ctypes.c_void_p), ("num_segments", ctypes.c_int32), ("obs_slot", ctypes.c_void_p),
                 ("num_tiles", ctypes.c_int32), ("tile_desc", ctypes.c_void_p), ("tile_batches", ctypes.c_void_p),
-                ("chol_split_a", ctypes.c_int32), ("chol_split_b", ctypes.c_int32), ("chol_first_blk", ctypes.c_void_p)]
+                ("chol_split_a", ctypes.c_int32), ("chol_split_b", ctypes.c_int32), ("chol_first_blk", ctypes.c_void_p), ("block_chunk", ctypes.c_void_p)]
 
 
 class BAOptions(ctypes.Structure):

@@ -36,6 +36,11 @@ OVERLAP_FACTORIZATION = False
 OVERLAP_MIN_OBS, OVERLAP_MIN_FRAMES = 1_000_000, 8 * GROUP   # smaller problems keep one batch
 TILE_BATCHES = 3     # Schur tile launches per iteration when the factorisation overlaps them (large problems)
 CHOL_CUS = 32        # CUs given to the factorisation while it overlaps (options.overlap_factorization; multiple of 32)
+XCDS = 1             # point-range parts for XCD placement of the Schur tile chunks (build_schur_tiles); 8 = one part per
+#                      accelerator complex die.  MEASURED AND LEFT OFF (round 2, c3): with 8 parts FETCH_SIZE of the
+#                      off-diagonal launch only went from 3.04 to 2.79 GB and the launch from 0.64 to 0.76 ms -- a 4 MB L2
+#                      turns over every ~6 us under this stream, far less than the drift between the tiles that share a
+#                      segment, so same-XCD placement alone does not produce hits
 
 
 # ------------------------------------------------------------------ rotations (Eigen conventions)
@@ -108,6 +113,7 @@ class DeviceProblem:
     chol_split: tuple = (0, 0)        # (columns of A, columns of B): block-diagonal leading part of the reduced system
     cam_perm: Optional[torch.Tensor] = None     # (S,) long: camera s of this problem is input frame cam_perm[s] (None = identity)
     chol_first_blk: Optional[torch.Tensor] = None   # (ceil(n / 64),) int32 device: row envelope of the reduced system (None = dense)
+    block_chunk: Optional[torch.Tensor] = None      # (num_chunks,) int32 device: launch position -> chunk (XCD placement; None = identity)
 
     @property
     def num_obs(self):
@@ -135,10 +141,11 @@ class DeviceProblem:
         P.num_segments = self.num_segments
         P.chol_split_a, P.chol_split_b = int(self.chol_split[0]), int(self.chol_split[1])
         P.chol_first_blk = None if self.chol_first_blk is None else self.chol_first_blk.data_ptr()
+        P.block_chunk = None if self.block_chunk is None else self.block_chunk.data_ptr()
         return P
 
 
-def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=None, num_batches=1, later_scale=1.0):
+def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=None, num_batches=1, later_scale=1.0, xcds=XCDS):
     """Block-sparse Schur work list (device, torch ops; structure is fixed for the whole solve).
 
     A *segment* is the run of one point's observations that falls into one group of `group`
@@ -155,14 +162,22 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     of group g are done -- which lets the factorisation start on the first batch while the later ones are still
     being computed.  batch_desc row = (chunk_begin, first_diagonal_chunk, chunk_end, tile_begin, tile_end,
     first_camera_group).  `later_scale` shrinks the workgroup caps of the batches after the first (they run on a
-    CU-masked stream beside the factorisation)."""
+    CU-masked stream beside the factorisation).
+
+    XCD placement (`xcds` > 1): a point with segments in g camera groups appears in g (g + 1) / 2 tiles, and every one of
+    them stages the point's segments again.  The eight XCDs have private L2s, and workgroup b of a launch runs on XCD
+    b % 8: so the POINT range is cut into `xcds` parts of about equal entry counts, every tile's entry list is chunked
+    per part, and the returned `block_chunk` (num_chunks,) int32 maps launch position -> chunk such that the chunks of
+    part x sit at positions = x (mod xcds).  All tiles then process a given point on the same XCD and its segments come
+    through the fabric once per iteration instead of once per tile -- in principle; see the note at XCDS (measured:
+    no pay-off, default 1 part)."""
     dev = obs_cam.device
     O = obs_cam.shape[0]
     P = row_ptr.shape[0] - 1
     if O == 0:
         z = torch.zeros((0, 4), dtype=torch.int32, device=dev)
         return (torch.zeros((0, 6), dtype=torch.int32, device=dev), z, z.clone(), torch.zeros(0, dtype=torch.int32, device=dev), 0,
-                torch.zeros((1, 6), dtype=torch.int32))
+                torch.zeros((1, 6), dtype=torch.int32), torch.zeros(0, dtype=torch.int32, device=dev))
     counts = (row_ptr[1:] - row_ptr[:-1]).long()
     obs_pt = torch.repeat_interleave(torch.arange(P, device=dev), counts)
     grp = (obs_cam // group).long()
@@ -197,7 +212,16 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     order = torch.argsort(key, stable=True)
     A, B, key = A[order], B[order], key[order]
     entries = torch.stack([seg_pt[A], A, B, seg_mask[A] | (seg_mask[B] << 16)], 1).to(torch.int32)
-    ukeys, kcounts = torch.unique_consecutive(key, return_counts=True)
+    # part of an entry = the XCD its point belongs to: `xcds` contiguous point ranges with about equal entry counts
+    xcds = max(1, int(xcds))
+    per_point = torch.bincount(seg_pt[A], minlength=P).double()
+    cum_pt = torch.cumsum(per_point, 0) - per_point
+    part_of_point = torch.clamp((cum_pt * xcds / max(float(total), 1.0)).long(), max=xcds - 1)
+    epart = part_of_point[seg_pt[A]]
+    # chunking unit = (tile, part): inside a tile the entries are sorted by point, hence by part
+    ukeys, kcounts = torch.unique_consecutive(key * xcds + epart, return_counts=True)
+    upart = ukeys % xcds
+    ukeys = ukeys // xcds
     tile_start = torch.cumsum(kcounts, 0) - kcounts
     tbatch = ukeys // (2 * nn)
     is_diag = (ukeys % (2 * nn)) >= nn
@@ -222,15 +246,26 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
                     lo, hi = (lo, mid) if fits(mid) else (mid + 1, hi)
                 csize[sel] = lo * SUB
     nchunks = (kcounts + csize - 1) // csize
-    ctile = torch.repeat_interleave(torch.arange(ukeys.shape[0], device=dev), nchunks)
+    ctile = torch.repeat_interleave(torch.arange(ukeys.shape[0], device=dev), nchunks)          # unit of every chunk
     cfirst = torch.cumsum(nchunks, 0) - nchunks
     local = torch.arange(ctile.shape[0], device=dev) - cfirst[ctile]
     chunk_desc = torch.stack([ukeys[ctile] // ngroups, ukeys[ctile] % ngroups, tile_start[ctile],
                               tile_start[ctile] + kcounts[ctile], local, nchunks[ctile]], 1).to(torch.int32)
-    tile_desc = torch.stack([ukeys // ngroups, ukeys % ngroups, cfirst, cfirst + nchunks], 1).to(torch.int32)
+    chunk_part = upart[ctile]
+    # tiles: runs of consecutive units with the same tile key (the partial tiles of ALL their chunks are summed)
+    ukey_full = tbatch * (2 * nn) + is_diag.long() * nn + ukeys
+    new_tile = torch.ones_like(ukey_full, dtype=torch.bool)
+    new_tile[1:] = ukey_full[1:] != ukey_full[:-1]
+    tfirst_unit = torch.nonzero(new_tile).squeeze(1)
+    tile_of_unit = torch.cumsum(new_tile.long(), 0) - 1
+    t_chunks = torch.zeros(tfirst_unit.shape[0], dtype=torch.long, device=dev).index_add_(0, tile_of_unit, nchunks)
+    t_cfirst = cfirst[tfirst_unit]
+    tile_desc = torch.stack([ukeys[tfirst_unit] // ngroups, ukeys[tfirst_unit] % ngroups, t_cfirst, t_cfirst + t_chunks],
+                            1).to(torch.int32)
     obs_slot = (seg_id * group + obs_cam.long() % group).to(torch.int32)
-    # host-side batch table
-    tb, td, tn, tf = tbatch.cpu(), is_diag.cpu(), nchunks.cpu(), cfirst.cpu()
+    # host-side batch table (per tile)
+    tbatch, is_diag, ukeys = tbatch[tfirst_unit], is_diag[tfirst_unit], ukeys[tfirst_unit]
+    tb, td, tn, tf = tbatch.cpu(), is_diag.cpu(), t_chunks.cpu(), t_cfirst.cpu()
     tg = (ukeys // ngroups).cpu()
     batch_desc = torch.zeros((nb, 6), dtype=torch.int32)
     for b in range(nb):
@@ -245,8 +280,25 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
         dg = ids[td[ids]]
         cm = int(tf[dg[0]]) if dg.numel() else c1
         batch_desc[b] = torch.tensor([c0, cm, c1, int(ids[0]), int(ids[-1]) + 1, int(tg[ids].min())])
+    # launch position -> chunk: inside every launch range (off-diagonal / diagonal chunks of a batch) the chunks of part x
+    # go to the positions = x (mod xcds); a part that runs out of chunks is filled from the fullest remaining one
+    cp = chunk_part.cpu().tolist()
+    block_chunk = list(range(len(cp)))
+    if xcds > 1:
+        for b in range(nb):
+            c0, cm, c1 = (int(v) for v in batch_desc[b, :3])
+            for lo, hi in ((c0, cm), (cm, c1)):
+                lists = [[c for c in range(lo, hi) if cp[c] == x] for x in range(xcds)]
+                heads = [0] * xcds
+                for pos in range(lo, hi):
+                    x = (pos - lo) % xcds
+                    if heads[x] >= len(lists[x]):
+                        x = max(range(xcds), key=lambda y: len(lists[y]) - heads[y])
+                    block_chunk[pos] = lists[x][heads[x]]
+                    heads[x] += 1
+    block_chunk = torch.tensor(block_chunk, dtype=torch.int32, device=dev)
     return (chunk_desc.contiguous(), entries.contiguous(), tile_desc.contiguous(), obs_slot.contiguous(), int(nseg),
-            batch_desc.contiguous())
+            batch_desc.contiguous(), block_chunk)
 
 
 CAMERA_SPLIT_MIN_STEPS = 2    # shared 64-column factorisation steps below which re-ordering the cameras is not worth it
@@ -445,11 +497,11 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
     # three batches when the factorisation can overlap the later ones (enough camera groups, enough work per batch)
     overlap = OVERLAP_FACTORIZATION if overlap is None else bool(overlap)
     nb = TILE_BATCHES if (overlap and int(obs_cam.shape[0]) >= OVERLAP_MIN_OBS and S >= OVERLAP_MIN_FRAMES) else 1
-    chunk_desc, entries, tile_desc, obs_slot, nseg, batch_desc = build_schur_tiles(
+    chunk_desc, entries, tile_desc, obs_slot, nseg, batch_desc, block_chunk = build_schur_tiles(
         row_ptr, obs_cam, max_chunks=slots, num_batches=nb, later_scale=(cus - CHOL_CUS) / cus)
     prob = DeviceProblem(cam_q, cam_t, intr, pts, row_ptr, obs_cam, obs_uv, col_ptr, cobs_pt, cobs_uv, chunk_desc,
                          entries, tile_desc, obs_slot, nseg, MODEL_ID[camera_type], cam_const=cam_const,
-                         batch_desc=batch_desc, chol_split=chol_split, cam_perm=cam_perm)
+                         batch_desc=batch_desc, chol_split=chol_split, cam_perm=cam_perm, block_chunk=block_chunk)
     if first_group is not None:
         kd = 2 if camera_type == "SIMPLE_RADIAL" else 1              # upper bound of the intrinsics unknowns per block
         prob.chol_first_blk = envelope_blocks(first_group, S, 6 * S + kd * n_intr).to(dev)

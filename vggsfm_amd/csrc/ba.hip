@@ -522,12 +522,14 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
       else
         eval_full<KD>(d, pb.cam_q + 4 * c, pb.cam_t + 3 * c, pb.intr + 4 * a, X, uv,
                       pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
+#ifndef VGG_PP_NO_CACHE
       if (head) {
 #pragma unroll
         for (int i = 0; i < 2 * BD; ++i) cF[i] = F[i];
 #pragma unroll
         for (int i = 0; i < 6; ++i) cE[i] = E[i];
       }
+#endif
       V[0] += E[0] * E[0] + E[3] * E[3]; V[1] += E[0] * E[1] + E[3] * E[4]; V[2] += E[0] * E[2] + E[3] * E[5];
       V[3] += E[1] * E[1] + E[4] * E[4]; V[4] += E[1] * E[2] + E[4] * E[5]; V[5] += E[2] * E[2] + E[5] * E[5];
       g[0] += E[0] * r[0] + E[3] * r[1]; g[1] += E[1] * r[0] + E[4] * r[1]; g[2] += E[2] * r[0] + E[5] * r[1];
@@ -602,22 +604,30 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
     }
     // per-observation Schur factors Y_i = s_c o ((F_i^T E_i) G) -> slot obs_slot[o] of the zero-padded
     // segment buffer consumed by schur_tile_kernel
+#ifndef VGG_PP_NO_Y            // (timing experiment: phase 1 alone)
     {
       const int bdt = d.shared ? 6 : BD;          // rows of the tile block (intrinsics only when per camera)
       for (int o = o0 + lane; o < o1; o += 64) {
         const bool head = (o - o0 < 64);
         const int c = head ? f_c : pb.obs_cam[o];
         double F[2 * BD], E[6];
+#ifndef VGG_PP_NO_CACHE
         if (head) {                               // cached Jacobians of the first slice
 #pragma unroll
           for (int i = 0; i < 2 * BD; ++i) F[i] = cF[i];
 #pragma unroll
           for (int i = 0; i < 6; ++i) E[i] = cE[i];
-        } else {
+        } else
+#endif
+        {
           const int a = d.shared ? 0 : c;
           double r[2];
-          eval_full<KD>(d, pb.cam_q + 4 * c, pb.cam_t + 3 * c, pb.intr + 4 * a, X, pb.obs_uv[o],
-                        pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
+          if (LDSCAM)
+            eval_full<KD>(d, lq + 4 * c, lt + 3 * c, pb.intr + 4 * a, X, head ? f_uv : pb.obs_uv[o], (unsigned)lfl[c],
+                          pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
+          else
+            eval_full<KD>(d, pb.cam_q + 4 * c, pb.cam_t + 3 * c, pb.intr + 4 * a, X, pb.obs_uv[o],
+                          pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
         }
         // segment layout: [component 0..2][slot 0..15][row 0..bdt-1]  (three rows of the K dimension)
         const int slot = head ? f_slot : pb.obs_slot[o], rt = kGroup * bdt;
@@ -636,6 +646,7 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
         }
       }
     }
+#endif
     if (lane == 0) {
       if (first) { w.scale_p[3 * p] = s[0]; w.scale_p[3 * p + 1] = s[1]; w.scale_p[3 * p + 2] = s[2]; }
 #pragma unroll
@@ -701,7 +712,8 @@ typedef double f64x4_t __attribute__((ext_vector_type(4)));
 
 template <int BD, bool DIAG>
 __global__ __launch_bounds__(256, (BD == 6 ? (DIAG ? 4 : VGG_OFFDIAG_OCC) : 2)) void schur_tile_kernel(Ws w, const int32_t* __restrict__ chunk_desc,
-                                                         const int32_t* __restrict__ entries, int chunk0, int zero_seg) {
+                                                         const int32_t* __restrict__ entries, int chunk0, int zero_seg,
+                                                         const int32_t* __restrict__ block_chunk) {
   constexpr int YS = BD * 3;                      // doubles per Y block
   constexpr int SEG = kGroup * YS;                // doubles per segment (16 slots)
   constexpr int R = kGroup * BD;                  // rows / cols of the tile
@@ -721,7 +733,8 @@ __global__ __launch_bounds__(256, (BD == 6 ? (DIAG ? 4 : VGG_OFFDIAG_OCC) : 2)) 
   // workgroup j takes the sub-chunks j, j+J, j+2J, ... of kSub entries, so all workgroups of all tiles sweep
   // the point range at the same relative rate and the (up to ~G) re-reads of one point's segments by
   // different tiles fall close together in time (they hit the L2 / Infinity Cache instead of HBM).
-  const int chunk = chunk0 + blockIdx.x;
+  // launch position -> chunk (XCD placement: the chunks of one point range share an XCD and its L2; vggsfm_amd.h)
+  const int chunk = block_chunk ? block_chunk[chunk0 + blockIdx.x] : chunk0 + blockIdx.x;
   const int e0 = chunk_desc[6 * chunk + 2], e1 = chunk_desc[6 * chunk + 3];
   const int cj = chunk_desc[6 * chunk + 4], cJ = chunk_desc[6 * chunk + 5];
   constexpr int BPS = kSub / 4;                   // batches of 4 entries per sub-chunk
@@ -1273,6 +1286,7 @@ struct ProfScope {
 struct Launch {
   Dims d; DevProblem dp; Ws w; vgg_ba_options opt; hipStream_t st; int wgB;
   const int32_t* chunk_desc; const int32_t* entries; int num_chunks, num_segments;
+  const int32_t* block_chunk;                   // launch position -> chunk (XCD placement) or NULL
   const int32_t* tile_desc; int num_tiles;
   const int32_t* batches; int num_batches;      // HOST table [num_batches][6], see vgg_ba_problem.tile_batches
   int chol_split_a, chol_split_b;               // block-diagonal leading part of the reduced system (0 = none)
@@ -1316,11 +1330,11 @@ static void launch_schur_batch(const Launch& L, int batch, hipStream_t st, doubl
   const int c0 = B[0], cm = B[1], c1 = B[2], t0 = B[3], t1 = B[4];
   if (cm > c0) {
     ProfScope ps(kProfSchurTile, st);
-    schur_tile_kernel<BD, false><<<cm - c0, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, c0, L.num_segments);
+    schur_tile_kernel<BD, false><<<cm - c0, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, c0, L.num_segments, L.block_chunk);
   }
   if (c1 > cm) {
     ProfScope ps(kProfSchurTileDiag, st);
-    schur_tile_kernel<BD, true><<<c1 - cm, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, cm, L.num_segments);
+    schur_tile_kernel<BD, true><<<c1 - cm, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, cm, L.num_segments, L.block_chunk);
   }
   if (t1 > t0)
     tile_reduce_kernel<BD><<<dim3(div_up(kGroup * BD * kGroup * BD, 256), t1 - t0), 256, 0, st>>>(L.w, L.d.n_red, L.d.C, L.d.kd,
@@ -1468,6 +1482,7 @@ static int make_launch(const vgg_ba_problem* pb, const vgg_ba_options* opt, void
   L->st = st;
   L->wgB = min(max(div_up(L->d.P, 4), 1), kMaxWG);
   L->chunk_desc = pb->chunk_desc; L->entries = pb->entries; L->num_chunks = pb->num_chunks;
+  L->block_chunk = pb->block_chunk;
   L->num_segments = pb->num_segments;
   L->batches = pb->tile_batches; L->num_batches = pb->num_tile_batches;
   L->chol_split_a = pb->chol_split_a; L->chol_split_b = pb->chol_split_b;

@@ -139,6 +139,10 @@ typedef struct {
   int32_t num_segments;       /* segments: runs of one point's observations inside one camera group */
   const int32_t* obs_slot;    /* [num_obs] = segment*16 + (camera % 16): where the point-major observation's
                                  Schur factor lives in the zero-padded segment buffer */
+  const int32_t* obs_pt;      /* [num_obs] optional: the point of every point-major observation (the inverse of row_ptr).  With it
+                                 the per-observation Schur factors Y are written by a thread-per-observation kernel after the
+                                 wave-per-point reductions (fewer registers, full lanes for short tracks); NULL = the fused
+                                 wave-per-point pass of round 1. */
   int32_t num_tiles;
   const int32_t* tile_desc;   /* [num_tiles,4] = groupI, groupJ, chunk_begin, chunk_end (chunks of one tile
                                  are consecutive; their partial sums are reduced in this order) */

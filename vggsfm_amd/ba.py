@@ -114,6 +114,7 @@ class DeviceProblem:
     cam_perm: Optional[torch.Tensor] = None     # (S,) long: camera s of this problem is input frame cam_perm[s] (None = identity)
     chol_first_blk: Optional[torch.Tensor] = None   # (ceil(n / 64),) int32 device: row envelope of the reduced system (None = dense)
     block_chunk: Optional[torch.Tensor] = None      # (num_chunks,) int32 device: launch position -> chunk (XCD placement; None = identity)
+    obs_pt: Optional[torch.Tensor] = None           # (O,) int32 device: point of every point-major observation (None = fused Y pass)
 
     @property
     def num_obs(self):
@@ -126,7 +127,7 @@ class DeviceProblem:
         P.camera_model, P.refine_focal, P.refine_extra = self.camera_model, int(self.refine_focal), int(self.refine_extra)
         P.loss, P.loss_scale = self.loss, self.loss_scale
         for name in ("cam_q", "cam_t", "intr", "pts", "row_ptr", "obs_cam", "obs_uv", "col_ptr", "cobs_pt", "cobs_uv",
-                     "cam_const", "intr_const", "pt_const", "chunk_desc", "entries", "tile_desc", "obs_slot"):
+                     "cam_const", "intr_const", "pt_const", "chunk_desc", "entries", "tile_desc", "obs_slot", "obs_pt"):
             t = getattr(self, name)
             setattr(P, name, None if t is None else t.data_ptr())
         P.num_chunks = self.chunk_desc.shape[0]
@@ -501,7 +502,8 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
         row_ptr, obs_cam, max_chunks=slots, num_batches=nb, later_scale=(cus - CHOL_CUS) / cus)
     prob = DeviceProblem(cam_q, cam_t, intr, pts, row_ptr, obs_cam, obs_uv, col_ptr, cobs_pt, cobs_uv, chunk_desc,
                          entries, tile_desc, obs_slot, nseg, MODEL_ID[camera_type], cam_const=cam_const,
-                         batch_desc=batch_desc, chol_split=chol_split, cam_perm=cam_perm, block_chunk=block_chunk)
+                         batch_desc=batch_desc, chol_split=chol_split, cam_perm=cam_perm, block_chunk=block_chunk,
+                         obs_pt=pm[:, 0].to(torch.int32).contiguous())
     if first_group is not None:
         kd = 2 if camera_type == "SIMPLE_RADIAL" else 1              # upper bound of the intrinsics unknowns per block
         prob.chol_first_blk = envelope_blocks(first_group, S, 6 * S + kd * n_intr).to(dev)

@@ -37,6 +37,9 @@ constexpr int kGroup = 16;       // cameras per Schur tile side
 #ifndef VGG_OFFDIAG_OCC
 #define VGG_OFFDIAG_OCC 3   // wavefronts per SIMD of the off-diagonal Schur kernel (BD = 6): see DESIGN.md section 6
 #endif
+#ifndef VGG_PP_OCC_SPLIT
+#define VGG_PP_OCC_SPLIT 3   // point_pass without the Y sweep: 158 VGPRs
+#endif
 #ifndef VGG_PP_OCC
 #define VGG_PP_OCC 2
 #endif
@@ -154,7 +157,7 @@ static Ws carve(const Dims& d, int max_iters, int num_chunks, int num_segments, 
 struct DevProblem {  // by-value kernel argument
   Dims d;
   const double *cam_q, *cam_t, *intr, *pts;
-  const int32_t *row_ptr, *obs_cam, *col_ptr, *cobs_pt, *obs_slot;
+  const int32_t *row_ptr, *obs_cam, *col_ptr, *cobs_pt, *obs_slot, *obs_pt;
   const float2 *obs_uv, *cobs_uv;
   const uint8_t *cam_const, *intr_const, *pt_const;
 };
@@ -163,7 +166,7 @@ static DevProblem dev_problem(const vgg_ba_problem* pb, const Dims& d) {
   DevProblem p;
   p.d = d; p.cam_q = pb->cam_q; p.cam_t = pb->cam_t; p.intr = pb->intr; p.pts = pb->pts;
   p.row_ptr = pb->row_ptr; p.obs_cam = pb->obs_cam; p.col_ptr = pb->col_ptr; p.cobs_pt = pb->cobs_pt;
-  p.obs_slot = pb->obs_slot;
+  p.obs_slot = pb->obs_slot; p.obs_pt = pb->obs_pt;
   p.obs_uv = (const float2*)pb->obs_uv; p.cobs_uv = (const float2*)pb->cobs_uv;
   p.cam_const = pb->cam_const; p.intr_const = pb->intr_const; p.pt_const = pb->pt_const;
   return p;
@@ -435,10 +438,19 @@ __global__ void damping_kernel(Ws w, vgg_ba_options opt, int n_red) {
   w.dsq_c[j] = dd / w.ctl->radius;
 }
 
+// VGG_SPLIT_POINT_PASS=1 in the environment selects the split form of the point pass -- wave-per-point reductions without
+// the Y sweep (158 VGPRs, 3 wavefronts per SIMD) + y_write_kernel (thread per observation, 127 VGPRs).  Built and measured
+// in round 2 (c3): 0.25 + 0.47 ms against 0.43 ms for the fused pass -- the reductions did not speed up with the third
+// wavefront and a thread-per-observation writer without the LDS camera table is slower than the in-wave sweep -- so
+// the fused pass stays the default.
+static const bool g_fused_point_pass = [] { const char* e = getenv("VGG_SPLIT_POINT_PASS"); return !(e && e[0] == '1'); }();
+
 // ---------------------------------------------------------------------------------------------
 // point-major pass: one wavefront per point
-template <int KD, bool LDSCAM>
-__global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem pb, Ws w, vgg_ba_options opt) {
+// WRITE_Y = false: the per-observation Schur factors are left to y_write_kernel (thread per observation); this kernel
+// then needs neither the cached Jacobians nor the slot prefetch and fits three wavefronts per SIMD.
+template <int KD, bool LDSCAM, bool WRITE_Y>
+__global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void point_pass_kernel(DevProblem pb, Ws w, vgg_ba_options opt) {
   constexpr int BD = 6 + KD;
   __shared__ double wmax[4];
   extern __shared__ double cam_cache[];          // LDSCAM: q[4C] t[3C] pose scales[6C] flags[C] (as doubles)
@@ -480,7 +492,7 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
     n_o0 = pb.row_ptr[p]; n_o1 = pb.row_ptr[p + 1];
     n_X0 = pb.pts[3 * p]; n_X1 = pb.pts[3 * p + 1]; n_X2 = pb.pts[3 * p + 2];
     n_ptc = pb.pt_const ? pb.pt_const[p] != 0 : false;
-    if (n_o0 + lane < n_o1) { n_c = pb.obs_cam[n_o0 + lane]; n_uv = pb.obs_uv[n_o0 + lane]; n_slot = pb.obs_slot[n_o0 + lane]; }
+    if (n_o0 + lane < n_o1) { n_c = pb.obs_cam[n_o0 + lane]; n_uv = pb.obs_uv[n_o0 + lane]; if (WRITE_Y) n_slot = pb.obs_slot[n_o0 + lane]; }
     if (p + nw < d.P) {
       const int pm = p + nw;
       m_o0 = pb.row_ptr[pm]; m_o1 = pb.row_ptr[pm + 1];
@@ -497,7 +509,7 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
     {
       // stage 1 -> current of the next iteration: observations of point p + nw (its bounds arrived an iteration ago)
       n_o0 = m_o0; n_o1 = m_o1; n_X0 = m_X0; n_X1 = m_X1; n_X2 = m_X2; n_ptc = m_ptc;
-      if (p + nw < d.P && n_o0 + lane < n_o1) { n_c = pb.obs_cam[n_o0 + lane]; n_uv = pb.obs_uv[n_o0 + lane]; n_slot = pb.obs_slot[n_o0 + lane]; }
+      if (p + nw < d.P && n_o0 + lane < n_o1) { n_c = pb.obs_cam[n_o0 + lane]; n_uv = pb.obs_uv[n_o0 + lane]; if (WRITE_Y) n_slot = pb.obs_slot[n_o0 + lane]; }
       // stage 2: bounds / coordinates of point p + 2 nw
       const int pm = p + 2 * nw;
       if (pm < d.P) {
@@ -522,14 +534,12 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
       else
         eval_full<KD>(d, pb.cam_q + 4 * c, pb.cam_t + 3 * c, pb.intr + 4 * a, X, uv,
                       pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
-#ifndef VGG_PP_NO_CACHE
-      if (head) {
+      if (WRITE_Y && head) {
 #pragma unroll
         for (int i = 0; i < 2 * BD; ++i) cF[i] = F[i];
 #pragma unroll
         for (int i = 0; i < 6; ++i) cE[i] = E[i];
       }
-#endif
       V[0] += E[0] * E[0] + E[3] * E[3]; V[1] += E[0] * E[1] + E[3] * E[4]; V[2] += E[0] * E[2] + E[3] * E[5];
       V[3] += E[1] * E[1] + E[4] * E[4]; V[4] += E[1] * E[2] + E[4] * E[5]; V[5] += E[2] * E[2] + E[5] * E[5];
       g[0] += E[0] * r[0] + E[3] * r[1]; g[1] += E[1] * r[0] + E[4] * r[1]; g[2] += E[2] * r[0] + E[5] * r[1];
@@ -604,30 +614,22 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
     }
     // per-observation Schur factors Y_i = s_c o ((F_i^T E_i) G) -> slot obs_slot[o] of the zero-padded
     // segment buffer consumed by schur_tile_kernel
-#ifndef VGG_PP_NO_Y            // (timing experiment: phase 1 alone)
-    {
+    if (WRITE_Y) {
       const int bdt = d.shared ? 6 : BD;          // rows of the tile block (intrinsics only when per camera)
       for (int o = o0 + lane; o < o1; o += 64) {
         const bool head = (o - o0 < 64);
         const int c = head ? f_c : pb.obs_cam[o];
         double F[2 * BD], E[6];
-#ifndef VGG_PP_NO_CACHE
         if (head) {                               // cached Jacobians of the first slice
 #pragma unroll
           for (int i = 0; i < 2 * BD; ++i) F[i] = cF[i];
 #pragma unroll
           for (int i = 0; i < 6; ++i) E[i] = cE[i];
-        } else
-#endif
-        {
+        } else {
           const int a = d.shared ? 0 : c;
           double r[2];
-          if (LDSCAM)
-            eval_full<KD>(d, lq + 4 * c, lt + 3 * c, pb.intr + 4 * a, X, head ? f_uv : pb.obs_uv[o], (unsigned)lfl[c],
-                          pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
-          else
-            eval_full<KD>(d, pb.cam_q + 4 * c, pb.cam_t + 3 * c, pb.intr + 4 * a, X, pb.obs_uv[o],
-                          pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
+          eval_full<KD>(d, pb.cam_q + 4 * c, pb.cam_t + 3 * c, pb.intr + 4 * a, X, pb.obs_uv[o],
+                        pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
         }
         // segment layout: [component 0..2][slot 0..15][row 0..bdt-1]  (three rows of the K dimension)
         const int slot = head ? f_slot : pb.obs_slot[o], rt = kGroup * bdt;
@@ -646,7 +648,6 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
         }
       }
     }
-#endif
     if (lane == 0) {
       if (first) { w.scale_p[3 * p] = s[0]; w.scale_p[3 * p + 1] = s[1]; w.scale_p[3 * p + 2] = s[2]; }
 #pragma unroll
@@ -662,6 +663,44 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
   if (lane == 0) wmax[wave] = gmax;
   __syncthreads();
   if (threadIdx.x == 0) w.part_B[blockIdx.x] = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
+}
+
+// Per-observation Schur factors Y_i = s_c o ((F_i^T E_i) G_p), one THREAD per observation (point-major order, so the
+// lanes of a wavefront read consecutive observations, mostly of the same point and of consecutive cameras: the gathers of
+// the point's X / G and of the cameras coalesce or hit L1).  No reductions and no per-point serial work in here: ~100
+// registers, and every lane is busy whatever the track length.  Same arithmetic as the Y sweep of point_pass_kernel
+// (G is read back from w.G instead of being held in registers): bit-identical Y.
+template <int KD>
+__global__ __launch_bounds__(256, 4) void y_write_kernel(DevProblem pb, Ws w) {
+  constexpr int BD = 6 + KD;
+  if (w.ctl->done) return;
+  const Dims& d = pb.d;
+  const int bdt = d.shared ? 6 : BD, rt = kGroup * bdt;
+  const int O = d.O;
+  for (int o = blockIdx.x * 256 + threadIdx.x; o < O; o += gridDim.x * 256) {
+    const int p = pb.obs_pt[o], c = pb.obs_cam[o], slot = pb.obs_slot[o];
+    const float2 uv = pb.obs_uv[o];
+    const int a = d.shared ? 0 : c;
+    const double X[3] = {pb.pts[3 * p], pb.pts[3 * p + 1], pb.pts[3 * p + 2]};
+    const bool pt_c = pb.pt_const ? pb.pt_const[p] != 0 : false;
+    const double* Gp = w.G + 6 * (size_t)p;
+    const double G0 = Gp[0], G1 = Gp[1], G2 = Gp[2], G3 = Gp[3], G4 = Gp[4], G5 = Gp[5];
+    double r[2], F[2 * BD], E[6];
+    eval_full<KD>(d, pb.cam_q + 4 * c, pb.cam_t + 3 * c, pb.intr + 4 * a, X, uv, pb.cam_const ? pb.cam_const[c] : 0u,
+                  pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
+    double* y = w.Y + (size_t)(slot >> 4) * (3 * rt) + (slot & 15) * bdt;
+#pragma unroll
+    for (int i = 0; i < BD; ++i) {
+      if (i < bdt) {
+        const double sc = (i < 6) ? w.scale_c[6 * c + i] : w.scale_c[6 * d.C + KD * c + (i - 6)];
+        const double w0 = F[i] * E[0] + F[BD + i] * E[3], w1 = F[i] * E[1] + F[BD + i] * E[4],
+                     w2 = F[i] * E[2] + F[BD + i] * E[5];
+        y[i] = sc * (w0 * G0);
+        y[rt + i] = sc * (w0 * G1 + w1 * G3);
+        y[2 * rt + i] = sc * (w0 * G2 + w1 * G4 + w2 * G5);
+      }
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void reduce_gmax_kernel(Ws w, int nparts) {
@@ -1395,8 +1434,12 @@ static void phase_schur(const Launch& L) {
     ProfScope ps(kProfPointPass, L.st);
     // cameras (q, t, pose scales, constant flags: 14 doubles each) cached in LDS when they fit beside 2 workgroups/CU
     const size_t cam_lds = sizeof(double) * 14 * (size_t)d.C;
-    if (cam_lds <= 48 * 1024) point_pass_kernel<KD, true><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w, L.opt);
-    else point_pass_kernel<KD, false><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w, L.opt);
+    if (L.dp.obs_pt && !g_fused_point_pass) {
+      if (cam_lds <= 48 * 1024) point_pass_kernel<KD, true, false><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w, L.opt);
+      else point_pass_kernel<KD, false, false><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w, L.opt);
+      y_write_kernel<KD><<<min(div_up(L.d.O, 256), 256 * 16), 256, 0, L.st>>>(L.dp, L.w);
+    } else if (cam_lds <= 48 * 1024) point_pass_kernel<KD, true, true><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w, L.opt);
+    else point_pass_kernel<KD, false, true><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w, L.opt);
   }
   reduce_gmax_kernel<<<1, 256, 0, L.st>>>(L.w, L.wgB);
   {

@@ -230,3 +230,34 @@ def test_find_camera_split_on_sliding_window_visibility():
     assert BA.find_camera_split(m, adjacency_reduce=couple)[0] is None
     full = torch.ones(200, 50, dtype=torch.bool)
     assert BA.find_camera_split(full)[0] is None and BA.find_camera_split(m[:40])[0] is None
+
+
+def test_find_camera_order_kway_and_envelope():
+    """Video-like visibility (1000 frames, tracks of at most 40 frames): ``find_camera_order`` returns a nested-dissection
+    order -- k > 2 interior runs, then their separators -- in which the interiors do not couple, frames 0 / 1 (the gauge)
+    stay in front, and ``envelope_blocks`` is a valid ROW ENVELOPE of the permuted reduced system: no co-visible camera
+    pair lies left of it.  Short sequences / wide bands: no k-way order (the two-way split handles those)."""
+    rng = np.random.default_rng(0)
+    S, P = 1000, 20000
+    start, ln = rng.integers(0, S - 40, P), rng.integers(5, 40, P)
+    fr = np.arange(S)[:, None]
+    m = torch.from_numpy((fr >= start[None]) & (fr < (start + ln)[None]))
+    perm, fg = BA.find_camera_order(m)
+    assert perm is not None and sorted(perm.tolist()) == list(range(S)) and perm[:2].tolist() == [0, 1]
+    G = len(fg)
+    roots = [p for p in range(G) if int(fg[p]) == p]                       # groups that start an independent block
+    assert len(roots) >= 3
+    fb = BA.envelope_blocks(fg, S, 6 * S + 2)
+    assert fb.dtype == torch.int32 and len(fb) == (6 * S + 2 + 63) // 64 and int(fb[-1]) == 0      # intrinsics rows are dense
+    mp = m[perm].float()
+    covis = (mp @ mp.t()) > 0                                             # camera x camera in the new order
+    first_cam = torch.tensor([int(torch.nonzero(covis[c])[0]) if bool(covis[c].any()) else c for c in range(S)])
+    rows = torch.arange(6 * S)
+    first_col = 6 * first_cam[rows // 6]
+    for r in range(0, 6 * S, 64):
+        assert int(fb[r // 64]) * 64 <= int(first_col[r:r + 64].min())
+    # the envelope is far from dense: most block rows start well to the right
+    assert float((fb[:-1] > 0).float().mean()) > 0.8
+    sc = make_scene(200, 4000, "SIMPLE_RADIAL", shared_camera=True, seed=0)
+    assert BA.find_camera_order(T(sc.mask))[0] is None                     # band of 40 % of the frames: two-way split instead
+    assert BA.find_camera_order(m[:60])[0] is None

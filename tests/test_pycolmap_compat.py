@@ -396,3 +396,73 @@ def test_reference_runner_end_to_end_on_compat(monkeypatch, tmp_path):
     runner.save_sparse_reconstruction(pred, output_dir=str(tmp_path))
     back = pc.Reconstruction(str(tmp_path / "sparse"))
     assert back.num_points3D() == rec.num_points3D() and back.images[0].name == os.path.basename(paths[0])
+
+
+@needs_reference
+def test_reference_video_runner_joint_ba_and_alignment_on_compat(monkeypatch):
+    """Cut line B2 for the video path: the reference's unmodified ``VideoRunner.{convert_pred_to_point_frame_dict,
+    dicts_to_reconstruction, joint_BA, reconstruction_to_dicts, build_camera_for_video, align_next_window}`` and the
+    module-level ``solve_bundle_adjustment`` (video_runner.py:354-473, 494-638, 940-1060, 1321-1331) bound to a bare
+    instance, with ``pycolmap`` / ``pyceres`` = the compat modules.  The joint BA must agree with the drop-in's tensor
+    path (``vggsfm_amd.video.joint_bundle_adjustment``) on the same state -- two routes, one answer."""
+    from collections import defaultdict
+    from tests import cpu_backend
+    from vggsfm_amd import pyceres_compat
+    from vggsfm_amd import video as V
+    cpu_backend.patch(monkeypatch)
+    VR = _reference_module("vggsfm.runners.video_runner", monkeypatch)
+    sc = make_scene(12, 500, "SIMPLE_RADIAL", shared_camera=True, seed=41, outlier_frac=0.0)
+    from vggsfm_amd.scene import perturb_for_ba
+    ext0, K0, xp0, pts0 = perturb_for_ba(sc, seed=41)
+    valid = sc.mask.sum(0) >= 3
+    T_ = torch.from_numpy
+    runner = object.__new__(VR.VideoRunner)
+    runner.cfg = types.SimpleNamespace(camera_type="SIMPLE_RADIAL", shared_camera=True)
+    runner.device = "cpu"
+    runner.point_dict, runner.frame_dict = {}, defaultdict(dict)
+    runner.intrinsics = T_(K0[0:1]).float()
+    runner.extra_params = T_(xp0[0:1]).float()
+    runner.image_size = torch.tensor([1024, 1024])
+    pred = {"pred_track": T_(sc.tracks), "pred_vis": T_(sc.vis), "valid_2D_mask": T_(sc.mask[:, valid]),
+            "valid_tracks": T_(valid), "points3D": T_(pts0[valid]).float(), "points3D_rgb": None,
+            "extrinsics_opencv": T_(ext0)}
+    runner.convert_pred_to_point_frame_dict(pred, 0, 12)
+    rec = runner.dicts_to_reconstruction(0, 12)
+    assert isinstance(rec, pc.Reconstruction) and rec.num_points3D() == int(valid.sum()) and len(rec.cameras) == 1
+    # the drop-in's tensor path on the same state (float32 points, as the dicts hold them)
+    p_opt, e_opt, K_opt, x_opt, inl, keep, _ = V.joint_bundle_adjustment(
+        T_(pts0[valid]).float().double(), T_(ext0), runner.intrinsics.double(), T_(sc.tracks[:, valid]), T_(sc.mask[:, valid]),
+        runner.extra_params.double(), "SIMPLE_RADIAL", reproj_error=2.0, tri_angle=1.5, normalize=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        runner.joint_BA(0, 12, reproj_error=2.0, tri_angle=1.5, normalize=True)
+    got_ext = torch.stack([runner.frame_dict[i]["extri"] for i in range(12)]).numpy()
+    np.testing.assert_allclose(got_ext, e_opt.numpy(), atol=1e-6)
+    np.testing.assert_allclose(runner.intrinsics[0].double().numpy(), K_opt[0].numpy(), rtol=1e-6)
+    np.testing.assert_allclose(float(runner.extra_params[0, 0]), float(x_opt[0, 0]), atol=1e-6)
+    assert len(runner.point_dict) == int(keep.sum())
+    kept = p_opt[keep].numpy()
+    got_pts = np.stack([runner.point_dict[i]["xyz"].numpy() for i in sorted(runner.point_dict)])
+    np.testing.assert_allclose(got_pts, kept, atol=1e-5)
+    n_obs = sum(len(runner.point_dict[i]["track"]) for i in runner.point_dict)
+    assert n_obs == int(inl[:, keep].sum())
+    # pose alignment of a window through pycolmap.pose_refinement (video_runner.py:940-1017)
+    ext_gt = np.stack([runner.frame_dict[i]["extri"].numpy() for i in range(12)])
+    pert = ext_gt.copy()
+    pert[1:, :, 3] += 0.02
+    refined = runner.align_next_window(T_(pert), T_(sc.tracks[:, valid][:, keep.numpy()]), T_(sc.mask[:, valid][:, keep.numpy()]),
+                                       T_(got_pts).double())
+    assert np.abs(refined.numpy()[1:] - ext_gt[1:]).max() < 0.3 * 0.02 and np.array_equal(refined.numpy()[0], pert[0])
+    # window BA through BundleAdjustmentConfig / BundleAdjuster / pyceres.solve (video_runner.py:813-836, 1321-1331)
+    rec2 = runner.dicts_to_reconstruction(0, 12)
+    opts = pc.BundleAdjustmentOptions()
+    opts.refine_focal_length = opts.refine_extra_params = False
+    cfg = pc.BundleAdjustmentConfig()
+    for i in rec2.reg_image_ids():
+        cfg.add_image(i)
+    cfg.set_constant_cam_pose(rec2.reg_image_ids()[0])
+    for pid in rec2.point3D_ids():
+        (cfg.add_constant_point if pid <= 50 else cfg.add_variable_point)(pid)
+    summary = VR.solve_bundle_adjustment(rec2, opts, cfg)
+    assert isinstance(summary, pyceres_compat.SolverSummary) and VR.log_ba_summary(summary)
+    assert summary.final_cost <= summary.initial_cost and summary.num_residuals_reduced > 0

@@ -77,9 +77,26 @@ def test_estimate_preliminary_cameras_on_a_scene():
     vis = sc.vis.copy()
     vis[:, ::17] = 0.0
     np.random.seed(0)
-    _, pre = estimate_preliminary_cameras(D(sc.tracks)[None], D(vis)[None], 1024, 1024, tracks_score=D(sc.score)[None],
-                                          max_error=2.0, max_ransac_iters=512, lo_num=60)
+    cams, pre = estimate_preliminary_cameras(D(sc.tracks)[None], D(vis)[None], 1024, 1024, tracks_score=D(sc.score)[None],
+                                             max_error=2.0, max_ransac_iters=512, lo_num=60)
     m = pre["fmat_inlier_mask"][0].cpu().numpy()
+    # preliminary cameras (estimate_preliminary.py:153-241): E = K^T F K with the DEFAULT intrinsics (focal = 1024 where the
+    # scene has ~1000), decomposed, cheirality resolved: rotation close to the true relative rotation, translation
+    # direction within a few degrees, camera 0 the identity; pred_cameras = the same in the PyTorch3D convention
+    Ro, to = pre["R_opencv"][0].cpu().numpy(), pre["t_opencv"][0].cpu().numpy()
+    assert Ro.shape == (S, 3, 3) and np.array_equal(Ro[0], np.eye(3)) and not to[0].any()
+    E0 = sc.extrinsics
+    for s_ in range(1, S):
+        Rrel = E0[s_, :, :3] @ E0[0, :, :3].T
+        trel = E0[s_, :, 3] - Rrel @ E0[0, :, 3]
+        ang = np.degrees(np.arccos(np.clip((np.trace(Ro[s_] @ Rrel.T) - 1) / 2, -1, 1)))
+        cosd = float(to[s_] @ trel / (np.linalg.norm(to[s_]) * np.linalg.norm(trel)))
+        assert ang < 3.0 and cosd > 0.98, (s_, ang, cosd)
+    Rp, Tp = cams.R.cpu().numpy(), cams.T.cpu().numpy()
+    flipxy = np.array([-1.0, -1.0, 1.0])
+    assert np.allclose(Rp, np.transpose(Ro, (0, 2, 1)) * flipxy[None, None, :]) and np.allclose(Tp, to * flipxy[None])
+    assert pre["default_intri"].shape == (1, S - 1, 3, 3) and float(pre["default_intri"][0, 0, 0, 0]) == 1024.0
+    assert pre["emat_fromf"].shape == (S - 1, 3, 3)
     assert m.shape == (S - 1, N) and pre["fmat"].shape == (1, S - 1, 3, 3) and pre["fmat_residuals"].shape == (1, S - 1, N)
     assert not m[:, ::17].any()
     clean = ~(sc.outlier[1:] | sc.outlier[0:1]) & (vis[1:] > 0)

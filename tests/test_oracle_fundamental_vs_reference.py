@@ -138,3 +138,55 @@ def test_seven_point_pencil_matches_reference_modulo_the_cubic_solver():
                 dist.append(np.abs(ru_[h] - _unit(mine[h, s])[None]).max((-1, -2)).min())
     dist = np.array(dist)
     assert len(dist) >= 150 and np.median(dist) < 1e-4 and (dist < 5e-3).mean() > 0.97, (np.median(dist), np.sort(dist)[-8:])
+
+
+def test_preliminary_camera_helpers_match_reference():
+    """``essential_from_fundamental``, ``decompose_essential_matrix``, ``build_default_kmat`` of
+    vggsfm_amd/two_view_geo/estimate_preliminary.py (torch ops, device agnostic) against the reference's own functions
+    (vggsfm/two_view_geo/fundamental.py:186-212, essential.py:36-83 -- kornia's ``cross_product_matrix`` / ``eye_like``
+    style helpers restated by the harness -- and estimate_preliminary.py:244-272)."""
+    import torch
+    ref_harness.install()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        from vggsfm.two_view_geo import essential as RE
+        from vggsfm.two_view_geo import estimate_preliminary as RP
+        from vggsfm.two_view_geo import fundamental as RF
+    from vggsfm_amd.two_view_geo import estimate_preliminary as P
+    # kornia helpers the reference imports by name (stubbed by the harness): restated here
+    RE.ones_like, RE.where, RE.stack = torch.ones_like, torch.where, torch.stack
+    RE._torch_svd_cast = lambda m: torch.svd(m)
+
+    def cross_product_matrix(x):
+        x0, x1, x2 = x[..., 0], x[..., 1], x[..., 2]
+        z = torch.zeros_like(x0)
+        return torch.stack([z, -x2, x1, x2, z, -x0, -x1, x0, z], dim=-1).view(*x.shape[:-1], 3, 3)
+    RE.cross_product_matrix = cross_product_matrix
+    rng = np.random.default_rng(3)
+    from scipy.spatial.transform import Rotation
+    B = 7
+    Rt = Rotation.random(B, random_state=2).as_matrix()
+    tt = rng.normal(size=(B, 3))
+    tt /= np.linalg.norm(tt, axis=1, keepdims=True)
+    tx = np.zeros((B, 3, 3))
+    tx[:, 0, 1], tx[:, 0, 2], tx[:, 1, 0], tx[:, 1, 2], tx[:, 2, 0], tx[:, 2, 1] = -tt[:, 2], tt[:, 1], tt[:, 2], -tt[:, 0], -tt[:, 1], tt[:, 0]
+    E = torch.from_numpy(tx @ Rt)
+    k1r, k2r, flr, ppr = RP.build_default_kmat(1024, 768, 1, B + 1, 10, device="cpu", dtype=torch.float64)
+    k1, k2, fl, pp = P.build_default_kmat(1024, 768, 1, B + 1, 10, device="cpu", dtype=torch.float64)
+    for a, b in ((k1, k1r), (k2, k2r), (fl, flr), (pp, ppr)):
+        assert torch.equal(a, b)
+    F = torch.linalg.inv(k2).transpose(-2, -1) @ E @ torch.linalg.inv(k1)
+    Er, _, _ = RF.essential_from_fundamental(F, k1, k2)
+    Em = P.essential_from_fundamental(F, k1, k2)
+    assert torch.allclose(Em, Er, rtol=0, atol=1e-12) and torch.allclose(Em, E, atol=1e-9)
+    Rs_r, Ts_r = RE.decompose_essential_matrix(E)
+    Rs, Ts = P.decompose_essential_matrix(E)
+    # the candidate SET is what matters (an SVD is unique up to joint sign flips): every reference candidate is among ours
+    for b in range(B):
+        for c in range(4):
+            d = [(Rs[b, k] - Rs_r[b, c]).abs().max().item() + (Ts[b, k] - Ts_r[b, c]).abs().max().item() for k in range(4)]
+            assert min(d) < 1e-9
+        # and the true motion is one of them (t up to sign is handled by the +-t pair)
+        d = [np.abs(Rs[b, k].numpy() - Rt[b]).max() + np.abs(Ts[b, k].numpy() - tt[b]).max() for k in range(4)]
+        assert min(d) < 1e-8

@@ -232,16 +232,14 @@ def main():
         n_red = int(fin["n_reduced"])
         bd = 6 if shared else 6 + (2 if cam_type == "SIMPLE_RADIAL" else 1)     # Schur block width
         # camera-pair blocks (a <= b) of the Schur complement, split by the launch that computes them
-        emask = prob.entries[:, 3].long()
-        na = torch.zeros_like(emask)
-        nb_ = torch.zeros_like(emask)
-        for bit in range(16):
-            na += (emask >> bit) & 1
-            nb_ += (emask >> (16 + bit)) & 1
-        ediag = prob.entries[:, 1] == prob.entries[:, 2]
-        pairs_off = float((na * nb_)[~ediag].sum().item())
-        pairs_diag = float((na * (na + 1) // 2)[ediag].sum().item())
-        assert abs(pairs_off + pairs_diag - float((counts * (counts + 1) / 2).sum().item())) < 0.5
+        seg_count = torch.bincount(prob.obs_slot.long() // BA.GROUP, minlength=prob.num_segments).double()   # cameras per segment
+        pairs_all = float((counts * (counts + 1) / 2).sum().item())
+        pairs_diag = float((seg_count * (seg_count + 1) / 2).sum().item())       # both cameras in one 16-camera group
+        pairs_off = pairs_all - pairs_diag
+        super_tiles = prob.quad_mask is not None
+        if super_tiles:               # opt-in 2 x 2 super-tiles: ONE launch computes every pair (reported under schur_tile<offdiag>)
+            pairs_off, pairs_diag = pairs_all, 0.0
+            ROCPROF_NAME["schur_tile<offdiag>"] = "super_tile_kernel"
         # algorithmic work per launch (DESIGN.md "Kernels"): flops for the fp64-compute-bound kernels,
         # bytes for the streaming kernels
         work = {

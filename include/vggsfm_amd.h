@@ -134,8 +134,10 @@ typedef struct {
   int32_t num_tile_batches;   /* >= 1: the tiles are cut into batches of consecutive camera groups groupI (tile_batches) */
   const int32_t* chunk_desc;  /* [num_chunks,6] = groupI, groupJ, tile_entry_begin, tile_entry_end, j, J:
                                  workgroup j of the J of its tile takes the 32-entry sub-chunks j, j+J, ... */
-  const int32_t* entries;     /* [num_entries,4] = point, segment_A, segment_B, maskA | maskB<<16
-                                 (bit l of a mask: camera group*16+l observes the point) */
+  const int32_t* entries;     /* [num_entries,4] = sweep position of the point, segment_A, segment_B, maskA | maskB<<16 of the
+                                 QUAD: the four consecutive entries, aligned to tile_entry_begin, that the kernel packs
+                                 along K (bit l of a mask: camera group*16+l observes one of the four points; 16-row
+                                 blocks of the tile without any camera are skipped for the quad) */
   int32_t num_segments;       /* segments: runs of one point's observations inside one camera group */
   const int32_t* obs_slot;    /* [num_obs] = segment*16 + (camera % 16): where the point-major observation's
                                  Schur factor lives in the zero-padded segment buffer */
@@ -173,6 +175,17 @@ typedef struct {
                                  range, so that all tiles stage a given point's segments on ONE XCD (ba.py:
                                  build_schur_tiles).  A permutation inside every [chunk_begin, first_diagonal_chunk) and
                                  [first_diagonal_chunk, chunk_end) range of tile_batches.  NULL = identity. */
+  int32_t super_tiles;           /* 0: 16-camera tiles as described above.  1 (only for 6 x 6 camera blocks: num_intr == 1, or
+                                 refine_focal == refine_extra == 0): 2 x 2 SUPER-TILES of 32 x 32 cameras, one launch
+                                 (ba.py: build_schur_supertiles) -- then
+                                   chunk_desc  [num_chunks,8] = superI, superJ, entry_begin, entry_end, j, J, quad_begin, 0
+                                   entries     [num_entries,4] = segment_A0, segment_A1, segment_B0, segment_B1 (the two camera
+                                               groups of either side; num_segments = absent; a diagonal super-tile has B = A)
+                                   quad_mask   [num_quads,2] = presence of the 32 cameras of superI / superJ in the quad
+                                               (entries and quad_mask: padded by 32 entries / 8 quads behind the last tile)
+                                   tile_desc   [num_tiles,4] = superI, superJ, chunk_begin, chunk_end
+                                   tile_batches one row (0, 0, num_chunks, 0, num_tiles, 0); block_chunk unused */
+  const int32_t* quad_mask;
 } vgg_ba_problem;
 
 typedef struct {

@@ -197,6 +197,28 @@ def test_ba_camera_split_matches_unsplit(monkeypatch, shared, N):
     np.testing.assert_array_equal(a[1][0].cpu().numpy(), ext0[0])             # the gauge frame is still frame 0
 
 
+@pytest.mark.parametrize("S,N,cam", [(160, 8000, "SIMPLE_RADIAL"), (40, 1500, "SIMPLE_PINHOLE"), (9, 300, "SIMPLE_RADIAL")])
+def test_ba_super_tiles_match_tiles(monkeypatch, S, N, cam):
+    """The opt-in 2 x 2 super-tile Schur path (ba.SUPER_TILES: 32 x 32 cameras per workgroup, LDS-DMA ring, presence
+    skipping) against the default 16-camera tiles on shared-intrinsics problems: same trajectory to rounding."""
+    sc = make_scene(S, N, cam, shared_camera=True, seed=17)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=17)
+    opt = BundleAdjustmentOptions()
+    opt.solver_options.max_num_iterations = 10
+
+    def solve():
+        return BA.bundle_adjustment(D(pts0), D(ext0), D(K0), D(sc.tracks), D(sc.mask), None, D(extra0), True, cam, opt)
+    monkeypatch.setattr(BA, "SUPER_TILES", False)
+    ref = solve()
+    monkeypatch.setattr(BA, "SUPER_TILES", True)
+    a = solve()
+    assert a[4]["num_iterations"] == ref[4]["num_iterations"]
+    assert abs(a[4]["final_cost"] - ref[4]["final_cost"]) <= 1e-9 * ref[4]["final_cost"]
+    for x, y in zip(a[:4], ref[:4]):
+        if x is not None:
+            np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-7, atol=1e-7)
+
+
 def test_cholesky_flags_indefinite():
     A = np.eye(40)
     A[17, 17] = -1.0

@@ -58,7 +58,8 @@ def test_quaternion_conversion_matches_oracle():
 
 
 @pytest.mark.parametrize("S,N", [(5, 40), (40, 300), (70, 150)])
-def test_compile_problem_matches_oracle_construction(S, N):
+def test_compile_problem_matches_oracle_construction(S, N, monkeypatch):
+    monkeypatch.setattr(BA, "SUPER_TILES", False)        # (the 2 x 2 super-tile list has its own test below)
     sc = make_scene(S, N, "SIMPLE_RADIAL", shared_camera=True, seed=S)
     ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=S)
     masks = sc.mask.copy()
@@ -94,29 +95,44 @@ def test_compile_problem_matches_oracle_construction(S, N):
     assert (slot % BA.GROUP == obs_cam % BA.GROUP).all()
     seg_of = slot // BA.GROUP
     seg_first = {int(sg): int(np.nonzero(seg_of == sg)[0][0]) for sg in np.unique(seg_of)}
+    seg_mask = {int(sg): sum(1 << (int(c) % BA.GROUP) for c in obs_cam[seg_of == sg]) for sg in np.unique(seg_of)}
+    pt_of_obs = np.repeat(np.arange(len(vi)), np.diff(row_ptr))
     covered = {}
     seen_entries = np.zeros(len(ent), bool)
+    pos_of_point = {}
     for gI, gJ, tb, te, j, J in desc:
         # workgroup j of J of the tile sweeps the strided sub-chunks j, j+J, ... of SUB entries
         assert gI <= gJ and 0 <= j < J and J <= max(1, -(-(te - tb) // BA.MIN_CHUNK))
+        assert (np.diff(ent[tb:te, 0]) > 0).all()                   # inside a tile: ascending sweep positions, one entry per point
         own = [k for s0 in range(tb + j * BA.SUB, te, J * BA.SUB) for k in range(s0, min(s0 + BA.SUB, te))]
         for k in own:
             assert not seen_entries[k]
             seen_entries[k] = True
-            p, sa, sb, msk = ent[k]
-            mA, mB = int(msk) & 0xffff, (int(msk) >> 16) & 0xffff
+            pos, sa, sb, msk = ent[k]
+            mA, mB = seg_mask[sa], seg_mask[sb]
+            # field 3 = the union of the own masks over the quad the entry belongs to (aligned to the tile's begin)
+            q0 = tb + (k - tb) // 4 * 4
+            quad = 0
+            for kk in range(q0, min(q0 + 4, te)):
+                quad |= seg_mask[ent[kk, 1]] | (seg_mask[ent[kk, 2]] << 16)
+            assert (int(msk) & 0xffffffff) == quad
             ca, cb = bin(mA).count("1"), bin(mB).count("1")
             oa, ob = seg_first[sa], seg_first[sb]
             A = obs_cam[oa:oa + ca]
             B = obs_cam[ob:ob + cb]
-            assert mA == sum(1 << (int(c) % BA.GROUP) for c in A) and mB == sum(1 << (int(c) % BA.GROUP) for c in B)
             assert (A // BA.GROUP == gI).all() and (B // BA.GROUP == gJ).all()
+            p = int(pt_of_obs[oa])
+            assert pos_of_point.setdefault(p, int(pos)) == int(pos)
             assert row_ptr[p] <= oa and oa + ca <= row_ptr[p + 1] and row_ptr[p] <= ob and ob + cb <= row_ptr[p + 1]
             for a in A:
                 for bb in B:
                     if gI == gJ and a > bb:
                         continue
                     covered[(p, int(a), int(bb))] = covered.get((p, int(a), int(bb)), 0) + 1
+    # the sweep order: points by (first camera, last camera)
+    by_pos = sorted(pos_of_point, key=pos_of_point.get)
+    keys = [(int(obs_cam[row_ptr[q]]), int(obs_cam[row_ptr[q + 1] - 1])) for q in by_pos]
+    assert keys == sorted(keys) and len(set(pos_of_point.values())) == len(pos_of_point)
     assert seen_entries.all()
     assert len(desc) <= max(2 * 256 * 4, len(prob.tile_desc))  # one resident round per launch (off-diag, diag)
     # tiles: consecutive chunk ranges that cover all chunks exactly once, one tile per (gI, gJ)
@@ -142,6 +158,81 @@ def test_normalize_matches_oracle():
     e2, p2 = OB.normalize_reconstruction(sc.extrinsics, sc.points3D, alive)
     np.testing.assert_allclose(e1.numpy(), e2, rtol=1e-13, atol=1e-13)
     np.testing.assert_allclose(p1.numpy(), p2, rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("S,N,max_wgs", [(5, 40, 256), (40, 300, 256), (70, 900, 16), (130, 600, 40)])
+def test_supertile_list_covers_every_camera_pair_once(S, N, max_wgs, monkeypatch):
+    """build_schur_supertiles: every co-observing camera pair (a <= b) of every point is produced by exactly one
+    (super-tile, entry, half pair); quads carry the union of the presence of their four entries; the strided sub-chunks
+    of the workgroups partition every tile's entry list; the workgroup count respects the cap (or is one per tile)."""
+    sc = make_scene(S, N, "SIMPLE_RADIAL", shared_camera=True, seed=S)
+    m = torch.from_numpy(sc.mask)
+    m[:, 3] = False
+    m[:2, 3] = True
+    pm = torch.nonzero(m.t())
+    obs_cam = pm[:, 1].to(torch.int32)
+    row_ptr = torch.zeros(N + 1, dtype=torch.int32)
+    row_ptr[1:] = torch.cumsum(m.sum(0), 0).to(torch.int32)
+    cd, ent, qm, td, slot, nseg = (t.numpy() if torch.is_tensor(t) else t for t in BA.build_schur_supertiles(row_ptr, obs_cam, max_wgs=max_wgs))
+    oc, rp = obs_cam.numpy(), row_ptr.numpy()
+    G = BA.GROUP
+    nent = int(cd[:, 3].max())
+    assert len(ent) == nent + BA.SUB and (ent[nent:] == nseg).all() and len(qm) >= (nent + 3) // 4 + BA.SUB // 4      # padding
+    ent = ent[:nent]
+    assert len(np.unique(slot)) == len(slot) and slot.max() < nseg * G and (slot % G == oc % G).all()
+    seg_of = slot // G
+    pt_of_obs = np.repeat(np.arange(N), np.diff(rp))
+    seg_cams = {int(sg): oc[seg_of == sg] for sg in np.unique(seg_of)}
+    seg_pt = {int(sg): int(pt_of_obs[np.nonzero(seg_of == sg)[0][0]]) for sg in np.unique(seg_of)}
+    seg_cams[nseg] = np.zeros(0, np.int32)                    # the all-zero segment
+    mask32 = lambda s0, s1: (sum(1 << (int(c) % G) for c in seg_cams[s0]) | (sum(1 << (int(c) % G) for c in seg_cams[s1]) << 16))
+    covered, seen = {}, np.zeros(len(ent), int)
+    assert len(cd) <= max(max_wgs, len(td))
+    assert td[0, 2] == 0 and td[-1, 3] == len(cd) and (td[1:, 2] == td[:-1, 3]).all()
+    assert len({(int(a), int(b)) for a, b, _, _ in td}) == len(td)
+    for sI, sJ, c0, c1 in td:
+        assert (cd[c0:c1, 0] == sI).all() and (cd[c0:c1, 1] == sJ).all() and (cd[c0:c1, 5] == c1 - c0).all()
+        assert sorted(cd[c0:c1, 4].tolist()) == list(range(c1 - c0))
+    for sI, sJ, tb, te, j, J, q0, _ in cd:
+        assert sI <= sJ
+        for s0 in range(tb + j * BA.SUB, te, J * BA.SUB):
+            for k in range(s0, min(s0 + BA.SUB, te)):
+                seen[k] += 1
+                a0, a1, b0, b1 = (int(v) for v in ent[k])
+                if sI == sJ:
+                    assert (a0, a1) == (b0, b1)
+                assert a0 < nseg or a1 < nseg
+                p = seg_pt[a0 if a0 < nseg else a1]
+                for sg, grp in ((a0, 2 * sI), (a1, 2 * sI + 1), (b0, 2 * sJ), (b1, 2 * sJ + 1)):
+                    assert sg == nseg or (seg_pt[sg] == p and (seg_cams[sg] // G == grp).all())
+                q = q0 + (k - tb) // 4
+                qa = qb = 0
+                for kk in range(tb + (k - tb) // 4 * 4, min(tb + (k - tb) // 4 * 4 + 4, te)):
+                    qa |= mask32(ent[kk, 0], ent[kk, 1])
+                    qb |= mask32(ent[kk, 2], ent[kk, 3])
+                assert (int(qm[q, 0]) & 0xffffffff) == qa and (int(qm[q, 1]) & 0xffffffff) == qb
+                A = np.concatenate([seg_cams[a0], seg_cams[a1]])
+                B = np.concatenate([seg_cams[b0], seg_cams[b1]])
+                for a in A:
+                    for bb in B:
+                        if sI == sJ and a > bb:
+                            continue
+                        covered[(p, int(a), int(bb))] = covered.get((p, int(a), int(bb)), 0) + 1
+    assert (seen == 1).all()
+    expect = set()
+    for p in range(N):
+        cams = oc[rp[p]:rp[p + 1]]
+        for i, a in enumerate(cams):
+            for bb in cams[i:]:
+                expect.add((p, int(a), int(bb)))
+    assert set(covered) == expect and all(v == 1 for v in covered.values())
+    # compile_problem hands the super-tile list to shared-intrinsics problems when the path is switched on
+    monkeypatch.setattr(BA, "SUPER_TILES", True)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=S)
+    prob, _, _ = BA.compile_problem(T(pts0), T(ext0), T(K0), T(sc.tracks), T(sc.mask), T(extra0), True, "SIMPLE_RADIAL")
+    assert prob.quad_mask is not None and prob.chunk_desc.shape[1] == 8 and prob.c_struct().super_tiles == 1
+    prob, _, _ = BA.compile_problem(T(pts0), T(ext0), T(K0), T(sc.tracks), T(sc.mask), T(extra0), False, "SIMPLE_RADIAL")
+    assert prob.quad_mask is None and prob.chunk_desc.shape[1] == 6 and prob.c_struct().super_tiles == 0
 
 
 @pytest.mark.parametrize("xcds", [1, 8])

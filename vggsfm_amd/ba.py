@@ -18,6 +18,8 @@ import ctypes
 from dataclasses import dataclass
 from typing import Optional
 
+import os
+
 import torch
 
 from . import _lib
@@ -115,6 +117,7 @@ class DeviceProblem:
     chol_first_blk: Optional[torch.Tensor] = None   # (ceil(n / 64),) int32 device: row envelope of the reduced system (None = dense)
     block_chunk: Optional[torch.Tensor] = None      # (num_chunks,) int32 device: launch position -> chunk (XCD placement; None = identity)
     obs_pt: Optional[torch.Tensor] = None           # (O,) int32 device: point of every point-major observation (None = fused Y pass)
+    quad_mask: Optional[torch.Tensor] = None        # (Q,2) int32 device: set <=> chunk_desc / entries / tile_desc are SUPER-TILES
 
     @property
     def num_obs(self):
@@ -127,10 +130,13 @@ class DeviceProblem:
         P.camera_model, P.refine_focal, P.refine_extra = self.camera_model, int(self.refine_focal), int(self.refine_extra)
         P.loss, P.loss_scale = self.loss, self.loss_scale
         for name in ("cam_q", "cam_t", "intr", "pts", "row_ptr", "obs_cam", "obs_uv", "col_ptr", "cobs_pt", "cobs_uv",
-                     "cam_const", "intr_const", "pt_const", "chunk_desc", "entries", "tile_desc", "obs_slot", "obs_pt"):
+                     "cam_const", "intr_const", "pt_const", "chunk_desc", "entries", "tile_desc", "obs_slot", "obs_pt", "quad_mask"):
             t = getattr(self, name)
             setattr(P, name, None if t is None else t.data_ptr())
         P.num_chunks = self.chunk_desc.shape[0]
+        P.super_tiles = int(self.quad_mask is not None)
+        if self.quad_mask is not None:
+            self.batch_desc = torch.tensor([[0, 0, self.chunk_desc.shape[0], 0, self.tile_desc.shape[0], 0]], dtype=torch.int32)
         if self.batch_desc is None:                 # a hand-built problem: one batch, off-diagonal chunks first
             noff = int((self.chunk_desc[:, 0] != self.chunk_desc[:, 1]).sum().item())
             self.batch_desc = torch.tensor([[0, noff, self.chunk_desc.shape[0], 0, self.tile_desc.shape[0], 0]],
@@ -151,9 +157,11 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
 
     A *segment* is the run of one point's observations that falls into one group of `group`
     consecutive cameras; an *entry* pairs two segments (gI <= gJ) of the same point; entries are
-    sorted by tile (gI, gJ) and by point inside a tile; a tile with k entries gets J = ceil(k / `chunk`)
+    sorted by tile (gI, gJ) and, inside a tile, by the sweep position of the point (first camera, last camera); a tile with k entries gets J = ceil(k / `chunk`)
     workgroups ("chunks", off-diagonal tiles first), workgroup j taking the sub-chunks j, j+J, ... of SUB entries (kSub in ba.hip).
-    Returns (chunk_desc (n,6) int32 = gI,gJ,tile_begin,tile_end,j,J ; entries (E,4) int32 = point,segA,segB,maskA|maskB<<16 ;
+    Returns (chunk_desc (n,6) int32 = gI,gJ,tile_begin,tile_end,j,J ; entries (E,4) int32 = sweep position of the point,
+    segA, segB, maskA|maskB<<16 of the QUAD (the union over the four consecutive entries, aligned to the tile's begin, that one
+    MFMA K-step packs; bit l of a mask <=> camera group*16 + l observes one of the four points) ;
     tile_desc (T,4) int32 = gI,gJ,chunk_begin,chunk_end ; obs_slot (O,) int32 = segment*16 + camera%16 ;
     number of segments ; batch_desc (B,6) int32 ON THE HOST).
 
@@ -202,6 +210,15 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     B = A + (torch.arange(total, device=dev) - pair_start[A])
     # batch of a camera group: runs of consecutive groups gI with about equal numbers of entries
     gA, gB = seg_grp[A], seg_grp[B]
+    # sweep position of a point: all tiles walk the points in the order (first camera, last camera), so that the four
+    # entries a workgroup packs along K (a "quad") have about the same presence pattern (the tile kernels skip the 16-row
+    # blocks in which none of the four has a camera) and every tile still meets a given point at about the same time
+    ncam = int(obs_cam.max().item()) + 1
+    has = counts > 0
+    first_cam = torch.where(has, obs_cam.long()[row_ptr[:-1].long().clamp(max=O - 1)], torch.zeros_like(counts))
+    last_cam = torch.where(has, obs_cam.long()[(row_ptr[1:].long() - 1).clamp(min=0)], torch.zeros_like(counts))
+    prank = torch.empty(P, dtype=torch.long, device=dev)
+    prank[torch.argsort(first_cam * ncam + last_cam, stable=True)] = torch.arange(P, device=dev)
     per_group = torch.bincount(gA, minlength=ngroups).double()
     nb = max(1, min(int(num_batches), ngroups))
     cum = torch.cumsum(per_group, 0) - per_group                    # entries before group g
@@ -210,20 +227,30 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     # tile key: batch-major; inside a batch the off-diagonal tiles first, then the diagonal ones (separate launches)
     nn = ngroups * ngroups
     key = batch_of_group[gA] * (2 * nn) + (gA == gB).long() * nn + gA * ngroups + gB
-    order = torch.argsort(key, stable=True)
-    A, B, key = A[order], B[order], key[order]
-    entries = torch.stack([seg_pt[A], A, B, seg_mask[A] | (seg_mask[B] << 16)], 1).to(torch.int32)
-    # part of an entry = the XCD its point belongs to: `xcds` contiguous point ranges with about equal entry counts
+    epos = prank[seg_pt[A]]
+    order = torch.argsort(key * P + epos)
+    A, B, key, epos = A[order], B[order], key[order], epos[order]
+    emask = seg_mask[A] | (seg_mask[B] << 16)
+    # part of an entry = the XCD its point belongs to: `xcds` contiguous ranges of sweep positions with about equal entry counts
     xcds = max(1, int(xcds))
-    per_point = torch.bincount(seg_pt[A], minlength=P).double()
+    per_point = torch.bincount(epos, minlength=P).double()
     cum_pt = torch.cumsum(per_point, 0) - per_point
-    part_of_point = torch.clamp((cum_pt * xcds / max(float(total), 1.0)).long(), max=xcds - 1)
-    epart = part_of_point[seg_pt[A]]
-    # chunking unit = (tile, part): inside a tile the entries are sorted by point, hence by part
+    part_of_pos = torch.clamp((cum_pt * xcds / max(float(total), 1.0)).long(), max=xcds - 1)
+    epart = part_of_pos[epos]
+    # chunking unit = (tile, part): inside a tile the entries are sorted by sweep position, hence by part
     ukeys, kcounts = torch.unique_consecutive(key * xcds + epart, return_counts=True)
     upart = ukeys % xcds
     ukeys = ukeys // xcds
     tile_start = torch.cumsum(kcounts, 0) - kcounts
+    # presence of a quad = union over its four entries (quads are aligned to the start of the unit, like the kernel's batches)
+    unit_of_entry = torch.repeat_interleave(torch.arange(kcounts.shape[0], device=dev), kcounts)
+    upos = torch.arange(total, device=dev) - tile_start[unit_of_entry]
+    nquad = (kcounts + 3) // 4
+    quad = (torch.cumsum(nquad, 0) - nquad)[unit_of_entry] + upos // 4
+    qm = torch.zeros((int(nquad.sum().item()), 4), dtype=torch.long, device=dev)
+    qm[quad, upos % 4] = emask
+    qm = qm[:, 0] | qm[:, 1] | qm[:, 2] | qm[:, 3]
+    entries = torch.stack([epos, A, B, qm[quad]], 1).to(torch.int32)
     tbatch = ukeys // (2 * nn)
     is_diag = (ukeys % (2 * nn)) >= nn
     ukeys = ukeys % nn
@@ -300,6 +327,162 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     block_chunk = torch.tensor(block_chunk, dtype=torch.int32, device=dev)
     return (chunk_desc.contiguous(), entries.contiguous(), tile_desc.contiguous(), obs_slot.contiguous(), int(nseg),
             batch_desc.contiguous(), block_chunk)
+
+
+SUPER_BATCH_OVERHEAD = 12.0  # cost of a batch besides its matrix instructions, in matrix instructions of one SIMD (barrier, operand fetch)
+
+
+def _super_block_bits(group=GROUP, bd=6):
+    """(24 * bd / 16,) long: bits of the 32-camera presence mask of a super-group whose cameras have rows in each 16-row
+    block of the super-tile (`super_block_bits` in csrc/ba.hip)."""
+    per_half = group * bd // 16
+    out = []
+    for blk in range(2 * per_half):
+        half, b = divmod(blk, per_half)
+        s0, s1 = (16 * b) // bd, min(group - 1, (16 * b + 15) // bd)
+        out.append((((2 << s1) - 1) & ~((1 << s0) - 1)) << (16 * half))
+    return torch.tensor(out, dtype=torch.long)
+
+
+# Opt-in (VGGSFM_SUPER_TILES=1): 2 x 2 super-tiles of 32 x 32 cameras for shared-intrinsics problems (build_schur_supertiles,
+# super_tile_kernel).  Measured on c3: 1.62 ms against 0.62 + 0.27 ms of the 16-camera tile kernels -- see DESIGN.md section 6.
+SUPER_TILES = os.environ.get("VGGSFM_SUPER_TILES", "0") == "1"
+
+
+def build_schur_supertiles(row_ptr, obs_cam, group=GROUP, max_wgs=256):
+    """Schur work list in 2 x 2 SUPER-TILES (6 x 6 camera blocks only; `super_tile_kernel` in csrc/ba.hip).
+
+    The tile kernel of `build_schur_tiles` is bound by the staging of its operands: a 96 x 96 tile multiplies two 2304-byte
+    segments per entry, 12 flop per staged byte -- the machine balance (78.6 TFLOP/s over ~6.4 TB/s).  A workgroup of 8
+    wavefronts that owns the 192 x 192 tile of a PAIR of camera groups on either side stages 4 segments for 4 products:
+    twice the flops per byte, and with the presence skipping of the kernels the absent halves cost nothing.
+
+    A super-group = 2 consecutive camera groups (32 cameras); a super-entry pairs the (up to) two segments of a point in
+    super-group sI with those in sJ >= sI; the segment buffer and `obs_slot` are those of `build_schur_tiles`.
+    Returns (chunk_desc (n,8) int32 = sI,sJ,entry_begin,entry_end,j,J,quad_begin,0 ; entries (E,4) int32 = segA0,segA1,segB0,
+    segB1 (`num_segments` = the all-zero segment stands for an absent half; a diagonal super-tile has B = A) ; quad_mask
+    (Q,2) int32 = presence of the 32 cameras of sI / of sJ in the union of the four entries of a quad (quads are aligned to
+    the tile's begin) ; tile_desc (T,4) int32 = sI,sJ,chunk_begin,chunk_end ; obs_slot ; number of segments).  `entries` and
+    `quad_mask` carry one sub-chunk (SUB entries, SUB / 4 quads) of padding behind the last tile.
+    Entries are sorted by tile (off-diagonal tiles first) and by the sweep position of the point inside a tile; a tile with
+    Entries are sorted by tile (off-diagonal tiles first) and, inside a tile, by block pattern and sweep position; a tile
+    gets J workgroups in proportion to its cost (matrix instructions of the busiest SIMD, from the quad masks), all
+    workgroups together filling `max_wgs` (one resident round of one workgroup per CU); workgroup j takes the sub-chunks
+    j, j + J, ... of SUB entries."""
+    dev = obs_cam.device
+    O = obs_cam.shape[0]
+    P = row_ptr.shape[0] - 1
+    i32 = lambda *shape: torch.zeros(shape, dtype=torch.int32, device=dev)
+    if O == 0:
+        return i32(0, 8), i32(0, 4), i32(0, 2), i32(0, 4), i32(0), 0
+    counts = (row_ptr[1:] - row_ptr[:-1]).long()
+    obs_pt = torch.repeat_interleave(torch.arange(P, device=dev), counts)
+    grp = (obs_cam // group).long()
+    is_start = torch.ones(O, dtype=torch.bool, device=dev)
+    is_start[1:] = (obs_pt[1:] != obs_pt[:-1]) | (grp[1:] != grp[:-1])
+    seg_begin = torch.nonzero(is_start).squeeze(1)
+    nseg = seg_begin.shape[0]
+    seg_id = torch.cumsum(is_start.long(), 0) - 1
+    seg_mask = torch.zeros(nseg + 1, dtype=torch.long, device=dev).index_add_(0, seg_id, 1 << (obs_cam.long() % group))
+    seg_pt, seg_grp = obs_pt[seg_begin], grp[seg_begin]
+    obs_slot = (seg_id * group + obs_cam.long() % group).to(torch.int32)
+    # super-segments: runs of (point, group // 2) -- one or two consecutive segments
+    sgrp = seg_grp // 2
+    s_start = torch.ones(nseg, dtype=torch.bool, device=dev)
+    s_start[1:] = (seg_pt[1:] != seg_pt[:-1]) | (sgrp[1:] != sgrp[:-1])
+    ss_first = torch.nonzero(s_start).squeeze(1)
+    nss = ss_first.shape[0]
+    ss_n = torch.bincount(torch.cumsum(s_start.long(), 0) - 1, minlength=nss)
+    first_half = seg_grp[ss_first] % 2
+    zero = torch.full_like(ss_first, nseg)
+    h0 = torch.where(first_half == 0, ss_first, zero)
+    h1 = torch.where(first_half == 1, ss_first, torch.where(ss_n == 2, ss_first + 1, zero))
+    ss_mask = seg_mask[h0] | (seg_mask[h1] << 16)                  # (seg_mask[nseg] = 0: the zero segment)
+    ss_pt, ss_g = seg_pt[ss_first], sgrp[ss_first]
+    nsg = int(ss_g.max().item()) + 1
+    # pairs (sI <= sJ) of the super-segments of a point
+    pss_ptr = torch.zeros(P + 1, dtype=torch.long, device=dev)
+    pss_ptr[1:] = torch.cumsum(torch.bincount(ss_pt, minlength=P), 0)
+    idx = torch.arange(nss, device=dev)
+    npair = pss_ptr[ss_pt + 1] - idx
+    total = int(npair.sum().item())
+    A = torch.repeat_interleave(idx, npair)
+    B = A + (torch.arange(total, device=dev) - (torch.cumsum(npair, 0) - npair)[A])
+    # sweep position of a point (see build_schur_tiles)
+    ncam = int(obs_cam.max().item()) + 1
+    first_cam = obs_cam.long()[row_ptr[:-1].long().clamp(max=O - 1)]
+    last_cam = obs_cam.long()[(row_ptr[1:].long() - 1).clamp(min=0)]
+    prank = torch.empty(P, dtype=torch.long, device=dev)
+    prank[torch.argsort(first_cam * ncam + last_cam, stable=True)] = torch.arange(P, device=dev)
+    sI, sJ = ss_g[A], ss_g[B]
+    nn = nsg * nsg
+    key = (sI == sJ).long() * nn + sI * nsg + sJ
+    # inside a tile: by BLOCK PATTERN (which of the 2 x 12 sixteen-row blocks of the super-tile hold a camera of the entry),
+    # then by sweep position -- the four entries of a quad then have (nearly) the same pattern and the union the kernel
+    # skips by is (nearly) what every one of them needs
+    bits = _super_block_bits(group)
+    patA = (((ss_mask[:, None] & bits[None].to(dev)) != 0).long() * (1 << torch.arange(bits.shape[0], device=dev))[None]).sum(1)
+    pat = patA[A] * (1 << bits.shape[0]) + patA[B]
+    order = torch.argsort((key * (1 << (2 * bits.shape[0])) + pat) * P + prank[ss_pt[A]])
+    A, B, key = A[order], B[order], key[order]
+    entries = torch.stack([h0[A], h1[A], h0[B], h1[B]], 1).to(torch.int32)
+    ukeys, kcounts = torch.unique_consecutive(key, return_counts=True)
+    tile_start = torch.cumsum(kcounts, 0) - kcounts
+    is_diag = ukeys >= nn
+    ukeys = ukeys % nn
+    # quads
+    unit = torch.repeat_interleave(torch.arange(kcounts.shape[0], device=dev), kcounts)
+    upos = torch.arange(total, device=dev) - tile_start[unit]
+    nquad = (kcounts + 3) // 4
+    quad_start = torch.cumsum(nquad, 0) - nquad
+    quad = quad_start[unit] + upos // 4
+    NQ = int(nquad.sum().item())
+    qa = torch.zeros((NQ, 4), dtype=torch.long, device=dev)
+    qb = torch.zeros((NQ, 4), dtype=torch.long, device=dev)
+    qa[quad, upos % 4] = ss_mask[A]
+    qb[quad, upos % 4] = ss_mask[B]
+    quad_mask = torch.stack([qa[:, 0] | qa[:, 1] | qa[:, 2] | qa[:, 3], qb[:, 0] | qb[:, 1] | qb[:, 2] | qb[:, 3]], 1).to(torch.int32)
+    # Workgroups per tile in proportion to the tile's COST: per quad, the matrix instructions of the busiest SIMD under the
+    # kernel's sub-tile ownership (+ a constant per batch), summed over the tile.  The strided sub-chunks give every
+    # workgroup of a tile the same mix of patterns, so its cost is the tile's / J.
+    ua = ((quad_mask[:, 0:1].long() & bits[None].to(dev)) != 0)                  # (Q, 12) blocks of side A with a camera
+    ub = ((quad_mask[:, 1:2].long() & bits[None].to(dev)) != 0)
+    nblk = bits.shape[0]
+    cls = torch.arange(nblk, device=dev) % 4
+    ra4 = torch.stack([ua[:, cls == k].sum(1) for k in range(4)], 1).double()      # active rows per class r % 4
+    cb4 = torch.stack([ub[:, cls == k].sum(1) for k in range(4)], 1).double()
+    off_simd = torch.stack([sum(ra4[:, k] * cb4[:, (sd - k) % 4] for k in range(4)) for sd in range(4)], 1)   # (r + c) % 4 == sd
+    tri_r, tri_c = torch.tril_indices(nblk, nblk, device=dev)                     # row-major enumeration of the lower triangle
+    tri_on = (ua[:, tri_r] & ua[:, tri_c]).double()
+    tcls = torch.arange(tri_r.shape[0], device=dev) % 4
+    diag_simd = torch.stack([tri_on[:, tcls == k].sum(1) for k in range(4)], 1)
+    quad_diag = torch.repeat_interleave(is_diag, nquad)
+    quad_cost = 3.0 * torch.where(quad_diag, diag_simd.max(1).values, off_simd.max(1).values) + SUPER_BATCH_OVERHEAD
+    tile_cost = torch.zeros(kcounts.shape[0], dtype=torch.float64, device=dev).index_add_(
+        0, torch.repeat_interleave(torch.arange(kcounts.shape[0], device=dev), nquad), quad_cost)
+    max_j = torch.clamp((kcounts + MIN_CHUNK - 1) // MIN_CHUNK, min=1)            # at least MIN_CHUNK entries per workgroup
+    jof = lambda c: torch.minimum(torch.clamp(torch.ceil(tile_cost / c).long(), min=1), max_j)
+    lo_c, hi_c = float(tile_cost.sum().item()) / max(max_wgs, 1), float(tile_cost.max().item()) + 1.0
+    if int(jof(hi_c).sum().item()) > max_wgs:       # more tiles than workgroup slots: one workgroup per tile
+        lo_c = hi_c
+    for _ in range(40):                             # smallest cost per workgroup whose workgroup count fits
+        mid = 0.5 * (lo_c + hi_c)
+        if int(jof(mid).sum().item()) <= max_wgs:
+            hi_c = mid
+        else:
+            lo_c = mid
+    nchunks = jof(hi_c)
+    ctile = torch.repeat_interleave(torch.arange(ukeys.shape[0], device=dev), nchunks)
+    cfirst = torch.cumsum(nchunks, 0) - nchunks
+    local = torch.arange(ctile.shape[0], device=dev) - cfirst[ctile]
+    chunk_desc = torch.stack([ukeys[ctile] // nsg, ukeys[ctile] % nsg, tile_start[ctile], tile_start[ctile] + kcounts[ctile],
+                              local, nchunks[ctile], quad_start[ctile], torch.zeros_like(local)], 1).to(torch.int32)
+    tile_desc = torch.stack([ukeys // nsg, ukeys % nsg, cfirst, cfirst + nchunks], 1).to(torch.int32)
+    # the kernel fetches indices and masks a whole sub-chunk at a time: one sub-chunk of padding behind the last tile
+    entries = torch.cat([entries, torch.full((SUB, 4), nseg, dtype=torch.int32, device=dev)])
+    quad_mask = torch.cat([quad_mask, torch.zeros((SUB // 4, 2), dtype=torch.int32, device=dev)])
+    return (chunk_desc.contiguous(), entries.contiguous(), quad_mask.contiguous(), tile_desc.contiguous(), obs_slot.contiguous(),
+            int(nseg))
 
 
 CAMERA_SPLIT_MIN_STEPS = 2    # shared 64-column factorisation steps below which re-ordering the cameras is not worth it
@@ -498,11 +681,17 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
     # three batches when the factorisation can overlap the later ones (enough camera groups, enough work per batch)
     overlap = OVERLAP_FACTORIZATION if overlap is None else bool(overlap)
     nb = TILE_BATCHES if (overlap and int(obs_cam.shape[0]) >= OVERLAP_MIN_OBS and S >= OVERLAP_MIN_FRAMES) else 1
-    chunk_desc, entries, tile_desc, obs_slot, nseg, batch_desc, block_chunk = build_schur_tiles(
-        row_ptr, obs_cam, max_chunks=slots, num_batches=nb, later_scale=(cus - CHOL_CUS) / cus)
+    quad_mask = None
+    if SUPER_TILES and shared_camera and nb == 1 and int(obs_cam.shape[0]) > 0:
+        # 6 x 6 camera blocks: 2 x 2 super-tiles, one workgroup of 8 wavefronts per CU, one launch
+        chunk_desc, entries, quad_mask, tile_desc, obs_slot, nseg = build_schur_supertiles(row_ptr, obs_cam, max_wgs=cus)
+        batch_desc, block_chunk = None, None
+    else:
+        chunk_desc, entries, tile_desc, obs_slot, nseg, batch_desc, block_chunk = build_schur_tiles(
+            row_ptr, obs_cam, max_chunks=slots, num_batches=nb, later_scale=(cus - CHOL_CUS) / cus)
     prob = DeviceProblem(cam_q, cam_t, intr, pts, row_ptr, obs_cam, obs_uv, col_ptr, cobs_pt, cobs_uv, chunk_desc,
                          entries, tile_desc, obs_slot, nseg, MODEL_ID[camera_type], cam_const=cam_const,
-                         batch_desc=batch_desc, chol_split=chol_split, cam_perm=cam_perm, block_chunk=block_chunk,
+                         batch_desc=batch_desc, chol_split=chol_split, cam_perm=cam_perm, block_chunk=block_chunk, quad_mask=quad_mask,
                          obs_pt=pm[:, 0].to(torch.int32).contiguous())
     if first_group is not None:
         kd = 2 if camera_type == "SIMPLE_RADIAL" else 1              # upper bound of the intrinsics unknowns per block

@@ -33,7 +33,7 @@ w0 = tr[:, 0]
 tot = w0[:, 3]
 print("cycles per workgroup: min %d median %d max %d" % (tot.min(), np.median(tot), tot.max()))
 print("cycles per batch:", np.round(np.percentile(tot / np.maximum(w0[:, 2], 1), [0, 25, 50, 75, 100])))
-print("wall (10 ns units): kernel span %d, per workgroup median %d" % (tr[:, :, 7].max() - tr[:, :, 6].min(), np.median(w0[:, 7] - w0[:, 6])))
-print("load wait fraction:", np.round(np.percentile(w0[:, 4] / tot, [0, 50, 100]), 3), "barrier wait fraction:", np.round(np.percentile(w0[:, 5] / tot, [0, 50, 100]), 3))
-for c in range(0, tr.shape[0], 12):
-    print(c, w0[c, :6].tolist(), "start %d dur %d" % (w0[c, 6] - tr[:, :, 6].min(), w0[c, 7] - w0[c, 6]), "wave waits", tr[c, :, 5].tolist())
+nbt = np.maximum(w0[:, 2], 1)
+for name, col in (("load wait", 4), ("barrier wait", 5), ("pre-MFMA (index readfirstlane, index DMA, fetch issue)", 6), ("MFMA phase (operand reads, tests, matrix instructions, DMA pieces)", 7)):
+    for wv in (0, 4):
+        print("wave %d  %-70s cycles per batch: %s" % (wv, name, np.round(np.percentile(tr[:, wv, col] / nbt, [0, 25, 50, 75, 100])).tolist()))

@@ -1022,7 +1022,7 @@ __device__ __forceinline__ uint32_t super_block_bits(int blk) {
 }
 
 #if VGG_SUPER_TRACE
-__device__ long long g_super_trace[1024 * 8 * 8];   // [chunk][wave][sI, sJ, batches, cycles, load wait, barrier wait, wall begin, wall end]
+__device__ long long g_super_trace[1024 * 8 * 8];   // [chunk][wave][sI, sJ, batches, cycles, load wait, barrier wait, pre-MFMA, MFMA phase]
 #endif
 // LDS-DMA: 16 bytes per active lane from `src` (per lane) to LDS byte address lds_dst + 16 * lane (wave-uniform base in
 // M0).  Not counted by the compiler: completion is awaited with explicit s_waitcnt vmcnt(N) (one count per statement).
@@ -1115,7 +1115,7 @@ __device__ __forceinline__ void super_tile_body(const Ws& w, double* __restrict_
   };
 
 #if VGG_SUPER_TRACE
-  long long t_load = 0, t_bar = 0;
+  long long t_load = 0, t_bar = 0, t_pre = 0, t_mfma = 0;
   const long long t_begin = __builtin_readcyclecounter(), t_wall0 = (long long)wall_clock64();
 #endif
   // prologue: index slots of sub-chunks 0 and 1, then the operand images of batches 0, 1, 2
@@ -1156,14 +1156,21 @@ __device__ __forceinline__ void super_tile_body(const Ws& w, double* __restrict_
 #pragma unroll
       for (int h = 0; h < SPW; ++h) sgv[h] = fetch_seg(b + kSRing, h);
       qav = fetch_mask(b + 1, 0); qbv = fetch_mask(b + 1, 1);
+#if VGG_SUPER_TRACE
+      const long long tw3 = __builtin_readcyclecounter();
+#endif
       mfma_batch(ops + (size_t)(b & (kSRing - 1)) * BUF, qa, qb, [&](int p) __attribute__((always_inline)) { issue_piece(refill, sg_next, p); });
+#if VGG_SUPER_TRACE
+      const long long tw4 = __builtin_readcyclecounter();
+      t_pre += tw3 - tw2; t_mfma += tw4 - tw3;
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // nothing may land in LDS after this workgroup has gone
 #if VGG_SUPER_TRACE
     if (lane == 0 && chunk < 1024) {
       long long* tr = g_super_trace + ((size_t)chunk * 8 + wave) * 8;
       tr[0] = cd[0]; tr[1] = cd[1]; tr[2] = nb; tr[3] = (long long)__builtin_readcyclecounter() - t_begin; tr[4] = t_load; tr[5] = t_bar;
-      tr[6] = t_wall0; tr[7] = (long long)wall_clock64();
+      tr[6] = t_pre; tr[7] = t_mfma;
     }
 #endif
   };

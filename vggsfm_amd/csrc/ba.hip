@@ -24,6 +24,8 @@
 //   cholesky        chol.hip (matrix-core trailing update)
 //   point_step      back-substitution, model cost change, candidate cost
 //   control         Ceres' accept / reject logic, one workgroup
+#include <type_traits>
+
 #include "camera_model.hpp"
 #include "../../include/vggsfm_amd.h"
 
@@ -39,6 +41,9 @@ constexpr int kGroup = 16;       // cameras per Schur tile side
 #endif
 #ifndef VGG_PP_OCC_SPLIT
 #define VGG_PP_OCC_SPLIT 3   // point_pass without the Y sweep: 158 VGPRs
+#endif
+#ifndef VGG_PP_ABLATE
+#define VGG_PP_ABLATE 0              // profiling builds of point_pass_kernel: 1 = no Y stores, 2 = no Y sweep
 #endif
 #ifndef VGG_PP_OCC
 #define VGG_PP_OCC 2
@@ -298,11 +303,48 @@ __global__ __launch_bounds__(256, VGG_CP_OCC) void cam_pass_kernel(DevProblem pb
   const int j_begin = pb.col_ptr[c], j_count = pb.col_ptr[c + 1] - j_begin;
   const int per = (j_count + split - 1) / split;
   const int j0 = j_begin + (int)blockIdx.y * per, j1 = min(j0 + per, j_begin + j_count);
-  for (int j = j0 + threadIdx.x; j < j1; j += 256) {
-    const int p = pb.cobs_pt[j];
-    const float2 uv = pb.cobs_uv[j];
-    double X[3] = {pb.pts[3 * p], pb.pts[3 * p + 1], pb.pts[3 * p + 2]};
-    const bool pt_c = pb.pt_const ? pb.pt_const[p] != 0 : false;
+  // Software pipeline over this thread's observations: (point index, pixel) are loaded TWO iterations ahead, the point
+  // coordinates (and, MODE 1, its back-substitution terms) -- a gather that depends on the index -- ONE iteration ahead:
+  // the two dependent memory round trips of an observation overlap the arithmetic of the two before it.  (Without it the
+  // pass ran 5x off its instruction-issue bound at 3-4 wavefronts per SIMD.)
+  constexpr int KM = (KD > 0) ? KD : 1;
+  int j = j0 + threadIdx.x;
+  int p2 = 0; float2 uv2 = make_float2(0.f, 0.f);
+  if (j < j1) { p2 = pb.cobs_pt[j]; uv2 = pb.cobs_uv[j]; }
+  int p1 = p2; float2 uv1 = uv2;
+  double X1[3] = {0, 0, 0}, h1[3] = {0, 0, 0}, M1[3 * KM];
+#pragma unroll
+  for (int i = 0; i < 3 * KM; ++i) M1[i] = 0;
+  bool c1 = false;
+  auto gather = [&](int p) __attribute__((always_inline)) {
+    X1[0] = pb.pts[3 * p]; X1[1] = pb.pts[3 * p + 1]; X1[2] = pb.pts[3 * p + 2];
+    c1 = pb.pt_const ? pb.pt_const[p] != 0 : false;
+    if (MODE == 1) {
+      h1[0] = w.hs[3 * p]; h1[1] = w.hs[3 * p + 1]; h1[2] = w.hs[3 * p + 2];
+#pragma unroll
+      for (int m = 0; m < KD; ++m)
+        if (m < kdsh) {
+          const double* M = w.Ms + ((size_t)p * kdsh + m) * 3;
+          M1[3 * m] = M[0]; M1[3 * m + 1] = M[1]; M1[3 * m + 2] = M[2];
+        }
+    }
+  };
+  if (j < j1) gather(p1);
+  if (j + 256 < j1) { p2 = pb.cobs_pt[j + 256]; uv2 = pb.cobs_uv[j + 256]; }
+  for (; j < j1; j += 256) {
+    const int p = p1;
+    const float2 uv = uv1;
+    const double X[3] = {X1[0], X1[1], X1[2]};
+    const bool pt_c = c1;
+    const double h0 = h1[0], h1v = h1[1], h2 = h1[2];
+    double Mc[3 * KM];
+#pragma unroll
+    for (int i = 0; i < 3 * KM; ++i) Mc[i] = M1[i];
+    // advance the pipeline: gather for iteration j + 256 (its index arrived an iteration ago), index for j + 512
+    p1 = p2; uv1 = uv2;
+    if (j + 256 < j1) gather(p1);
+    if (j + 512 < j1) { p2 = pb.cobs_pt[j + 512]; uv2 = pb.cobs_uv[j + 512]; }
+    (void)p;
     double r[2], F[2 * BD], E[6];
     const double rho0 = eval_full<KD>(d, q, t, in4, X, uv, camflag, intr_c, pt_c, r, F, E);
     if (MODE == 0) {
@@ -315,14 +357,13 @@ __global__ __launch_bounds__(256, VGG_CP_OCC) void cam_pass_kernel(DevProblem pb
       for (int i = 0; i < BD; ++i) acc[NU + i] += F[i] * r[0] + F[BD + i] * r[1];
       acc[NU + BD] += rho0;
     } else {
-      const double h0 = w.hs[3 * p], h1 = w.hs[3 * p + 1], h2 = w.hs[3 * p + 2];
       double R0[1 + KD], R1[1 + KD];
-      R0[0] = r[0] - (E[0] * h0 + E[1] * h1 + E[2] * h2);
-      R1[0] = r[1] - (E[3] * h0 + E[4] * h1 + E[5] * h2);
+      R0[0] = r[0] - (E[0] * h0 + E[1] * h1v + E[2] * h2);
+      R1[0] = r[1] - (E[3] * h0 + E[4] * h1v + E[5] * h2);
 #pragma unroll
       for (int m = 0; m < KD; ++m) {
         if (m < kdsh) {
-          const double* M = w.Ms + ((size_t)p * kdsh + m) * 3;
+          const double* M = Mc + 3 * m;
           R0[1 + m] = -(E[0] * M[0] + E[1] * M[1] + E[2] * M[2]);
           R1[1 + m] = -(E[3] * M[0] + E[4] * M[1] + E[5] * M[2]);
         } else { R0[1 + m] = 0; R1[1 + m] = 0; }
@@ -443,13 +484,25 @@ __global__ void damping_kernel(Ws w, vgg_ba_options opt, int n_red) {
 // in round 2 (c3): 0.25 + 0.47 ms against 0.43 ms for the fused pass -- the reductions did not speed up with the third
 // wavefront and a thread-per-observation writer without the LDS camera table is slower than the in-wave sweep -- so
 // the fused pass stays the default.
+// Lanes per point of the point passes from the mean track length (VGG_LPP=16|32|64 overrides): a point's lanes share
+// its serial work, so the narrowest group that still holds most tracks in one sweep wins.
+static int lanes_per_point(int P, int O) {
+  static const int forced = [] { const char* e = getenv("VGG_LPP"); return e ? atoi(e) : 0; }();
+  if (forced == 16 || forced == 32 || forced == 64) return forced;
+  const double mean = P > 0 ? (double)O / P : 64.0;
+  return mean <= 14.0 ? 16 : (mean <= 56.0 ? 32 : 64);   // (c2, mean 12.5: 16 beats 64 by 0.045 ms; c3, mean 50: 32 beats 64 by 0.075 ms)
+}
 static const bool g_fused_point_pass = [] { const char* e = getenv("VGG_SPLIT_POINT_PASS"); return !(e && e[0] == '1'); }();
 
 // ---------------------------------------------------------------------------------------------
-// point-major pass: one wavefront per point
+// point-major pass: LPP lanes per point, 64 / LPP points per wavefront (LPP = 64: one wavefront per point; 32 / 16 for
+// short tracks -- the per-point work that every lane repeats (nine reductions, the 3 x 3 factorisation, ~360 of the ~640
+// instructions of a point at 50 observations) is shared by 2 / 4 points, and a 12-observation track fills 12 of 16 lanes
+// instead of 12 of 64).  The lanes of a point reduce among themselves (xor offsets < LPP); observations beyond the first
+// LPP of a track are re-evaluated in the Y sweep.
 // WRITE_Y = false: the per-observation Schur factors are left to y_write_kernel (thread per observation); this kernel
 // then needs neither the cached Jacobians nor the slot prefetch and fits three wavefronts per SIMD.
-template <int KD, bool LDSCAM, bool WRITE_Y>
+template <int KD, bool LDSCAM, bool WRITE_Y, int LPP>
 __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void point_pass_kernel(DevProblem pb, Ws w, vgg_ba_options opt) {
   constexpr int BD = 6 + KD;
   __shared__ double wmax[4];
@@ -457,8 +510,10 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
   Ctl* ctl = w.ctl;
   if (ctl->done) return;
   const Dims& d = pb.d;
+  constexpr int PPW = 64 / LPP;                  // points per wavefront
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int nw = gridDim.x * 4;
+  const int sub = lane / LPP, sl = lane % LPP;   // point of the wavefront's group, lane inside the point
+  const int nw = gridDim.x * 4 * PPW;            // points per sweep of the grid
   const bool first = !ctl->scale_ready;
   const double radius = ctl->radius;
   const int kdsh = d.kdsh;
@@ -478,7 +533,7 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
   }
   // software pipeline over the points of this wavefront: the row bounds / coordinates of the NEXT point and the
   // camera index, pixel and slot of its first 64 observations are loaded while the current point is processed
-  int p = blockIdx.x * 4 + wave;
+  int p = (blockIdx.x * 4 + wave) * PPW + sub;   // (the lanes of one point run the same control flow: per-lane loops below)
   int n_o0 = 0, n_o1 = 0, n_c = 0, n_slot = 0;
   double n_X0 = 0, n_X1 = 0, n_X2 = 0;
   float2 n_uv = make_float2(0.f, 0.f);
@@ -492,7 +547,7 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
     n_o0 = pb.row_ptr[p]; n_o1 = pb.row_ptr[p + 1];
     n_X0 = pb.pts[3 * p]; n_X1 = pb.pts[3 * p + 1]; n_X2 = pb.pts[3 * p + 2];
     n_ptc = pb.pt_const ? pb.pt_const[p] != 0 : false;
-    if (n_o0 + lane < n_o1) { n_c = pb.obs_cam[n_o0 + lane]; n_uv = pb.obs_uv[n_o0 + lane]; if (WRITE_Y) n_slot = pb.obs_slot[n_o0 + lane]; }
+    if (n_o0 + sl < n_o1) { n_c = pb.obs_cam[n_o0 + sl]; n_uv = pb.obs_uv[n_o0 + sl]; if (WRITE_Y) n_slot = pb.obs_slot[n_o0 + sl]; }
     if (p + nw < d.P) {
       const int pm = p + nw;
       m_o0 = pb.row_ptr[pm]; m_o1 = pb.row_ptr[pm + 1];
@@ -509,7 +564,7 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
     {
       // stage 1 -> current of the next iteration: observations of point p + nw (its bounds arrived an iteration ago)
       n_o0 = m_o0; n_o1 = m_o1; n_X0 = m_X0; n_X1 = m_X1; n_X2 = m_X2; n_ptc = m_ptc;
-      if (p + nw < d.P && n_o0 + lane < n_o1) { n_c = pb.obs_cam[n_o0 + lane]; n_uv = pb.obs_uv[n_o0 + lane]; if (WRITE_Y) n_slot = pb.obs_slot[n_o0 + lane]; }
+      if (p + nw < d.P && n_o0 + sl < n_o1) { n_c = pb.obs_cam[n_o0 + sl]; n_uv = pb.obs_uv[n_o0 + sl]; if (WRITE_Y) n_slot = pb.obs_slot[n_o0 + sl]; }
       // stage 2: bounds / coordinates of point p + 2 nw
       const int pm = p + 2 * nw;
       if (pm < d.P) {
@@ -521,9 +576,9 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
     double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0}, Wa[3 * (KD ? KD : 1)];
 #pragma unroll
     for (int i = 0; i < 3 * (KD ? KD : 1); ++i) Wa[i] = 0;
-    double cF[2 * BD], cE[6];          // Jacobians of this lane's first observation (tracks > 64 recompute)
-    for (int o = o0 + lane; o < o1; o += 64) {
-      const bool head = (o - o0 < 64);
+    double cF[2 * BD], cE[6];          // Jacobians of this lane's first observation (tracks > LPP recompute)
+    for (int o = o0 + sl; o < o1; o += LPP) {
+      const bool head = (o - o0 < LPP);
       const int c = head ? f_c : pb.obs_cam[o];
       const float2 uv = head ? f_uv : pb.obs_uv[o];
       const int a = d.shared ? 0 : c;
@@ -551,14 +606,14 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
       }
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) V[i] = wave_sum(V[i]);
+    for (int i = 0; i < 6; ++i) V[i] = group_sum<LPP>(V[i]);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) g[i] = wave_sum(g[i]);
+    for (int i = 0; i < 3; ++i) g[i] = group_sum<LPP>(g[i]);
     if (KD > 0 && kdsh) {
 #pragma unroll
-      for (int i = 0; i < 3 * KD; ++i) Wa[i] = wave_sum(Wa[i]);
+      for (int i = 0; i < 3 * KD; ++i) Wa[i] = group_sum<LPP>(Wa[i]);
     }
-    // every lane now holds the totals; lane 0 writes
+    // every lane of the point now holds the totals; its lane 0 writes
     double s[3];
     const double colsq[3] = {V[0], V[3], V[5]};
     if (first) {
@@ -588,7 +643,7 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
       const double d22 = a22 - l20 * l20 - l21 * l21;
       ok = ok && d22 > 0;
       const double l22 = sqrt(d22);
-      if (!ok) { if (lane == 0) ctl->linear_fail = 1; }
+      if (!ok) { if (sl == 0) ctl->linear_fail = 1; }
       // Linv (lower): i00 i10 i11 i20 i21 i22
       const double i00 = 1 / l00, i11 = 1 / l11, i22 = 1 / l22;
       const double i10 = -l10 * i00 * i11;
@@ -614,10 +669,10 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
     }
     // per-observation Schur factors Y_i = s_c o ((F_i^T E_i) G) -> slot obs_slot[o] of the zero-padded
     // segment buffer consumed by schur_tile_kernel
-    if (WRITE_Y) {
+    if (WRITE_Y && VGG_PP_ABLATE != 2) {
       const int bdt = d.shared ? 6 : BD;          // rows of the tile block (intrinsics only when per camera)
-      for (int o = o0 + lane; o < o1; o += 64) {
-        const bool head = (o - o0 < 64);
+      for (int o = o0 + sl; o < o1; o += LPP) {
+        const bool head = (o - o0 < LPP);
         const int c = head ? f_c : pb.obs_cam[o];
         double F[2 * BD], E[6];
         if (head) {                               // cached Jacobians of the first slice
@@ -641,14 +696,20 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
                                       : w.scale_c[6 * d.C + KD * c + (i - 6)];
             const double w0 = F[i] * E[0] + F[BD + i] * E[3], w1 = F[i] * E[1] + F[BD + i] * E[4],
                          w2 = F[i] * E[2] + F[BD + i] * E[5];
+#if VGG_PP_ABLATE == 1                            // profiling build: the Y arithmetic without its stores
+            if (Gm[0] == 12345.678) {
+#endif
             y[i] = sc * (w0 * Gm[0]);
             y[rt + i] = sc * (w0 * Gm[1] + w1 * Gm[3]);
             y[2 * rt + i] = sc * (w0 * Gm[2] + w1 * Gm[4] + w2 * Gm[5]);
+#if VGG_PP_ABLATE == 1
+            }
+#endif
           }
         }
       }
     }
-    if (lane == 0) {
+    if (sl == 0) {
       if (first) { w.scale_p[3 * p] = s[0]; w.scale_p[3 * p + 1] = s[1]; w.scale_p[3 * p + 2] = s[2]; }
 #pragma unroll
       for (int i = 0; i < 6; ++i) w.G[6 * (size_t)p + i] = Gm[i];
@@ -660,6 +721,7 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
       }
     }
   }
+  gmax = wave_max(gmax);
   if (lane == 0) wmax[wave] = gmax;
   __syncthreads();
   if (threadIdx.x == 0) w.part_B[blockIdx.x] = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
@@ -1449,16 +1511,18 @@ __global__ void cam_update_kernel(DevProblem pb, Ws w) {
   w.cam_part[2 * c + 1] = xn;
 }
 
-// back-substitution, model cost change, candidate point and candidate cost: one wavefront per point
-template <int KD, bool LDSCAM>
+// back-substitution, model cost change, candidate point and candidate cost: LPP lanes per point (see point_pass_kernel)
+template <int KD, bool LDSCAM, int LPP>
 __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem pb, Ws w) {
   constexpr int BD = 6 + KD;
   __shared__ double red[4][4];
   extern __shared__ double cam_cache[];   // LDSCAM: q[4C] t[3C] dy_pose[6C] cand_q[4C] cand_t[3C] flags[C]
   if (w.ctl->done) return;
   const Dims& d = pb.d;
+  constexpr int PPW = 64 / LPP;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int nw = gridDim.x * 4;
+  const int sub = lane / LPP, sl = lane % LPP;
+  const int nw = gridDim.x * 4 * PPW;
   double s_cost = 0, s_mcc = 0, s_step = 0, s_xn = 0;
   const double* lq = cam_cache;
   const double* lt = lq + 4 * d.C;
@@ -1474,7 +1538,7 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
     __syncthreads();
   }
   // same software pipeline over the points of a wavefront as in point_pass_kernel
-  int p = blockIdx.x * 4 + wave;
+  int p = (blockIdx.x * 4 + wave) * PPW + sub;
   int n_o0 = 0, n_o1 = 0, n_c = 0;
   double n_X0 = 0, n_X1 = 0, n_X2 = 0;
   float2 n_uv = make_float2(0.f, 0.f);
@@ -1488,7 +1552,7 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
     n_o0 = pb.row_ptr[p]; n_o1 = pb.row_ptr[p + 1];
     n_X0 = pb.pts[3 * p]; n_X1 = pb.pts[3 * p + 1]; n_X2 = pb.pts[3 * p + 2];
     n_ptc = pb.pt_const ? pb.pt_const[p] != 0 : false;
-    if (n_o0 + lane < n_o1) { n_c = pb.obs_cam[n_o0 + lane]; n_uv = pb.obs_uv[n_o0 + lane]; }
+    if (n_o0 + sl < n_o1) { n_c = pb.obs_cam[n_o0 + sl]; n_uv = pb.obs_uv[n_o0 + sl]; }
     if (p + nw < d.P) {
       const int pm = p + nw;
       m_o0 = pb.row_ptr[pm]; m_o1 = pb.row_ptr[pm + 1];
@@ -1505,7 +1569,7 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
     {
       // stage 1 -> current of the next iteration: observations of point p + nw (its bounds arrived an iteration ago)
       n_o0 = m_o0; n_o1 = m_o1; n_X0 = m_X0; n_X1 = m_X1; n_X2 = m_X2; n_ptc = m_ptc;
-      if (p + nw < d.P && n_o0 + lane < n_o1) { n_c = pb.obs_cam[n_o0 + lane]; n_uv = pb.obs_uv[n_o0 + lane]; }
+      if (p + nw < d.P && n_o0 + sl < n_o1) { n_c = pb.obs_cam[n_o0 + sl]; n_uv = pb.obs_uv[n_o0 + sl]; }
       // stage 2: bounds / coordinates of point p + 2 nw
       const int pm = p + 2 * nw;
       if (pm < d.P) {
@@ -1515,10 +1579,10 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
       }
     }
     double t3[3] = {0, 0, 0};
-    // cached values of this lane's first observation (tracks longer than 64 recompute)
+    // cached values of this lane's first observation (tracks longer than LPP recompute)
     double c_r[2] = {0, 0}, c_fy[2] = {0, 0}, c_E[6] = {0, 0, 0, 0, 0, 0};
-    for (int o = o0 + lane; o < o1; o += 64) {
-      const bool head = (o - o0 < 64);
+    for (int o = o0 + sl; o < o1; o += LPP) {
+      const bool head = (o - o0 < LPP);
       const int c = head ? f_c : pb.obs_cam[o];
       const float2 uv = head ? f_uv : pb.obs_uv[o];
       const int a = d.shared ? 0 : c;
@@ -1542,7 +1606,7 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
       }
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) t3[i] = wave_sum(t3[i]);
+    for (int i = 0; i < 3; ++i) t3[i] = group_sum<LPP>(t3[i]);
     const double* Gp = w.G + 6 * (size_t)p;
     const double G00 = Gp[0], G01 = Gp[1], G02 = Gp[2], G11 = Gp[3], G12 = Gp[4], G22 = Gp[5];
     // ys = hs - G G^T t3
@@ -1552,13 +1616,13 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
     ys[1] = w.hs[3 * p + 1] - (G11 * u1 + G12 * u2);
     ys[2] = w.hs[3 * p + 2] - (G22 * u2);
     const double Xn[3] = {X[0] - ys[0], X[1] - ys[1], X[2] - ys[2]};
-    if (lane == 0) {
+    if (sl == 0) {
       w.cand_pts[3 * (size_t)p] = Xn[0]; w.cand_pts[3 * (size_t)p + 1] = Xn[1]; w.cand_pts[3 * (size_t)p + 2] = Xn[2];
       s_step += ys[0] * ys[0] + ys[1] * ys[1] + ys[2] * ys[2];
       if (!pt_c) s_xn += X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
     }
-    for (int o = o0 + lane; o < o1; o += 64) {
-      const bool head = (o - o0 < 64);
+    for (int o = o0 + sl; o < o1; o += LPP) {
+      const bool head = (o - o0 < LPP);
       const int c = head ? f_c : pb.obs_cam[o];
       const int a = d.shared ? 0 : c;
       double r[2], fy[2], E[6];
@@ -1698,6 +1762,7 @@ struct ProfScope {
 
 struct Launch {
   Dims d; DevProblem dp; Ws w; vgg_ba_options opt; hipStream_t st; int wgB;
+  int lpp;                                      // lanes per point of the point passes: 16, 32 or 64 (lanes_per_point)
   const int32_t* chunk_desc; const int32_t* entries; int num_chunks, num_segments;
   const int32_t* block_chunk;                   // launch position -> chunk (XCD placement) or NULL
   int super_tiles; const int32_t* quad_mask;    // 2 x 2 super-tiles (vgg_ba_problem.super_tiles)
@@ -1824,12 +1889,20 @@ static void phase_schur(const Launch& L) {
     ProfScope ps(kProfPointPass, L.st);
     // cameras (q, t, pose scales, constant flags: 14 doubles each) cached in LDS when they fit beside 2 workgroups/CU
     const size_t cam_lds = sizeof(double) * 14 * (size_t)d.C;
-    if (L.dp.obs_pt && !g_fused_point_pass) {
-      if (cam_lds <= 48 * 1024) point_pass_kernel<KD, true, false><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w, L.opt);
-      else point_pass_kernel<KD, false, false><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w, L.opt);
+    if (L.dp.obs_pt && !g_fused_point_pass && L.lpp == 64) {
+      if (cam_lds <= 48 * 1024) point_pass_kernel<KD, true, false, 64><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w, L.opt);
+      else point_pass_kernel<KD, false, false, 64><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w, L.opt);
       y_write_kernel<KD><<<min(div_up(L.d.O, 256), 256 * 16), 256, 0, L.st>>>(L.dp, L.w);
-    } else if (cam_lds <= 48 * 1024) point_pass_kernel<KD, true, true><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w, L.opt);
-    else point_pass_kernel<KD, false, true><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w, L.opt);
+    } else {
+      auto launch = [&](auto lpp) {
+        constexpr int LPP = decltype(lpp)::value;
+        if (cam_lds <= 48 * 1024) point_pass_kernel<KD, true, true, LPP><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w, L.opt);
+        else point_pass_kernel<KD, false, true, LPP><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w, L.opt);
+      };
+      if (L.lpp == 16) launch(std::integral_constant<int, 16>{});
+      else if (L.lpp == 32) launch(std::integral_constant<int, 32>{});
+      else launch(std::integral_constant<int, 64>{});
+    }
   }
   reduce_gmax_kernel<<<1, 256, 0, L.st>>>(L.w, L.wgB);
   {
@@ -1886,8 +1959,14 @@ static int phase_step(const Launch& L) {
   {
     ProfScope ps(kProfPointStep, L.st);
     const size_t cam_lds = sizeof(double) * 21 * (size_t)d.C;
-    if (cam_lds <= 64 * 1024) point_step_kernel<KD, true><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w);
-    else point_step_kernel<KD, false><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w);
+    auto launch = [&](auto lpp) {
+      constexpr int LPP = decltype(lpp)::value;
+      if (cam_lds <= 64 * 1024) point_step_kernel<KD, true, LPP><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w);
+      else point_step_kernel<KD, false, LPP><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w);
+    };
+    if (L.lpp == 16) launch(std::integral_constant<int, 16>{});
+    else if (L.lpp == 32) launch(std::integral_constant<int, 32>{});
+    else launch(std::integral_constant<int, 64>{});
   }
   reduce_step_kernel<<<1, 256, 0, L.st>>>(L.w, L.wgB);
   return VGG_OK;
@@ -1913,7 +1992,8 @@ static int make_launch(const vgg_ba_problem* pb, const vgg_ba_options* opt, void
   L->w = carve(L->d, opt->max_num_iterations, pb->num_chunks, pb->num_segments, workspace, pb->super_tiles);
   L->opt = *opt;
   L->st = st;
-  L->wgB = min(max(div_up(L->d.P, 4), 1), kMaxWG);
+  L->lpp = lanes_per_point(L->d.P, L->d.O);
+  L->wgB = min(max(div_up(L->d.P, 4 * (64 / L->lpp)), 1), kMaxWG);
   L->chunk_desc = pb->chunk_desc; L->entries = pb->entries; L->num_chunks = pb->num_chunks;
   L->block_chunk = pb->block_chunk;
   L->super_tiles = pb->super_tiles; L->quad_mask = pb->quad_mask;

@@ -33,6 +33,13 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
+// sum over the aligned group of W lanes (W = 16, 32, 64) this lane belongs to; every lane of the group gets the total
+template <int W>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+  for (int off = W / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));

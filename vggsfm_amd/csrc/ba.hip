@@ -484,13 +484,15 @@ __global__ void damping_kernel(Ws w, vgg_ba_options opt, int n_red) {
 // in round 2 (c3): 0.25 + 0.47 ms against 0.43 ms for the fused pass -- the reductions did not speed up with the third
 // wavefront and a thread-per-observation writer without the LDS camera table is slower than the in-wave sweep -- so
 // the fused pass stays the default.
-// Lanes per point of the point passes from the mean track length (VGG_LPP=16|32|64 overrides): a point's lanes share
-// its serial work, so the narrowest group that still holds most tracks in one sweep wins.
+// Lanes per point of the point passes from the mean track length (VGG_LPP=8|16|32|64 overrides).  A point's lanes share
+// its serial work (reductions, 3 x 3 factorisation), which outweighs the sweeps over its observations up to ~70 of them:
+// measured per LM iteration, point_pass + point_step -- c2 (mean 12.5 observations) 64: 0.112, 32: 0.075, 16: 0.065,
+// 8: 0.059 ms; c3 (mean 50) 64: 0.674, 32: 0.549, 16: 0.499, 8: 0.535 ms; one c4 shard (mean 100) 32: 0.509, 16: 0.544 ms.
 static int lanes_per_point(int P, int O) {
   static const int forced = [] { const char* e = getenv("VGG_LPP"); return e ? atoi(e) : 0; }();
-  if (forced == 16 || forced == 32 || forced == 64) return forced;
+  if (forced == 8 || forced == 16 || forced == 32 || forced == 64) return forced;
   const double mean = P > 0 ? (double)O / P : 64.0;
-  return mean <= 14.0 ? 16 : (mean <= 56.0 ? 32 : 64);   // (c2, mean 12.5: 16 beats 64 by 0.045 ms; c3, mean 50: 32 beats 64 by 0.075 ms)
+  return mean <= 72.0 ? 16 : 32;
 }
 static const bool g_fused_point_pass = [] { const char* e = getenv("VGG_SPLIT_POINT_PASS"); return !(e && e[0] == '1'); }();
 
@@ -534,7 +536,8 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
   // software pipeline over the points of this wavefront: the row bounds / coordinates of the NEXT point and the
   // camera index, pixel and slot of its first 64 observations are loaded while the current point is processed
   int p = (blockIdx.x * 4 + wave) * PPW + sub;   // (the lanes of one point run the same control flow: per-lane loops below)
-  int n_o0 = 0, n_o1 = 0, n_c = 0, n_slot = 0;
+  int n_o0 = 0, n_o1 = 0, n_c = 0, n_slot = 0, n_c2 = 0, n_slot2 = 0;   // (.2: the lane's SECOND observation, tracks > LPP)
+  float2 n_uv2 = make_float2(0.f, 0.f);
   double n_X0 = 0, n_X1 = 0, n_X2 = 0;
   float2 n_uv = make_float2(0.f, 0.f);
   bool n_ptc = false;
@@ -548,6 +551,7 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
     n_X0 = pb.pts[3 * p]; n_X1 = pb.pts[3 * p + 1]; n_X2 = pb.pts[3 * p + 2];
     n_ptc = pb.pt_const ? pb.pt_const[p] != 0 : false;
     if (n_o0 + sl < n_o1) { n_c = pb.obs_cam[n_o0 + sl]; n_uv = pb.obs_uv[n_o0 + sl]; if (WRITE_Y) n_slot = pb.obs_slot[n_o0 + sl]; }
+    if (n_o0 + LPP + sl < n_o1) { n_c2 = pb.obs_cam[n_o0 + LPP + sl]; n_uv2 = pb.obs_uv[n_o0 + LPP + sl]; if (WRITE_Y) n_slot2 = pb.obs_slot[n_o0 + LPP + sl]; }
     if (p + nw < d.P) {
       const int pm = p + nw;
       m_o0 = pb.row_ptr[pm]; m_o1 = pb.row_ptr[pm + 1];
@@ -559,12 +563,13 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
     const int o0 = n_o0, o1 = n_o1;
     const double X[3] = {n_X0, n_X1, n_X2};
     const bool pt_c = n_ptc;
-    const int f_c = n_c, f_slot = n_slot;
-    const float2 f_uv = n_uv;
+    const int f_c = n_c, f_slot = n_slot, f_c2 = n_c2, f_slot2 = n_slot2;
+    const float2 f_uv = n_uv, f_uv2 = n_uv2;
     {
       // stage 1 -> current of the next iteration: observations of point p + nw (its bounds arrived an iteration ago)
       n_o0 = m_o0; n_o1 = m_o1; n_X0 = m_X0; n_X1 = m_X1; n_X2 = m_X2; n_ptc = m_ptc;
       if (p + nw < d.P && n_o0 + sl < n_o1) { n_c = pb.obs_cam[n_o0 + sl]; n_uv = pb.obs_uv[n_o0 + sl]; if (WRITE_Y) n_slot = pb.obs_slot[n_o0 + sl]; }
+      if (p + nw < d.P && n_o0 + LPP + sl < n_o1) { n_c2 = pb.obs_cam[n_o0 + LPP + sl]; n_uv2 = pb.obs_uv[n_o0 + LPP + sl]; if (WRITE_Y) n_slot2 = pb.obs_slot[n_o0 + LPP + sl]; }
       // stage 2: bounds / coordinates of point p + 2 nw
       const int pm = p + 2 * nw;
       if (pm < d.P) {
@@ -578,9 +583,9 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
     for (int i = 0; i < 3 * (KD ? KD : 1); ++i) Wa[i] = 0;
     double cF[2 * BD], cE[6];          // Jacobians of this lane's first observation (tracks > LPP recompute)
     for (int o = o0 + sl; o < o1; o += LPP) {
-      const bool head = (o - o0 < LPP);
-      const int c = head ? f_c : pb.obs_cam[o];
-      const float2 uv = head ? f_uv : pb.obs_uv[o];
+      const bool head = (o - o0 < LPP), second = !head && (o - o0 < 2 * LPP);
+      const int c = head ? f_c : (second ? f_c2 : pb.obs_cam[o]);
+      const float2 uv = head ? f_uv : (second ? f_uv2 : pb.obs_uv[o]);
       const int a = d.shared ? 0 : c;
       double r[2], F[2 * BD], E[6];
       if (LDSCAM)
@@ -672,8 +677,8 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
     if (WRITE_Y && VGG_PP_ABLATE != 2) {
       const int bdt = d.shared ? 6 : BD;          // rows of the tile block (intrinsics only when per camera)
       for (int o = o0 + sl; o < o1; o += LPP) {
-        const bool head = (o - o0 < LPP);
-        const int c = head ? f_c : pb.obs_cam[o];
+        const bool head = (o - o0 < LPP), second = !head && (o - o0 < 2 * LPP);
+        const int c = head ? f_c : (second ? f_c2 : pb.obs_cam[o]);
         double F[2 * BD], E[6];
         if (head) {                               // cached Jacobians of the first slice
 #pragma unroll
@@ -683,11 +688,16 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
         } else {
           const int a = d.shared ? 0 : c;
           double r[2];
-          eval_full<KD>(d, pb.cam_q + 4 * c, pb.cam_t + 3 * c, pb.intr + 4 * a, X, pb.obs_uv[o],
-                        pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
+          const float2 uv = second ? f_uv2 : pb.obs_uv[o];
+          if (LDSCAM)
+            eval_full<KD>(d, lq + 4 * c, lt + 3 * c, pb.intr + 4 * a, X, uv, (unsigned)lfl[c],
+                          pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
+          else
+            eval_full<KD>(d, pb.cam_q + 4 * c, pb.cam_t + 3 * c, pb.intr + 4 * a, X, uv,
+                          pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
         }
         // segment layout: [component 0..2][slot 0..15][row 0..bdt-1]  (three rows of the K dimension)
-        const int slot = head ? f_slot : pb.obs_slot[o], rt = kGroup * bdt;
+        const int slot = head ? f_slot : (second ? f_slot2 : pb.obs_slot[o]), rt = kGroup * bdt;
         double* y = w.Y + (size_t)(slot >> 4) * (3 * rt) + (slot & 15) * bdt;
 #pragma unroll
         for (int i = 0; i < BD; ++i) {
@@ -1539,7 +1549,8 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
   }
   // same software pipeline over the points of a wavefront as in point_pass_kernel
   int p = (blockIdx.x * 4 + wave) * PPW + sub;
-  int n_o0 = 0, n_o1 = 0, n_c = 0;
+  int n_o0 = 0, n_o1 = 0, n_c = 0, n_c2 = 0;
+  float2 n_uv2 = make_float2(0.f, 0.f);
   double n_X0 = 0, n_X1 = 0, n_X2 = 0;
   float2 n_uv = make_float2(0.f, 0.f);
   bool n_ptc = false;
@@ -1553,6 +1564,7 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
     n_X0 = pb.pts[3 * p]; n_X1 = pb.pts[3 * p + 1]; n_X2 = pb.pts[3 * p + 2];
     n_ptc = pb.pt_const ? pb.pt_const[p] != 0 : false;
     if (n_o0 + sl < n_o1) { n_c = pb.obs_cam[n_o0 + sl]; n_uv = pb.obs_uv[n_o0 + sl]; }
+    if (n_o0 + LPP + sl < n_o1) { n_c2 = pb.obs_cam[n_o0 + LPP + sl]; n_uv2 = pb.obs_uv[n_o0 + LPP + sl]; }
     if (p + nw < d.P) {
       const int pm = p + nw;
       m_o0 = pb.row_ptr[pm]; m_o1 = pb.row_ptr[pm + 1];
@@ -1564,12 +1576,13 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
     const int o0 = n_o0, o1 = n_o1;
     const double X[3] = {n_X0, n_X1, n_X2};
     const bool pt_c = n_ptc;
-    const int f_c = n_c;
-    const float2 f_uv = n_uv;
+    const int f_c = n_c, f_c2 = n_c2;
+    const float2 f_uv = n_uv, f_uv2 = n_uv2;
     {
       // stage 1 -> current of the next iteration: observations of point p + nw (its bounds arrived an iteration ago)
       n_o0 = m_o0; n_o1 = m_o1; n_X0 = m_X0; n_X1 = m_X1; n_X2 = m_X2; n_ptc = m_ptc;
       if (p + nw < d.P && n_o0 + sl < n_o1) { n_c = pb.obs_cam[n_o0 + sl]; n_uv = pb.obs_uv[n_o0 + sl]; }
+      if (p + nw < d.P && n_o0 + LPP + sl < n_o1) { n_c2 = pb.obs_cam[n_o0 + LPP + sl]; n_uv2 = pb.obs_uv[n_o0 + LPP + sl]; }
       // stage 2: bounds / coordinates of point p + 2 nw
       const int pm = p + 2 * nw;
       if (pm < d.P) {
@@ -1582,9 +1595,9 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
     // cached values of this lane's first observation (tracks longer than LPP recompute)
     double c_r[2] = {0, 0}, c_fy[2] = {0, 0}, c_E[6] = {0, 0, 0, 0, 0, 0};
     for (int o = o0 + sl; o < o1; o += LPP) {
-      const bool head = (o - o0 < LPP);
-      const int c = head ? f_c : pb.obs_cam[o];
-      const float2 uv = head ? f_uv : pb.obs_uv[o];
+      const bool head = (o - o0 < LPP), second = !head && (o - o0 < 2 * LPP);
+      const int c = head ? f_c : (second ? f_c2 : pb.obs_cam[o]);
+      const float2 uv = head ? f_uv : (second ? f_uv2 : pb.obs_uv[o]);
       const int a = d.shared ? 0 : c;
       double r[2], F[2 * BD], E[6];
       if (LDSCAM)
@@ -1622,9 +1635,10 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
       if (!pt_c) s_xn += X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
     }
     for (int o = o0 + sl; o < o1; o += LPP) {
-      const bool head = (o - o0 < LPP);
-      const int c = head ? f_c : pb.obs_cam[o];
+      const bool head = (o - o0 < LPP), second = !head && (o - o0 < 2 * LPP);
+      const int c = head ? f_c : (second ? f_c2 : pb.obs_cam[o]);
       const int a = d.shared ? 0 : c;
+      const float2 uv = head ? f_uv : (second ? f_uv2 : pb.obs_uv[o]);
       double r[2], fy[2], E[6];
       if (head) {
         r[0] = c_r[0]; r[1] = c_r[1]; fy[0] = c_fy[0]; fy[1] = c_fy[1];
@@ -1632,11 +1646,15 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
         for (int k = 0; k < 6; ++k) E[k] = c_E[k];
       } else {
         double F[2 * BD];
-        eval_full<KD>(d, pb.cam_q + 4 * c, pb.cam_t + 3 * c, pb.intr + 4 * a, X, pb.obs_uv[o],
-                      pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
+        if (LDSCAM)
+          eval_full<KD>(d, lq + 4 * c, lt + 3 * c, pb.intr + 4 * a, X, uv, (unsigned)lfl[c],
+                        pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
+        else
+          eval_full<KD>(d, pb.cam_q + 4 * c, pb.cam_t + 3 * c, pb.intr + 4 * a, X, uv,
+                        pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
         fy[0] = 0; fy[1] = 0;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { const double v = w.dy[6 * c + k]; fy[0] += F[k] * v; fy[1] += F[BD + k] * v; }
+        for (int k = 0; k < 6; ++k) { const double v = LDSCAM ? ldy[6 * c + k] : w.dy[6 * c + k]; fy[0] += F[k] * v; fy[1] += F[BD + k] * v; }
 #pragma unroll
         for (int k = 0; k < KD; ++k) { const double v = w.dy[6 * d.C + KD * a + k]; fy[0] += F[6 + k] * v; fy[1] += F[BD + 6 + k] * v; }
       }
@@ -1645,7 +1663,6 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
       const double m1 = -(fy[1] + E[3] * ys[0] + E[4] * ys[1] + E[5] * ys[2]);
       s_mcc += -(m0 * (r[0] + m0 / 2.0) + m1 * (r[1] + m1 / 2.0));
       double rc[2];
-      const float2 uv = head ? f_uv : pb.obs_uv[o];
       if (LDSCAM) obs_residual(d.model, lcq + 4 * c, lct + 3 * c, w.cand_intr + 4 * a, Xn, (double)uv.x, (double)uv.y, rc);
       else obs_residual(d.model, w.cand_q + 4 * c, w.cand_t + 3 * c, w.cand_intr + 4 * a, Xn, (double)uv.x, (double)uv.y, rc);
       s_cost += loss_rho0(d, rc[0] * rc[0] + rc[1] * rc[1]);
@@ -1899,7 +1916,8 @@ static void phase_schur(const Launch& L) {
         if (cam_lds <= 48 * 1024) point_pass_kernel<KD, true, true, LPP><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w, L.opt);
         else point_pass_kernel<KD, false, true, LPP><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w, L.opt);
       };
-      if (L.lpp == 16) launch(std::integral_constant<int, 16>{});
+      if (L.lpp == 8) launch(std::integral_constant<int, 8>{});
+      else if (L.lpp == 16) launch(std::integral_constant<int, 16>{});
       else if (L.lpp == 32) launch(std::integral_constant<int, 32>{});
       else launch(std::integral_constant<int, 64>{});
     }
@@ -1964,7 +1982,8 @@ static int phase_step(const Launch& L) {
       if (cam_lds <= 64 * 1024) point_step_kernel<KD, true, LPP><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w);
       else point_step_kernel<KD, false, LPP><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w);
     };
-    if (L.lpp == 16) launch(std::integral_constant<int, 16>{});
+    if (L.lpp == 8) launch(std::integral_constant<int, 8>{});
+    else if (L.lpp == 16) launch(std::integral_constant<int, 16>{});
     else if (L.lpp == 32) launch(std::integral_constant<int, 32>{});
     else launch(std::integral_constant<int, 64>{});
   }

@@ -179,14 +179,28 @@ static DevProblem dev_problem(const vgg_ba_problem* pb, const Dims& d) {
 
 // ---------------------------------------------------------------------------------------------
 // One observation: corrected residual and corrected, constant-masked, UNSCALED Jacobians.
-//   F[2][6+KD]  (pose tangent 6, refined intrinsics KD), E[2][3] (point)
+//   F[2][6+KD]  (pose tangent 6, refined intrinsics KD), E[2][3] (point); Rm = rotation matrix of the camera (row-major)
+// value k of a lane's prefetched observations (k < N, selected with compile-time indices) or the load it stands for
+template <int N, typename T>
+__device__ __forceinline__ T pick_pf(const T (&pf)[N], int k, const T* src, int o) {
+  T v = pf[0];
+#pragma unroll
+  for (int j = 1; j < N; ++j) v = (k == j) ? pf[j] : v;
+  return (k < N) ? v : src[o];
+}
+
+struct CamR {                                    // rotation matrix of a quaternion in global memory (paths without the LDS cache)
+  double R[9];
+  __device__ __forceinline__ explicit CamR(const double* q) { quat_to_R(q, R); }
+};
+
 template <int KD>
-__device__ __forceinline__ double eval_full(const Dims& d, const double* q, const double* t, const double* in4,
+__device__ __forceinline__ double eval_full(const Dims& d, const double* Rm, const double* t, const double* in4,
                                             const double* X, float2 uv, unsigned camflag, bool intr_c, bool pt_c,
                                             double* r, double* F, double* E) {
   constexpr int BD = 6 + KD;
   double Jp[12], Ji[4];
-  obs_eval(d.model, q, t, in4, X, (double)uv.x, (double)uv.y, r, Jp, Ji, E);
+  obs_eval_R(d.model, Rm, t, in4, X, (double)uv.x, (double)uv.y, r, Jp, Ji, E);
 #pragma unroll
   for (int row = 0; row < 2; ++row) {
 #pragma unroll
@@ -286,9 +300,8 @@ __global__ __launch_bounds__(256, VGG_CP_OCC) void cam_pass_kernel(DevProblem pb
   // workgroup per camera left 200 workgroups = 0.8 wavefronts per SIMD on the chip); cam_reduce_kernel adds the
   // slices in a fixed order
   const int c = blockIdx.x, split = gridDim.y;
-  double q[4], t[3], in4[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) q[k] = pb.cam_q[4 * c + k];
+  double q[9], t[3], in4[4];                   // q: the camera's rotation MATRIX
+  quat_to_R(pb.cam_q + 4 * c, q);
 #pragma unroll
   for (int k = 0; k < 3; ++k) t[k] = pb.cam_t[3 * c + k];
   const int a = d.shared ? 0 : c;
@@ -508,7 +521,7 @@ template <int KD, bool LDSCAM, bool WRITE_Y, int LPP>
 __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void point_pass_kernel(DevProblem pb, Ws w, vgg_ba_options opt) {
   constexpr int BD = 6 + KD;
   __shared__ double wmax[4];
-  extern __shared__ double cam_cache[];          // LDSCAM: q[4C] t[3C] pose scales[6C] flags[C] (as doubles)
+  extern __shared__ double cam_cache[];          // LDSCAM: R[9C] t[3C] pose scales[6C] flags[C] (as doubles)
   Ctl* ctl = w.ctl;
   if (ctl->done) return;
   const Dims& d = pb.d;
@@ -522,24 +535,30 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
   double gmax = 0.0;
   // The per-observation camera gather is the second of three dependent memory round trips of a point; with the
   // cameras in LDS it is an LDS read.  (The wavefronts are latency bound: SQ_WAIT_ANY 60 %, 2 waves/SIMD.)
-  const double* lq = cam_cache;
-  const double* lt = lq + 4 * d.C;
+  const double* lq = cam_cache;                  // rotation matrices [9C]
+  const double* lt = lq + 9 * d.C;
   const double* lsc = lt + 3 * d.C;
   const double* lfl = lsc + 6 * d.C;
   if (LDSCAM) {
-    for (int i = threadIdx.x; i < 4 * d.C; i += 256) cam_cache[i] = pb.cam_q[i];
-    for (int i = threadIdx.x; i < 3 * d.C; i += 256) cam_cache[4 * d.C + i] = pb.cam_t[i];
-    for (int i = threadIdx.x; i < 6 * d.C; i += 256) cam_cache[7 * d.C + i] = w.scale_c[i];
-    for (int i = threadIdx.x; i < d.C; i += 256) cam_cache[13 * d.C + i] = pb.cam_const ? (double)pb.cam_const[i] : 0.0;
+    for (int i = threadIdx.x; i < d.C; i += 256) {
+      quat_to_R(pb.cam_q + 4 * i, cam_cache + 9 * i);
+      cam_cache[18 * d.C + i] = pb.cam_const ? (double)pb.cam_const[i] : 0.0;
+    }
+    for (int i = threadIdx.x; i < 3 * d.C; i += 256) cam_cache[9 * d.C + i] = pb.cam_t[i];
+    for (int i = threadIdx.x; i < 6 * d.C; i += 256) cam_cache[12 * d.C + i] = w.scale_c[i];
     __syncthreads();
   }
   // software pipeline over the points of this wavefront: the row bounds / coordinates of the NEXT point and the
   // camera index, pixel and slot of its first 64 observations are loaded while the current point is processed
   int p = (blockIdx.x * 4 + wave) * PPW + sub;   // (the lanes of one point run the same control flow: per-lane loops below)
-  int n_o0 = 0, n_o1 = 0, n_c = 0, n_slot = 0, n_c2 = 0, n_slot2 = 0;   // (.2: the lane's SECOND observation, tracks > LPP)
-  float2 n_uv2 = make_float2(0.f, 0.f);
+  // (camera, pixel, slot) of the lane's first NPF observations (o0 + sl + k LPP) are prefetched with the point; later
+  // ones are loaded where they are used
+  constexpr int NPF = 2;                         // (4 at 16 lanes per point: scratch, no gain)
+  int n_o0 = 0, n_o1 = 0, n_cs[NPF], n_slots[NPF];
+  float2 n_uvs[NPF];
+#pragma unroll
+  for (int k = 0; k < NPF; ++k) { n_cs[k] = 0; n_slots[k] = 0; n_uvs[k] = make_float2(0.f, 0.f); }
   double n_X0 = 0, n_X1 = 0, n_X2 = 0;
-  float2 n_uv = make_float2(0.f, 0.f);
   bool n_ptc = false;
   // (two stages: the row bounds / coordinates are loaded TWO points ahead, the observations ONE point ahead, so
   //  that the observation loads never wait for the row-bound load they depend on)
@@ -550,8 +569,9 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
     n_o0 = pb.row_ptr[p]; n_o1 = pb.row_ptr[p + 1];
     n_X0 = pb.pts[3 * p]; n_X1 = pb.pts[3 * p + 1]; n_X2 = pb.pts[3 * p + 2];
     n_ptc = pb.pt_const ? pb.pt_const[p] != 0 : false;
-    if (n_o0 + sl < n_o1) { n_c = pb.obs_cam[n_o0 + sl]; n_uv = pb.obs_uv[n_o0 + sl]; if (WRITE_Y) n_slot = pb.obs_slot[n_o0 + sl]; }
-    if (n_o0 + LPP + sl < n_o1) { n_c2 = pb.obs_cam[n_o0 + LPP + sl]; n_uv2 = pb.obs_uv[n_o0 + LPP + sl]; if (WRITE_Y) n_slot2 = pb.obs_slot[n_o0 + LPP + sl]; }
+#pragma unroll
+    for (int k = 0; k < NPF; ++k)
+      if (n_o0 + k * LPP + sl < n_o1) { const int oo = n_o0 + k * LPP + sl; n_cs[k] = pb.obs_cam[oo]; n_uvs[k] = pb.obs_uv[oo]; if (WRITE_Y) n_slots[k] = pb.obs_slot[oo]; }
     if (p + nw < d.P) {
       const int pm = p + nw;
       m_o0 = pb.row_ptr[pm]; m_o1 = pb.row_ptr[pm + 1];
@@ -563,13 +583,18 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
     const int o0 = n_o0, o1 = n_o1;
     const double X[3] = {n_X0, n_X1, n_X2};
     const bool pt_c = n_ptc;
-    const int f_c = n_c, f_slot = n_slot, f_c2 = n_c2, f_slot2 = n_slot2;
-    const float2 f_uv = n_uv, f_uv2 = n_uv2;
+    int f_cs[NPF], f_slots[NPF];
+    float2 f_uvs[NPF];
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) { f_cs[k] = n_cs[k]; f_slots[k] = n_slots[k]; f_uvs[k] = n_uvs[k]; }
     {
       // stage 1 -> current of the next iteration: observations of point p + nw (its bounds arrived an iteration ago)
       n_o0 = m_o0; n_o1 = m_o1; n_X0 = m_X0; n_X1 = m_X1; n_X2 = m_X2; n_ptc = m_ptc;
-      if (p + nw < d.P && n_o0 + sl < n_o1) { n_c = pb.obs_cam[n_o0 + sl]; n_uv = pb.obs_uv[n_o0 + sl]; if (WRITE_Y) n_slot = pb.obs_slot[n_o0 + sl]; }
-      if (p + nw < d.P && n_o0 + LPP + sl < n_o1) { n_c2 = pb.obs_cam[n_o0 + LPP + sl]; n_uv2 = pb.obs_uv[n_o0 + LPP + sl]; if (WRITE_Y) n_slot2 = pb.obs_slot[n_o0 + LPP + sl]; }
+      if (p + nw < d.P) {
+#pragma unroll
+        for (int k = 0; k < NPF; ++k)
+          if (n_o0 + k * LPP + sl < n_o1) { const int oo = n_o0 + k * LPP + sl; n_cs[k] = pb.obs_cam[oo]; n_uvs[k] = pb.obs_uv[oo]; if (WRITE_Y) n_slots[k] = pb.obs_slot[oo]; }
+      }
       // stage 2: bounds / coordinates of point p + 2 nw
       const int pm = p + 2 * nw;
       if (pm < d.P) {
@@ -583,16 +608,16 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
     for (int i = 0; i < 3 * (KD ? KD : 1); ++i) Wa[i] = 0;
     double cF[2 * BD], cE[6];          // Jacobians of this lane's first observation (tracks > LPP recompute)
     for (int o = o0 + sl; o < o1; o += LPP) {
-      const bool head = (o - o0 < LPP), second = !head && (o - o0 < 2 * LPP);
-      const int c = head ? f_c : (second ? f_c2 : pb.obs_cam[o]);
-      const float2 uv = head ? f_uv : (second ? f_uv2 : pb.obs_uv[o]);
+      const int pass = (o - o0) / LPP; const bool head = pass == 0;
+      const int c = pick_pf<NPF>(f_cs, pass, pb.obs_cam, o);
+      const float2 uv = pick_pf<NPF>(f_uvs, pass, pb.obs_uv, o);
       const int a = d.shared ? 0 : c;
       double r[2], F[2 * BD], E[6];
       if (LDSCAM)
-        eval_full<KD>(d, lq + 4 * c, lt + 3 * c, pb.intr + 4 * a, X, uv, (unsigned)lfl[c],
+        eval_full<KD>(d, lq + 9 * c, lt + 3 * c, pb.intr + 4 * a, X, uv, (unsigned)lfl[c],
                       pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
       else
-        eval_full<KD>(d, pb.cam_q + 4 * c, pb.cam_t + 3 * c, pb.intr + 4 * a, X, uv,
+        eval_full<KD>(d, CamR(pb.cam_q + 4 * c).R, pb.cam_t + 3 * c, pb.intr + 4 * a, X, uv,
                       pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
       if (WRITE_Y && head) {
 #pragma unroll
@@ -677,8 +702,8 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
     if (WRITE_Y && VGG_PP_ABLATE != 2) {
       const int bdt = d.shared ? 6 : BD;          // rows of the tile block (intrinsics only when per camera)
       for (int o = o0 + sl; o < o1; o += LPP) {
-        const bool head = (o - o0 < LPP), second = !head && (o - o0 < 2 * LPP);
-        const int c = head ? f_c : (second ? f_c2 : pb.obs_cam[o]);
+        const int pass = (o - o0) / LPP; const bool head = pass == 0;
+        const int c = pick_pf<NPF>(f_cs, pass, pb.obs_cam, o);
         double F[2 * BD], E[6];
         if (head) {                               // cached Jacobians of the first slice
 #pragma unroll
@@ -688,17 +713,22 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
         } else {
           const int a = d.shared ? 0 : c;
           double r[2];
-          const float2 uv = second ? f_uv2 : pb.obs_uv[o];
+          const float2 uv = pick_pf<NPF>(f_uvs, pass, pb.obs_uv, o);
           if (LDSCAM)
-            eval_full<KD>(d, lq + 4 * c, lt + 3 * c, pb.intr + 4 * a, X, uv, (unsigned)lfl[c],
+            eval_full<KD>(d, lq + 9 * c, lt + 3 * c, pb.intr + 4 * a, X, uv, (unsigned)lfl[c],
                           pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
           else
-            eval_full<KD>(d, pb.cam_q + 4 * c, pb.cam_t + 3 * c, pb.intr + 4 * a, X, uv,
+            eval_full<KD>(d, CamR(pb.cam_q + 4 * c).R, pb.cam_t + 3 * c, pb.intr + 4 * a, X, uv,
                           pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
         }
         // segment layout: [component 0..2][slot 0..15][row 0..bdt-1]  (three rows of the K dimension)
-        const int slot = head ? f_slot : (second ? f_slot2 : pb.obs_slot[o]), rt = kGroup * bdt;
+        const int slot = pick_pf<NPF>(f_slots, pass, pb.obs_slot, o), rt = kGroup * bdt;
         double* y = w.Y + (size_t)(slot >> 4) * (3 * rt) + (slot & 15) * bdt;
+        // the lane's three runs of bdt doubles go out 16 bytes at a time when bdt is even (the runs are then 16-byte
+        // aligned): half the store instructions and half the partial-line transactions of 8-byte stores.  Measured at 16
+        // lanes per point: the 720 MB of Y cost 0.13 of the 0.31 ms of this kernel, not overlapped with its arithmetic.
+        const bool pairs = (bdt & 1) == 0;
+        double prev[3] = {0, 0, 0};
 #pragma unroll
         for (int i = 0; i < BD; ++i) {
           if (i < bdt) {
@@ -706,12 +736,16 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
                                       : w.scale_c[6 * d.C + KD * c + (i - 6)];
             const double w0 = F[i] * E[0] + F[BD + i] * E[3], w1 = F[i] * E[1] + F[BD + i] * E[4],
                          w2 = F[i] * E[2] + F[BD + i] * E[5];
+            const double y0 = sc * (w0 * Gm[0]), y1 = sc * (w0 * Gm[1] + w1 * Gm[3]), y2 = sc * (w0 * Gm[2] + w1 * Gm[4] + w2 * Gm[5]);
 #if VGG_PP_ABLATE == 1                            // profiling build: the Y arithmetic without its stores
             if (Gm[0] == 12345.678) {
 #endif
-            y[i] = sc * (w0 * Gm[0]);
-            y[rt + i] = sc * (w0 * Gm[1] + w1 * Gm[3]);
-            y[2 * rt + i] = sc * (w0 * Gm[2] + w1 * Gm[4] + w2 * Gm[5]);
+            if (!pairs) { y[i] = y0; y[rt + i] = y1; y[2 * rt + i] = y2; }
+            else if (i & 1) {
+              *reinterpret_cast<double2*>(y + i - 1) = make_double2(prev[0], y0);
+              *reinterpret_cast<double2*>(y + rt + i - 1) = make_double2(prev[1], y1);
+              *reinterpret_cast<double2*>(y + 2 * rt + i - 1) = make_double2(prev[2], y2);
+            } else { prev[0] = y0; prev[1] = y1; prev[2] = y2; }
 #if VGG_PP_ABLATE == 1
             }
 #endif
@@ -758,7 +792,7 @@ __global__ __launch_bounds__(256, 4) void y_write_kernel(DevProblem pb, Ws w) {
     const double* Gp = w.G + 6 * (size_t)p;
     const double G0 = Gp[0], G1 = Gp[1], G2 = Gp[2], G3 = Gp[3], G4 = Gp[4], G5 = Gp[5];
     double r[2], F[2 * BD], E[6];
-    eval_full<KD>(d, pb.cam_q + 4 * c, pb.cam_t + 3 * c, pb.intr + 4 * a, X, uv, pb.cam_const ? pb.cam_const[c] : 0u,
+    eval_full<KD>(d, CamR(pb.cam_q + 4 * c).R, pb.cam_t + 3 * c, pb.intr + 4 * a, X, uv, pb.cam_const ? pb.cam_const[c] : 0u,
                   pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
     double* y = w.Y + (size_t)(slot >> 4) * (3 * rt) + (slot & 15) * bdt;
 #pragma unroll
@@ -1526,7 +1560,7 @@ template <int KD, bool LDSCAM, int LPP>
 __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem pb, Ws w) {
   constexpr int BD = 6 + KD;
   __shared__ double red[4][4];
-  extern __shared__ double cam_cache[];   // LDSCAM: q[4C] t[3C] dy_pose[6C] cand_q[4C] cand_t[3C] flags[C]
+  extern __shared__ double cam_cache[];   // LDSCAM: R[9C] t[3C] dy_pose[6C] cand R[9C] cand_t[3C] flags[C]
   if (w.ctl->done) return;
   const Dims& d = pb.d;
   constexpr int PPW = 64 / LPP;
@@ -1534,25 +1568,30 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
   const int sub = lane / LPP, sl = lane % LPP;
   const int nw = gridDim.x * 4 * PPW;
   double s_cost = 0, s_mcc = 0, s_step = 0, s_xn = 0;
-  const double* lq = cam_cache;
-  const double* lt = lq + 4 * d.C;
+  const double* lq = cam_cache;                  // rotation matrices [9C]
+  const double* lt = lq + 9 * d.C;
   const double* ldy = lt + 3 * d.C;
-  const double* lcq = ldy + 6 * d.C;
-  const double* lct = lcq + 4 * d.C;
+  const double* lcq = ldy + 6 * d.C;             // rotation matrices of the candidate [9C]
+  const double* lct = lcq + 9 * d.C;
   const double* lfl = lct + 3 * d.C;
   if (LDSCAM) {
-    for (int i = threadIdx.x; i < 4 * d.C; i += 256) { cam_cache[i] = pb.cam_q[i]; cam_cache[13 * d.C + i] = w.cand_q[i]; }
-    for (int i = threadIdx.x; i < 3 * d.C; i += 256) { cam_cache[4 * d.C + i] = pb.cam_t[i]; cam_cache[17 * d.C + i] = w.cand_t[i]; }
-    for (int i = threadIdx.x; i < 6 * d.C; i += 256) cam_cache[7 * d.C + i] = w.dy[i];
-    for (int i = threadIdx.x; i < d.C; i += 256) cam_cache[20 * d.C + i] = pb.cam_const ? (double)pb.cam_const[i] : 0.0;
+    for (int i = threadIdx.x; i < d.C; i += 256) {
+      quat_to_R(pb.cam_q + 4 * i, cam_cache + 9 * i);
+      quat_to_R(w.cand_q + 4 * i, cam_cache + 18 * d.C + 9 * i);
+      cam_cache[30 * d.C + i] = pb.cam_const ? (double)pb.cam_const[i] : 0.0;
+    }
+    for (int i = threadIdx.x; i < 3 * d.C; i += 256) { cam_cache[9 * d.C + i] = pb.cam_t[i]; cam_cache[27 * d.C + i] = w.cand_t[i]; }
+    for (int i = threadIdx.x; i < 6 * d.C; i += 256) cam_cache[12 * d.C + i] = w.dy[i];
     __syncthreads();
   }
   // same software pipeline over the points of a wavefront as in point_pass_kernel
   int p = (blockIdx.x * 4 + wave) * PPW + sub;
-  int n_o0 = 0, n_o1 = 0, n_c = 0, n_c2 = 0;
-  float2 n_uv2 = make_float2(0.f, 0.f);
+  constexpr int NPF = 2;                         // prefetched observations per lane (see point_pass_kernel)
+  int n_o0 = 0, n_o1 = 0, n_cs[NPF];
+  float2 n_uvs[NPF];
+#pragma unroll
+  for (int k = 0; k < NPF; ++k) { n_cs[k] = 0; n_uvs[k] = make_float2(0.f, 0.f); }
   double n_X0 = 0, n_X1 = 0, n_X2 = 0;
-  float2 n_uv = make_float2(0.f, 0.f);
   bool n_ptc = false;
   // (two stages: the row bounds / coordinates are loaded TWO points ahead, the observations ONE point ahead, so
   //  that the observation loads never wait for the row-bound load they depend on)
@@ -1563,8 +1602,9 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
     n_o0 = pb.row_ptr[p]; n_o1 = pb.row_ptr[p + 1];
     n_X0 = pb.pts[3 * p]; n_X1 = pb.pts[3 * p + 1]; n_X2 = pb.pts[3 * p + 2];
     n_ptc = pb.pt_const ? pb.pt_const[p] != 0 : false;
-    if (n_o0 + sl < n_o1) { n_c = pb.obs_cam[n_o0 + sl]; n_uv = pb.obs_uv[n_o0 + sl]; }
-    if (n_o0 + LPP + sl < n_o1) { n_c2 = pb.obs_cam[n_o0 + LPP + sl]; n_uv2 = pb.obs_uv[n_o0 + LPP + sl]; }
+#pragma unroll
+    for (int k = 0; k < NPF; ++k)
+      if (n_o0 + k * LPP + sl < n_o1) { const int oo = n_o0 + k * LPP + sl; n_cs[k] = pb.obs_cam[oo]; n_uvs[k] = pb.obs_uv[oo]; }
     if (p + nw < d.P) {
       const int pm = p + nw;
       m_o0 = pb.row_ptr[pm]; m_o1 = pb.row_ptr[pm + 1];
@@ -1576,13 +1616,18 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
     const int o0 = n_o0, o1 = n_o1;
     const double X[3] = {n_X0, n_X1, n_X2};
     const bool pt_c = n_ptc;
-    const int f_c = n_c, f_c2 = n_c2;
-    const float2 f_uv = n_uv, f_uv2 = n_uv2;
+    int f_cs[NPF];
+    float2 f_uvs[NPF];
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) { f_cs[k] = n_cs[k]; f_uvs[k] = n_uvs[k]; }
     {
       // stage 1 -> current of the next iteration: observations of point p + nw (its bounds arrived an iteration ago)
       n_o0 = m_o0; n_o1 = m_o1; n_X0 = m_X0; n_X1 = m_X1; n_X2 = m_X2; n_ptc = m_ptc;
-      if (p + nw < d.P && n_o0 + sl < n_o1) { n_c = pb.obs_cam[n_o0 + sl]; n_uv = pb.obs_uv[n_o0 + sl]; }
-      if (p + nw < d.P && n_o0 + LPP + sl < n_o1) { n_c2 = pb.obs_cam[n_o0 + LPP + sl]; n_uv2 = pb.obs_uv[n_o0 + LPP + sl]; }
+      if (p + nw < d.P) {
+#pragma unroll
+        for (int k = 0; k < NPF; ++k)
+          if (n_o0 + k * LPP + sl < n_o1) { const int oo = n_o0 + k * LPP + sl; n_cs[k] = pb.obs_cam[oo]; n_uvs[k] = pb.obs_uv[oo]; }
+      }
       // stage 2: bounds / coordinates of point p + 2 nw
       const int pm = p + 2 * nw;
       if (pm < d.P) {
@@ -1595,16 +1640,16 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
     // cached values of this lane's first observation (tracks longer than LPP recompute)
     double c_r[2] = {0, 0}, c_fy[2] = {0, 0}, c_E[6] = {0, 0, 0, 0, 0, 0};
     for (int o = o0 + sl; o < o1; o += LPP) {
-      const bool head = (o - o0 < LPP), second = !head && (o - o0 < 2 * LPP);
-      const int c = head ? f_c : (second ? f_c2 : pb.obs_cam[o]);
-      const float2 uv = head ? f_uv : (second ? f_uv2 : pb.obs_uv[o]);
+      const int pass = (o - o0) / LPP; const bool head = pass == 0;
+      const int c = pick_pf<NPF>(f_cs, pass, pb.obs_cam, o);
+      const float2 uv = pick_pf<NPF>(f_uvs, pass, pb.obs_uv, o);
       const int a = d.shared ? 0 : c;
       double r[2], F[2 * BD], E[6];
       if (LDSCAM)
-        eval_full<KD>(d, lq + 4 * c, lt + 3 * c, pb.intr + 4 * a, X, uv, (unsigned)lfl[c],
+        eval_full<KD>(d, lq + 9 * c, lt + 3 * c, pb.intr + 4 * a, X, uv, (unsigned)lfl[c],
                       pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
       else
-        eval_full<KD>(d, pb.cam_q + 4 * c, pb.cam_t + 3 * c, pb.intr + 4 * a, X, uv,
+        eval_full<KD>(d, CamR(pb.cam_q + 4 * c).R, pb.cam_t + 3 * c, pb.intr + 4 * a, X, uv,
                       pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
       double fy0 = 0, fy1 = 0;
 #pragma unroll
@@ -1635,10 +1680,10 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
       if (!pt_c) s_xn += X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
     }
     for (int o = o0 + sl; o < o1; o += LPP) {
-      const bool head = (o - o0 < LPP), second = !head && (o - o0 < 2 * LPP);
-      const int c = head ? f_c : (second ? f_c2 : pb.obs_cam[o]);
+      const int pass = (o - o0) / LPP; const bool head = pass == 0;
+      const int c = pick_pf<NPF>(f_cs, pass, pb.obs_cam, o);
       const int a = d.shared ? 0 : c;
-      const float2 uv = head ? f_uv : (second ? f_uv2 : pb.obs_uv[o]);
+      const float2 uv = pick_pf<NPF>(f_uvs, pass, pb.obs_uv, o);
       double r[2], fy[2], E[6];
       if (head) {
         r[0] = c_r[0]; r[1] = c_r[1]; fy[0] = c_fy[0]; fy[1] = c_fy[1];
@@ -1647,10 +1692,10 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
       } else {
         double F[2 * BD];
         if (LDSCAM)
-          eval_full<KD>(d, lq + 4 * c, lt + 3 * c, pb.intr + 4 * a, X, uv, (unsigned)lfl[c],
+          eval_full<KD>(d, lq + 9 * c, lt + 3 * c, pb.intr + 4 * a, X, uv, (unsigned)lfl[c],
                         pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
         else
-          eval_full<KD>(d, pb.cam_q + 4 * c, pb.cam_t + 3 * c, pb.intr + 4 * a, X, uv,
+          eval_full<KD>(d, CamR(pb.cam_q + 4 * c).R, pb.cam_t + 3 * c, pb.intr + 4 * a, X, uv,
                         pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
         fy[0] = 0; fy[1] = 0;
 #pragma unroll
@@ -1663,8 +1708,8 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
       const double m1 = -(fy[1] + E[3] * ys[0] + E[4] * ys[1] + E[5] * ys[2]);
       s_mcc += -(m0 * (r[0] + m0 / 2.0) + m1 * (r[1] + m1 / 2.0));
       double rc[2];
-      if (LDSCAM) obs_residual(d.model, lcq + 4 * c, lct + 3 * c, w.cand_intr + 4 * a, Xn, (double)uv.x, (double)uv.y, rc);
-      else obs_residual(d.model, w.cand_q + 4 * c, w.cand_t + 3 * c, w.cand_intr + 4 * a, Xn, (double)uv.x, (double)uv.y, rc);
+      if (LDSCAM) obs_residual_R(d.model, lcq + 9 * c, lct + 3 * c, w.cand_intr + 4 * a, Xn, (double)uv.x, (double)uv.y, rc);
+      else obs_residual_R(d.model, CamR(w.cand_q + 4 * c).R, w.cand_t + 3 * c, w.cand_intr + 4 * a, Xn, (double)uv.x, (double)uv.y, rc);
       s_cost += loss_rho0(d, rc[0] * rc[0] + rc[1] * rc[1]);
     }
   }
@@ -1905,15 +1950,15 @@ static void phase_schur(const Launch& L) {
   {
     ProfScope ps(kProfPointPass, L.st);
     // cameras (q, t, pose scales, constant flags: 14 doubles each) cached in LDS when they fit beside 2 workgroups/CU
-    const size_t cam_lds = sizeof(double) * 14 * (size_t)d.C;
+    const size_t cam_lds = sizeof(double) * 19 * (size_t)d.C;
     if (L.dp.obs_pt && !g_fused_point_pass && L.lpp == 64) {
-      if (cam_lds <= 48 * 1024) point_pass_kernel<KD, true, false, 64><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w, L.opt);
+      if (cam_lds <= 64 * 1024) point_pass_kernel<KD, true, false, 64><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w, L.opt);
       else point_pass_kernel<KD, false, false, 64><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w, L.opt);
       y_write_kernel<KD><<<min(div_up(L.d.O, 256), 256 * 16), 256, 0, L.st>>>(L.dp, L.w);
     } else {
       auto launch = [&](auto lpp) {
         constexpr int LPP = decltype(lpp)::value;
-        if (cam_lds <= 48 * 1024) point_pass_kernel<KD, true, true, LPP><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w, L.opt);
+        if (cam_lds <= 64 * 1024) point_pass_kernel<KD, true, true, LPP><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w, L.opt);
         else point_pass_kernel<KD, false, true, LPP><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w, L.opt);
       };
       if (L.lpp == 8) launch(std::integral_constant<int, 8>{});
@@ -1976,7 +2021,7 @@ static int phase_step(const Launch& L) {
   cam_update_kernel<KD><<<div_up(d.C + 1, 64), 64, 0, L.st>>>(L.dp, L.w);
   {
     ProfScope ps(kProfPointStep, L.st);
-    const size_t cam_lds = sizeof(double) * 21 * (size_t)d.C;
+    const size_t cam_lds = sizeof(double) * 31 * (size_t)d.C;
     auto launch = [&](auto lpp) {
       constexpr int LPP = decltype(lpp)::value;
       if (cam_lds <= 64 * 1024) point_step_kernel<KD, true, LPP><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w);

@@ -98,6 +98,55 @@ __device__ __forceinline__ void obs_eval(int model, const double* q, const doubl
   Ji[2] = v * d; Ji[3] = f * r2 * v;
 }
 
+// The same two with the rotation given as a matrix (row-major R[9], a = R X): the BA kernels keep R per camera (9 FMAs
+// instead of the 18-instruction quaternion sandwich + quat_to_R per observation).
+__device__ __forceinline__ void obs_residual_R(int model, const double* R, const double* t, const double* intr,
+                                               const double* X, double u_obs, double v_obs, double* r) {
+  const double Y0 = (R[0] * X[0] + R[1] * X[1] + R[2] * X[2]) + t[0];
+  const double Y1 = (R[3] * X[0] + R[4] * X[1] + R[5] * X[2]) + t[1];
+  const double Y2 = (R[6] * X[0] + R[7] * X[1] + R[8] * X[2]) + t[2];
+  const double k = (model == kSimpleRadial) ? intr[3] : 0.0;
+  const double iz = 1.0 / Y2;
+  const double u = Y0 * iz, v = Y1 * iz;
+  const double d = 1.0 + k * (u * u + v * v);
+  r[0] = intr[0] * (u * d) + intr[1] - u_obs;
+  r[1] = intr[0] * (v * d) + intr[2] - v_obs;
+}
+
+__device__ __forceinline__ void obs_eval_R(int model, const double* R, const double* t, const double* intr,
+                                           const double* X, double u_obs, double v_obs, double* r, double* Jp,
+                                           double* Ji, double* Jx) {
+  double a[3];
+  a[0] = R[0] * X[0] + R[1] * X[1] + R[2] * X[2];
+  a[1] = R[3] * X[0] + R[4] * X[1] + R[5] * X[2];
+  a[2] = R[6] * X[0] + R[7] * X[1] + R[8] * X[2];
+  const double Y0 = a[0] + t[0], Y1 = a[1] + t[1], Y2 = a[2] + t[2];
+  const double f = intr[0];
+  const double k = (model == kSimpleRadial) ? intr[3] : 0.0;
+  const double iz = 1.0 / Y2;
+  const double u = Y0 * iz, v = Y1 * iz;
+  const double r2 = u * u + v * v;
+  const double d = 1.0 + k * r2;
+  r[0] = f * (u * d) + intr[1] - u_obs;
+  r[1] = f * (v * d) + intr[2] - v_obs;
+  const double xu = f * (d + 2 * k * u * u), xv = f * (2 * k * u * v), yv = f * (d + 2 * k * v * v);
+  double JY[6];
+  JY[0] = xu * iz; JY[1] = xv * iz; JY[2] = -(xu * u + xv * v) * iz;
+  JY[3] = xv * iz; JY[4] = yv * iz; JY[5] = -(xv * u + yv * v) * iz;
+#pragma unroll
+  for (int row = 0; row < 2; ++row) {
+    const double* j = JY + 3 * row;
+    Jp[row * 6 + 0] = 2.0 * (j[2] * a[1] - j[1] * a[2]);
+    Jp[row * 6 + 1] = 2.0 * (j[0] * a[2] - j[2] * a[0]);
+    Jp[row * 6 + 2] = 2.0 * (j[1] * a[0] - j[0] * a[1]);
+    Jp[row * 6 + 3] = j[0]; Jp[row * 6 + 4] = j[1]; Jp[row * 6 + 5] = j[2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Jx[row * 3 + c] = j[0] * R[c] + j[1] * R[3 + c] + j[2] * R[6 + c];
+  }
+  Ji[0] = u * d; Ji[1] = f * r2 * u;
+  Ji[2] = v * d; Ji[3] = f * r2 * v;
+}
+
 // Ceres LossFunction::Evaluate
 __device__ __forceinline__ void loss_eval(int loss, double a, double s, double* rho) {
   const double b = a * a;

@@ -925,13 +925,15 @@ __global__ __launch_bounds__(256, (BD == 6 ? (DIAG ? 4 : VGG_OFFDIAG_OCC) : 2)) 
   const int32_t* seg_field = entries + 1 + sside;               // entries[e] = (point, segA, segB, masks)
   auto load_seg_index = [&](int eb) -> int { return seg_field[4 * (size_t)min(eb + se, e1 - 1)]; };
   auto seg_valid = [&](int eb) -> bool { return eb + se < e1; };
-  double2 sv[NV];
-  auto issue_loads = [&](int seg_index, bool valid) __attribute__((always_inline)) {
+  // two staging register sets: the loads of batch b + 2 are issued while batch b is multiplied and batch b + 1 (loaded an
+  // iteration earlier) is written to LDS -- twice the bytes in flight per workgroup for NV more double2 registers
+  double2 sv0[NV], sv1[NV];
+  auto issue_loads = [&](double2 (&sv)[NV], int seg_index, bool valid) __attribute__((always_inline)) {
     const double2* src = reinterpret_cast<const double2*>(w.Y) + (size_t)(valid ? seg_index : zero_seg) * V;
 #pragma unroll
     for (int i = 0; i < NV; ++i) { const int off = l32 + TPS * i; sv[i] = (off < V) ? src[off] : make_double2(0.0, 0.0); }
   };
-  auto write_lds = [&](int buf) __attribute__((always_inline)) {
+  auto write_lds = [&](const double2 (&sv)[NV], int buf) __attribute__((always_inline)) {
     double2* dst = reinterpret_cast<double2*>(&Ops[buf][sside][se][0]);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -946,39 +948,37 @@ __global__ __launch_bounds__(256, (BD == 6 ? (DIAG ? 4 : VGG_OFFDIAG_OCC) : 2)) 
 
   // presence of a batch (quad): field 3 of its first entry, wave-uniform (scalar load), fetched one batch ahead
   auto load_quad_mask = [&](int eb) -> uint32_t { return (uint32_t)entries[4 * (size_t)min(eb, e1 - 1) + 3]; };
-  issue_loads(load_seg_index(ebase(0)), seg_valid(ebase(0)));
-  int seg_next = load_seg_index(ebase(1));
-  bool valid_next = seg_valid(ebase(1));
+  issue_loads(sv0, load_seg_index(ebase(0)), seg_valid(ebase(0)));
+  issue_loads(sv1, load_seg_index(ebase(1)), seg_valid(ebase(1)));
+  int seg_next = load_seg_index(ebase(2));
+  bool valid_next = seg_valid(ebase(2));
   uint32_t qmask = load_quad_mask(ebase(0)), qmask_next = load_quad_mask(ebase(1));
-  write_lds(0);
+  write_lds(sv0, 0);
   __syncthreads();
-#if VGG_ABLATE == 2
-  issue_loads(0, false);
-  write_lds(0);
-  __syncthreads();
-#endif
-  // software pipeline shared by the two sub-tile assignments below
+  // software pipeline shared by the two sub-tile assignments below (two batches per trip: the register sets alternate)
   auto sweep = [&](auto&& mfma_batch) __attribute__((always_inline)) {
-    int buf = 0;
-    for (int b = 0; b < nb; ++b, buf ^= 1) {
+    auto step = [&](int b, int buf, double2 (&sv_load)[NV], const double2 (&sv_write)[NV]) __attribute__((always_inline)) {
 #if VGG_ABLATE != 2                               // (profiling builds only: 1 = no MFMA, 2 = no global loads)
-      issue_loads(seg_next, valid_next);          // batch b+1 (the zero segment past the end of the tile's list)
-      seg_next = load_seg_index(ebase(b + 2));
-      valid_next = seg_valid(ebase(b + 2));
+      issue_loads(sv_load, seg_next, valid_next); // batch b+2 (the zero segment past the end of the tile's list)
+      seg_next = load_seg_index(ebase(b + 3));
+      valid_next = seg_valid(ebase(b + 3));
 #endif
 #if VGG_ABLATE != 1
       mfma_batch(buf, qmask);
 #endif
-#if VGG_ABLATE == 4
-      mfma_batch(buf, qmask);
-#endif
       qmask = qmask_next;
       qmask_next = load_quad_mask(ebase(b + 2));
-      write_lds(buf ^ 1);
+      write_lds(sv_write, buf ^ 1);               // batch b+1, in flight since the previous step
 #if VGG_ABLATE != 3
       __syncthreads();
 #endif
+    };
+    int b = 0;
+    for (; b + 1 < nb; b += 2) {
+      step(b, 0, sv0, sv1);
+      step(b + 1, 1, sv1, sv0);
     }
+    if (b < nb) step(b, 0, sv0, sv1);
   };
   // partial tile of this chunk, row-major R x R (f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 reg);
   // tile_reduce_kernel sums the chunks of a tile in a fixed order (deterministic, no atomics)

@@ -1849,16 +1849,20 @@ __global__ __launch_bounds__(256) void pack_lower_kernel(Ws w, int n, int unpack
   }
 }
 
-// workgroups per camera of the camera passes: ~2048 workgroups in total
-static inline int cam_split_for(int C) {
-  const int s = 2048 / (C > 0 ? C : 1);
+// workgroups per camera of the camera passes: ~1024 workgroups in total for a large problem (c3: 19 observations per
+// thread; 2048 workgroups cost 0.117 + 0.131 ms, 1024: 0.099 + 0.128, 512: 0.105 + 0.146), at least ~2048 observations per
+// workgroup for a small one (c2: 512 workgroups 0.025 + 0.019 ms, 1024: 0.038 + 0.026).  VGG_CAM_WGS overrides the total.
+static inline int cam_split_for(int C, int O) {
+  static const int forced = [] { const char* e = getenv("VGG_CAM_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+  const int target = forced ? forced : min(1024, max(256, O / 2048));
+  const int s = target / (C > 0 ? C : 1);
   return s < 1 ? 1 : (s > kCamSplitMax ? kCamSplitMax : s);
 }
 
 template <int KD>
 static void phase_linearize(const Launch& L) {
   ProfScope ps(kProfLinearize, L.st);
-  const int split = cam_split_for(L.d.C);
+  const int split = cam_split_for(L.d.C, L.d.O);
   cam_pass_kernel<KD, 0><<<dim3(L.d.C, split), 256, 0, L.st>>>(L.dp, L.w);
   cam_reduce_kernel<KD, 0><<<L.d.C, 64, 0, L.st>>>(L.dp, L.w, split);
 }
@@ -1970,7 +1974,7 @@ static void phase_schur(const Launch& L) {
   reduce_gmax_kernel<<<1, 256, 0, L.st>>>(L.w, L.wgB);
   {
     ProfScope ps(kProfCamRhs, L.st);
-    const int split = cam_split_for(d.C);
+    const int split = cam_split_for(d.C, d.O);
     cam_pass_kernel<KD, 1><<<dim3(d.C, split), 256, 0, L.st>>>(L.dp, L.w);
     cam_reduce_kernel<KD, 1><<<d.C, 64, 0, L.st>>>(L.dp, L.w, split);
   }

@@ -2061,7 +2061,11 @@ static int make_launch(const vgg_ba_problem* pb, const vgg_ba_options* opt, void
   L->opt = *opt;
   L->st = st;
   L->lpp = lanes_per_point(L->d.P, L->d.O);
-  L->wgB = min(max(div_up(L->d.P, 4 * (64 / L->lpp)), 1), kMaxWG);
+  {
+    static const int forced = [] { const char* e = getenv("VGG_POINT_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+    // (c3: 512 or 1024 workgroups 2.18 ms per iteration, 2048: 2.21 -- every workgroup fills its LDS camera cache first)
+    L->wgB = min(max(div_up(L->d.P, 4 * (64 / L->lpp)), 1), forced ? min(forced, kMaxWG) : 1024);
+  }
   L->chunk_desc = pb->chunk_desc; L->entries = pb->entries; L->num_chunks = pb->num_chunks;
   L->block_chunk = pb->block_chunk;
   L->super_tiles = pb->super_tiles; L->quad_mask = pb->quad_mask;

@@ -51,6 +51,9 @@ constexpr int kGroup = 16;       // cameras per Schur tile side
 #ifndef VGG_PS_OCC
 #define VGG_PS_OCC 2
 #endif
+#ifndef VGG_CP_OCC_RHS
+#define VGG_CP_OCC_RHS 2
+#endif
 #ifndef VGG_CP_OCC
 #define VGG_CP_OCC 2
 #endif
@@ -180,14 +183,38 @@ static DevProblem dev_problem(const vgg_ba_problem* pb, const Dims& d) {
 // ---------------------------------------------------------------------------------------------
 // One observation: corrected residual and corrected, constant-masked, UNSCALED Jacobians.
 //   F[2][6+KD]  (pose tangent 6, refined intrinsics KD), E[2][3] (point); Rm = rotation matrix of the camera (row-major)
-// value k of a lane's prefetched observations (k < N, selected with compile-time indices) or the load it stands for
-template <int N, typename T>
-__device__ __forceinline__ T pick_pf(const T (&pf)[N], int k, const T* src, int o) {
-  T v = pf[0];
-#pragma unroll
-  for (int j = 1; j < N; ++j) v = (k == j) ? pf[j] : v;
-  return (k < N) ? v : src[o];
-}
+// (camera, pixel, slot) of the first N observations of a lane, prefetched with the point.  Named scalar members and
+// explicit selects: arrays filled in (later unrolled) loops stayed dynamically indexed stack objects -- scratch.
+template <int N>
+struct ObsPf {
+  static_assert(N == 2 || N == 4, "prefetch depth");
+  int c0 = 0, c1 = 0, c2 = 0, c3 = 0, s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  float2 u0 = make_float2(0.f, 0.f), u1 = make_float2(0.f, 0.f), u2 = make_float2(0.f, 0.f), u3 = make_float2(0.f, 0.f);
+  template <bool SLOT>
+  __device__ __forceinline__ void load(const int32_t* cam, const float2* uv, const int32_t* slot, int o0, int o1, int stride, int sl) {
+    int o = o0 + sl;
+    if (o < o1) { c0 = cam[o]; u0 = uv[o]; if (SLOT) s0 = slot[o]; }
+    o += stride;
+    if (o < o1) { c1 = cam[o]; u1 = uv[o]; if (SLOT) s1 = slot[o]; }
+    if (N == 4) {
+      o += stride;
+      if (o < o1) { c2 = cam[o]; u2 = uv[o]; if (SLOT) s2 = slot[o]; }
+      o += stride;
+      if (o < o1) { c3 = cam[o]; u3 = uv[o]; if (SLOT) s3 = slot[o]; }
+    }
+  }
+  template <typename T>
+  __device__ __forceinline__ static T pick(T a0, T a1, T a2, T a3, int k) {
+    const T lo = (k & 1) ? a1 : a0, hi = (k & 1) ? a3 : a2;
+    return (N == 4 && (k & 2)) ? hi : lo;
+  }
+  __device__ __forceinline__ int cam(int k, const int32_t* src, int o) const { return k < N ? pick(c0, c1, c2, c3, k) : src[o]; }
+  __device__ __forceinline__ int slot(int k, const int32_t* src, int o) const { return k < N ? pick(s0, s1, s2, s3, k) : src[o]; }
+  __device__ __forceinline__ float2 uv(int k, const float2* src, int o) const {
+    if (k >= N) return src[o];
+    return make_float2(pick(u0.x, u1.x, u2.x, u3.x, k), pick(u0.y, u1.y, u2.y, u3.y, k));
+  }
+};
 
 struct CamR {                                    // rotation matrix of a quaternion in global memory (paths without the LDS cache)
   double R[9];
@@ -287,7 +314,7 @@ __global__ void init_kernel(DevProblem pb, Ws w, vgg_ba_options opt, int rank, i
 // ---------------------------------------------------------------------------------------------
 // camera-major pass.  MODE 0: linearisation terms U_c, g_c, cost.  MODE 1: T_c = F^T [r - E hs | -E Ms].
 template <int KD, int MODE>
-__global__ __launch_bounds__(256, VGG_CP_OCC) void cam_pass_kernel(DevProblem pb, Ws w) {
+__global__ __launch_bounds__(256, (MODE == 1) ? VGG_CP_OCC_RHS : VGG_CP_OCC) void cam_pass_kernel(DevProblem pb, Ws w) {
   constexpr int BD = 6 + KD;
   constexpr int NU = BD * (BD + 1) / 2;
   constexpr int NV = (MODE == 0) ? (NU + BD + 1) : (BD * (1 + KD));
@@ -507,6 +534,7 @@ static int lanes_per_point(int P, int O) {
   const double mean = P > 0 ? (double)O / P : 64.0;
   return mean <= 72.0 ? 16 : 32;
 }
+static const int g_pp_longt = [] { const char* e = getenv("VGG_PP_LONGT"); return e ? atoi(e) : -1; }();   // experiment switch: 0 / 1 forces
 static const bool g_fused_point_pass = [] { const char* e = getenv("VGG_SPLIT_POINT_PASS"); return !(e && e[0] == '1'); }();
 
 // ---------------------------------------------------------------------------------------------
@@ -517,7 +545,7 @@ static const bool g_fused_point_pass = [] { const char* e = getenv("VGG_SPLIT_PO
 // LPP of a track are re-evaluated in the Y sweep.
 // WRITE_Y = false: the per-observation Schur factors are left to y_write_kernel (thread per observation); this kernel
 // then needs neither the cached Jacobians nor the slot prefetch and fits three wavefronts per SIMD.
-template <int KD, bool LDSCAM, bool WRITE_Y, int LPP>
+template <int KD, bool LDSCAM, bool WRITE_Y, int LPP, bool LONGT = false>
 __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void point_pass_kernel(DevProblem pb, Ws w, vgg_ba_options opt) {
   constexpr int BD = 6 + KD;
   __shared__ double wmax[4];
@@ -553,11 +581,13 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
   int p = (blockIdx.x * 4 + wave) * PPW + sub;   // (the lanes of one point run the same control flow: per-lane loops below)
   // (camera, pixel, slot) of the lane's first NPF observations (o0 + sl + k LPP) are prefetched with the point; later
   // ones are loaded where they are used
-  constexpr int NPF = 2;                         // (4 at 16 lanes per point: scratch, no gain)
-  int n_o0 = 0, n_o1 = 0, n_cs[NPF], n_slots[NPF];
-  float2 n_uvs[NPF];
-#pragma unroll
-  for (int k = 0; k < NPF; ++k) { n_cs[k] = 0; n_slots[k] = 0; n_uvs[k] = make_float2(0.f, 0.f); }
+  // LONGT (tracks of several sweeps: mean length > 1.5 LPP): four observations per lane prefetched and NO cached Jacobians
+  // (the cache serves one sweep in four there and costs 36 registers) -- every load of a point is then issued before the
+  // Y stores of the previous one (loads issued behind a burst of stores wait for the stores' acknowledgements)
+  constexpr int NPF = LONGT ? 4 : 2;
+  constexpr bool CACHEJ = !LONGT;
+  int n_o0 = 0, n_o1 = 0;
+  ObsPf<NPF> n_pf;
   double n_X0 = 0, n_X1 = 0, n_X2 = 0;
   bool n_ptc = false;
   // (two stages: the row bounds / coordinates are loaded TWO points ahead, the observations ONE point ahead, so
@@ -569,9 +599,7 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
     n_o0 = pb.row_ptr[p]; n_o1 = pb.row_ptr[p + 1];
     n_X0 = pb.pts[3 * p]; n_X1 = pb.pts[3 * p + 1]; n_X2 = pb.pts[3 * p + 2];
     n_ptc = pb.pt_const ? pb.pt_const[p] != 0 : false;
-#pragma unroll
-    for (int k = 0; k < NPF; ++k)
-      if (n_o0 + k * LPP + sl < n_o1) { const int oo = n_o0 + k * LPP + sl; n_cs[k] = pb.obs_cam[oo]; n_uvs[k] = pb.obs_uv[oo]; if (WRITE_Y) n_slots[k] = pb.obs_slot[oo]; }
+    n_pf.template load<WRITE_Y>(pb.obs_cam, pb.obs_uv, pb.obs_slot, n_o0, n_o1, LPP, sl);
     if (p + nw < d.P) {
       const int pm = p + nw;
       m_o0 = pb.row_ptr[pm]; m_o1 = pb.row_ptr[pm + 1];
@@ -583,18 +611,11 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
     const int o0 = n_o0, o1 = n_o1;
     const double X[3] = {n_X0, n_X1, n_X2};
     const bool pt_c = n_ptc;
-    int f_cs[NPF], f_slots[NPF];
-    float2 f_uvs[NPF];
-#pragma unroll
-    for (int k = 0; k < NPF; ++k) { f_cs[k] = n_cs[k]; f_slots[k] = n_slots[k]; f_uvs[k] = n_uvs[k]; }
+    const ObsPf<NPF> f_pf = n_pf;
     {
       // stage 1 -> current of the next iteration: observations of point p + nw (its bounds arrived an iteration ago)
       n_o0 = m_o0; n_o1 = m_o1; n_X0 = m_X0; n_X1 = m_X1; n_X2 = m_X2; n_ptc = m_ptc;
-      if (p + nw < d.P) {
-#pragma unroll
-        for (int k = 0; k < NPF; ++k)
-          if (n_o0 + k * LPP + sl < n_o1) { const int oo = n_o0 + k * LPP + sl; n_cs[k] = pb.obs_cam[oo]; n_uvs[k] = pb.obs_uv[oo]; if (WRITE_Y) n_slots[k] = pb.obs_slot[oo]; }
-      }
+      if (p + nw < d.P) n_pf.template load<WRITE_Y>(pb.obs_cam, pb.obs_uv, pb.obs_slot, n_o0, n_o1, LPP, sl);
       // stage 2: bounds / coordinates of point p + 2 nw
       const int pm = p + 2 * nw;
       if (pm < d.P) {
@@ -609,8 +630,8 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
     double cF[2 * BD], cE[6];          // Jacobians of this lane's first observation (tracks > LPP recompute)
     for (int o = o0 + sl; o < o1; o += LPP) {
       const int pass = (o - o0) / LPP; const bool head = pass == 0;
-      const int c = pick_pf<NPF>(f_cs, pass, pb.obs_cam, o);
-      const float2 uv = pick_pf<NPF>(f_uvs, pass, pb.obs_uv, o);
+      const int c = f_pf.cam(pass, pb.obs_cam, o);
+      const float2 uv = f_pf.uv(pass, pb.obs_uv, o);
       const int a = d.shared ? 0 : c;
       double r[2], F[2 * BD], E[6];
       if (LDSCAM)
@@ -619,7 +640,7 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
       else
         eval_full<KD>(d, CamR(pb.cam_q + 4 * c).R, pb.cam_t + 3 * c, pb.intr + 4 * a, X, uv,
                       pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
-      if (WRITE_Y && head) {
+      if (WRITE_Y && CACHEJ && head) {
 #pragma unroll
         for (int i = 0; i < 2 * BD; ++i) cF[i] = F[i];
 #pragma unroll
@@ -703,9 +724,9 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
       const int bdt = d.shared ? 6 : BD;          // rows of the tile block (intrinsics only when per camera)
       for (int o = o0 + sl; o < o1; o += LPP) {
         const int pass = (o - o0) / LPP; const bool head = pass == 0;
-        const int c = pick_pf<NPF>(f_cs, pass, pb.obs_cam, o);
+        const int c = f_pf.cam(pass, pb.obs_cam, o);
         double F[2 * BD], E[6];
-        if (head) {                               // cached Jacobians of the first slice
+        if (CACHEJ && head) {                     // cached Jacobians of the first slice
 #pragma unroll
           for (int i = 0; i < 2 * BD; ++i) F[i] = cF[i];
 #pragma unroll
@@ -713,7 +734,7 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
         } else {
           const int a = d.shared ? 0 : c;
           double r[2];
-          const float2 uv = pick_pf<NPF>(f_uvs, pass, pb.obs_uv, o);
+          const float2 uv = f_pf.uv(pass, pb.obs_uv, o);
           if (LDSCAM)
             eval_full<KD>(d, lq + 9 * c, lt + 3 * c, pb.intr + 4 * a, X, uv, (unsigned)lfl[c],
                           pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
@@ -722,7 +743,7 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
                           pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
         }
         // segment layout: [component 0..2][slot 0..15][row 0..bdt-1]  (three rows of the K dimension)
-        const int slot = pick_pf<NPF>(f_slots, pass, pb.obs_slot, o), rt = kGroup * bdt;
+        const int slot = f_pf.slot(pass, pb.obs_slot, o), rt = kGroup * bdt;
         double* y = w.Y + (size_t)(slot >> 4) * (3 * rt) + (slot & 15) * bdt;
         // the lane's three runs of bdt doubles go out 16 bytes at a time when bdt is even (the runs are then 16-byte
         // aligned): half the store instructions and half the partial-line transactions of 8-byte stores.  Measured at 16
@@ -1587,10 +1608,8 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
   // same software pipeline over the points of a wavefront as in point_pass_kernel
   int p = (blockIdx.x * 4 + wave) * PPW + sub;
   constexpr int NPF = 2;                         // prefetched observations per lane (see point_pass_kernel)
-  int n_o0 = 0, n_o1 = 0, n_cs[NPF];
-  float2 n_uvs[NPF];
-#pragma unroll
-  for (int k = 0; k < NPF; ++k) { n_cs[k] = 0; n_uvs[k] = make_float2(0.f, 0.f); }
+  int n_o0 = 0, n_o1 = 0;
+  ObsPf<NPF> n_pf;
   double n_X0 = 0, n_X1 = 0, n_X2 = 0;
   bool n_ptc = false;
   // (two stages: the row bounds / coordinates are loaded TWO points ahead, the observations ONE point ahead, so
@@ -1602,9 +1621,7 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
     n_o0 = pb.row_ptr[p]; n_o1 = pb.row_ptr[p + 1];
     n_X0 = pb.pts[3 * p]; n_X1 = pb.pts[3 * p + 1]; n_X2 = pb.pts[3 * p + 2];
     n_ptc = pb.pt_const ? pb.pt_const[p] != 0 : false;
-#pragma unroll
-    for (int k = 0; k < NPF; ++k)
-      if (n_o0 + k * LPP + sl < n_o1) { const int oo = n_o0 + k * LPP + sl; n_cs[k] = pb.obs_cam[oo]; n_uvs[k] = pb.obs_uv[oo]; }
+    n_pf.template load<false>(pb.obs_cam, pb.obs_uv, nullptr, n_o0, n_o1, LPP, sl);
     if (p + nw < d.P) {
       const int pm = p + nw;
       m_o0 = pb.row_ptr[pm]; m_o1 = pb.row_ptr[pm + 1];
@@ -1616,18 +1633,11 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
     const int o0 = n_o0, o1 = n_o1;
     const double X[3] = {n_X0, n_X1, n_X2};
     const bool pt_c = n_ptc;
-    int f_cs[NPF];
-    float2 f_uvs[NPF];
-#pragma unroll
-    for (int k = 0; k < NPF; ++k) { f_cs[k] = n_cs[k]; f_uvs[k] = n_uvs[k]; }
+    const ObsPf<NPF> f_pf = n_pf;
     {
       // stage 1 -> current of the next iteration: observations of point p + nw (its bounds arrived an iteration ago)
       n_o0 = m_o0; n_o1 = m_o1; n_X0 = m_X0; n_X1 = m_X1; n_X2 = m_X2; n_ptc = m_ptc;
-      if (p + nw < d.P) {
-#pragma unroll
-        for (int k = 0; k < NPF; ++k)
-          if (n_o0 + k * LPP + sl < n_o1) { const int oo = n_o0 + k * LPP + sl; n_cs[k] = pb.obs_cam[oo]; n_uvs[k] = pb.obs_uv[oo]; }
-      }
+      if (p + nw < d.P) n_pf.template load<false>(pb.obs_cam, pb.obs_uv, nullptr, n_o0, n_o1, LPP, sl);
       // stage 2: bounds / coordinates of point p + 2 nw
       const int pm = p + 2 * nw;
       if (pm < d.P) {
@@ -1641,8 +1651,8 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
     double c_r[2] = {0, 0}, c_fy[2] = {0, 0}, c_E[6] = {0, 0, 0, 0, 0, 0};
     for (int o = o0 + sl; o < o1; o += LPP) {
       const int pass = (o - o0) / LPP; const bool head = pass == 0;
-      const int c = pick_pf<NPF>(f_cs, pass, pb.obs_cam, o);
-      const float2 uv = pick_pf<NPF>(f_uvs, pass, pb.obs_uv, o);
+      const int c = f_pf.cam(pass, pb.obs_cam, o);
+      const float2 uv = f_pf.uv(pass, pb.obs_uv, o);
       const int a = d.shared ? 0 : c;
       double r[2], F[2 * BD], E[6];
       if (LDSCAM)
@@ -1681,9 +1691,9 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
     }
     for (int o = o0 + sl; o < o1; o += LPP) {
       const int pass = (o - o0) / LPP; const bool head = pass == 0;
-      const int c = pick_pf<NPF>(f_cs, pass, pb.obs_cam, o);
+      const int c = f_pf.cam(pass, pb.obs_cam, o);
       const int a = d.shared ? 0 : c;
-      const float2 uv = pick_pf<NPF>(f_uvs, pass, pb.obs_uv, o);
+      const float2 uv = f_pf.uv(pass, pb.obs_uv, o);
       double r[2], fy[2], E[6];
       if (head) {
         r[0] = c_r[0]; r[1] = c_r[1]; fy[0] = c_fy[0]; fy[1] = c_fy[1];
@@ -1962,7 +1972,11 @@ static void phase_schur(const Launch& L) {
     } else {
       auto launch = [&](auto lpp) {
         constexpr int LPP = decltype(lpp)::value;
-        if (cam_lds <= 64 * 1024) point_pass_kernel<KD, true, true, LPP><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w, L.opt);
+        const bool longt = g_pp_longt >= 0 ? g_pp_longt != 0 : (double)L.d.O > 1.5 * LPP * (double)L.d.P;
+        if (longt && LPP <= 32) {
+          if (cam_lds <= 64 * 1024) point_pass_kernel<KD, true, true, LPP, (LPP <= 32)><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w, L.opt);
+          else point_pass_kernel<KD, false, true, LPP, (LPP <= 32)><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w, L.opt);
+        } else if (cam_lds <= 64 * 1024) point_pass_kernel<KD, true, true, LPP><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w, L.opt);
         else point_pass_kernel<KD, false, true, LPP><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w, L.opt);
       };
       if (L.lpp == 8) launch(std::integral_constant<int, 8>{});

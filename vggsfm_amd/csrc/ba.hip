@@ -1577,7 +1577,7 @@ __global__ void cam_update_kernel(DevProblem pb, Ws w) {
 }
 
 // back-substitution, model cost change, candidate point and candidate cost: LPP lanes per point (see point_pass_kernel)
-template <int KD, bool LDSCAM, int LPP>
+template <int KD, bool LDSCAM, int LPP, bool LONGT = false>
 __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem pb, Ws w) {
   constexpr int BD = 6 + KD;
   __shared__ double red[4][4];
@@ -1607,7 +1607,7 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
   }
   // same software pipeline over the points of a wavefront as in point_pass_kernel
   int p = (blockIdx.x * 4 + wave) * PPW + sub;
-  constexpr int NPF = 2;                         // prefetched observations per lane (see point_pass_kernel)
+  constexpr int NPF = LONGT ? 4 : 2;             // prefetched observations per lane (see point_pass_kernel)
   int n_o0 = 0, n_o1 = 0;
   ObsPf<NPF> n_pf;
   double n_X0 = 0, n_X1 = 0, n_X2 = 0;
@@ -2042,7 +2042,11 @@ static int phase_step(const Launch& L) {
     const size_t cam_lds = sizeof(double) * 31 * (size_t)d.C;
     auto launch = [&](auto lpp) {
       constexpr int LPP = decltype(lpp)::value;
-      if (cam_lds <= 64 * 1024) point_step_kernel<KD, true, LPP><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w);
+      const bool longt = g_pp_longt >= 0 ? g_pp_longt != 0 : (double)L.d.O > 1.5 * LPP * (double)L.d.P;
+      if (longt && LPP <= 32) {
+        if (cam_lds <= 64 * 1024) point_step_kernel<KD, true, LPP, (LPP <= 32)><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w);
+        else point_step_kernel<KD, false, LPP, (LPP <= 32)><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w);
+      } else if (cam_lds <= 64 * 1024) point_step_kernel<KD, true, LPP><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w);
       else point_step_kernel<KD, false, LPP><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w);
     };
     if (L.lpp == 8) launch(std::integral_constant<int, 8>{});

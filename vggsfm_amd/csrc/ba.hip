@@ -34,6 +34,7 @@ namespace vgg {
 int cholesky_solve_enqueue(double* A, double* b, int n, double* inv_blocks, int32_t* device_fail, const int32_t* skip_flag,
                            hipStream_t st, const CholOverlap* overlap, int split_a, int split_b, const int32_t* first_blk);
 size_t cholesky_workspace_bytes(int n);
+void dataflow_signal(int32_t* flag, hipStream_t st);
 
 constexpr int kGroup = 16;       // cameras per Schur tile side
 #ifndef VGG_OFFDIAG_OCC
@@ -101,6 +102,7 @@ struct Ws {  // device workspace carve-up (pointers into the caller's buffer)
   size_t y_bytes;
   double* chol_inv;           // inverse diagonal blocks of the Cholesky factor
   double* tile_part;          // [num_chunks][R][R] partial Schur tiles, R = 16*BDt
+  int32_t* batch_flags;       // [8] overlap mode: tile batch b >= 1 has been summed into S2 (raised by a kernel behind it)
   size_t lin_count, sys_count, total_bytes;
 };
 
@@ -158,6 +160,7 @@ static Ws carve(const Dims& d, int max_iters, int num_chunks, int num_segments, 
     const size_t bdt = d.shared ? 6 : d.BDp;
     w.tile_part = (double*)take(8ull * (size_t)(num_chunks > 0 ? num_chunks : 1) * bdt * bdt * 256 * (super_tiles ? 4 : 1));   // R*R, R = 16*bdt (32*bdt)
   }
+  w.batch_flags = (int32_t*)take(64);
   w.total_bytes = off;
   return w;
 }
@@ -1912,11 +1915,13 @@ static void launch_schur_batch(const Launch& L, int batch, hipStream_t st, doubl
 }
 
 template <int KD>
-static void launch_schur_batches(const Launch& L, int b0, int b1, hipStream_t st, double* dst, hipEvent_t* done_events) {
+static void launch_schur_batches(const Launch& L, int b0, int b1, hipStream_t st, double* dst, hipEvent_t* done_events,
+                                 int32_t* done_flags = nullptr) {
   for (int b = b0; b < b1; ++b) {
     if (L.d.shared || KD == 0) launch_schur_batch<6>(L, b, st, dst);
     else launch_schur_batch<6 + KD>(L, b, st, dst);
     if (done_events) (void)hipEventRecord(done_events[b], st);
+    if (done_flags) dataflow_signal(done_flags + b, st);    // (for the single-launch factorisation, which waits on the device)
   }
 }
 
@@ -2012,11 +2017,13 @@ static int phase_step(const Launch& L) {
   fix_constant_kernel<<<div_up(d.n_red, 256), 256, 0, L.st>>>(L.w, d.n_red);
   int rc;
   if (OverlapCtx* oc = overlap_ctx(L)) {
+    (void)hipMemsetAsync(L.w.batch_flags, 0, 64, L.st);
     (void)hipEventRecord(oc->ready, L.st);
     (void)hipStreamWaitEvent(oc->st_rest, oc->ready, 0);
     (void)hipStreamWaitEvent(oc->st_chol, oc->ready, 0);
-    launch_schur_batches<KD>(L, 1, L.num_batches, oc->st_rest, L.w.S2, oc->batch_done);
+    launch_schur_batches<KD>(L, 1, L.num_batches, oc->st_rest, L.w.S2, oc->batch_done, L.w.batch_flags);
     CholOverlap ov;
+    ov.dev_flags = L.w.batch_flags + 1;            // flag of wait k = batch k + 1
     ov.S2 = L.w.S2;
     ov.first_col = 6 * kGroup * L.batches[6 * 1 + 5];
     ov.num_waits = L.num_batches - 1;
@@ -2026,7 +2033,8 @@ static int phase_step(const Launch& L) {
     }
     {
       ProfScope ps(kProfCholesky, oc->st_chol);
-      rc = cholesky_solve_enqueue(L.w.S, L.w.rhs, d.n_red, L.w.chol_inv, &L.w.ctl->linear_fail, &L.w.ctl->done, oc->st_chol, &ov, 0, 0, nullptr);
+      rc = cholesky_solve_enqueue(L.w.S, L.w.rhs, d.n_red, L.w.chol_inv, &L.w.ctl->linear_fail, &L.w.ctl->done, oc->st_chol, &ov,
+                                  L.chol_split_a, L.chol_split_b, L.chol_first_blk);
     }
     (void)hipEventRecord(oc->chol_done, oc->st_chol);
     (void)hipStreamWaitEvent(L.st, oc->chol_done, 0);

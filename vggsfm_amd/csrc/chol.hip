@@ -791,7 +791,8 @@ struct DfShared {
 // flags: ready[(nbk + 1) * nbk] (tile (r, c) final), then tready[nbk]; all zero on entry.
 __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__ A, int n, int nbk, double* __restrict__ Tinv,
                                                             int32_t* __restrict__ flags, int32_t* fail, const int32_t* skip,
-                                                            int split_a, int split_b, const int32_t* __restrict__ first_blk) {
+                                                            int split_a, int split_b, const int32_t* __restrict__ first_blk,
+                                                            DfOverlap ov) {
   extern __shared__ double df_smem[];
   DfShared& sh = *reinterpret_cast<DfShared*>(df_smem);
   constexpr int LD = DFB + 1;
@@ -816,6 +817,17 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
   const bool diag = (r == c);
   DF_STAMP(0);
 
+  // Overlap with the Schur tile batches (ba.hip, options.overlap_factorization): the contributions to the columns >=
+  // ov.first_col are still being summed into S2 by another stream when this launch starts; flag k says that everything
+  // for the columns >= ov.wait_col[k] has landed.  A tile waits for the last flag its columns need and adds S2.
+  const double* S2 = nullptr;
+  if (ov.S2 && r < nbk && c0 + vc > ov.first_col) {
+    int need = -1;
+    for (int k = 0; k < ov.num_waits; ++k)
+      if (ov.wait_col[k] < c0 + vc) need = k;
+    if (need >= 0) df_wait(&ov.flags[need], fail);
+    S2 = ov.S2;
+  }
   // the tile of A (C layout: row = 32 wy + 16 m + lk + 4 reg, col = 32 wx + 16 q + li) and the product accumulators
   f64x4 acc[2][2], a0[2][2];
 #pragma unroll
@@ -825,7 +837,9 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int i = 32 * wy + 16 * m + lk + 4 * reg, j = 32 * wx + 16 * q + li;
-        a0[m][q][reg] = (i < vr && j < vc && (!diag || j <= i)) ? A[(size_t)(r0 + i) * n + c0 + j] : 0.0;
+        const bool in = i < vr && j < vc && (!diag || j <= i);
+        a0[m][q][reg] = in ? A[(size_t)(r0 + i) * n + c0 + j] : 0.0;
+        if (S2 && in) a0[m][q][reg] += ld_agent(&S2[(size_t)(r0 + i) * n + c0 + j]);
         acc[m][q][reg] = 0.0;
       }
 
@@ -1048,8 +1062,12 @@ static bool use_dataflow(int n) {
   return !legacy && n >= 2 * DFB;
 }
 
+// raises one overlap flag (a launch of its own behind a tile batch: the batch's stores are then visible device-wide)
+__global__ void df_signal_kernel(int32_t* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+void dataflow_signal(int32_t* flag, hipStream_t st) { df_signal_kernel<<<1, 1, 0, st>>>(flag); }
+
 static int enqueue_dataflow(double* A, double* b, int n, double* ws, int32_t* device_fail, const int32_t* skip, hipStream_t st,
-                            int split_a, int split_b, const int32_t* first_blk) {
+                            int split_a, int split_b, const int32_t* first_blk, const CholOverlap* overlap = nullptr) {
   const int nbk = div_up(n, DFB);
   double* Tinv = ws;
   int32_t* flags = reinterpret_cast<int32_t*>(ws + (size_t)nbk * DFB * DFB);
@@ -1062,7 +1080,12 @@ static int enqueue_dataflow(double* A, double* b, int n, double* ws, int32_t* de
   }
   if (!(split_a >= DFB && split_b >= DFB && split_a % DFB == 0 && split_a + split_b <= n)) split_a = split_b = 0;
   const int tiles = nbk * (nbk + 1) / 2 + nbk;
-  chol_dataflow_kernel<<<tiles, 256, sizeof(DfShared), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b, first_blk);
+  DfOverlap ov = {};
+  if (overlap && overlap->dev_flags) {
+    ov.S2 = overlap->S2; ov.flags = overlap->dev_flags; ov.first_col = overlap->first_col; ov.num_waits = overlap->num_waits;
+    for (int k = 0; k < overlap->num_waits && k < 8; ++k) ov.wait_col[k] = overlap->wait_col[k];
+  }
+  chol_dataflow_kernel<<<tiles, 256, sizeof(DfShared), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b, first_blk, ov);
   int32_t* xready = flags + (size_t)(nbk + 1) * nbk + nbk;
   chol_backward_dataflow_kernel<<<nbk, 256, 0, st>>>(A, b, n, nbk, Tinv, xready, device_fail, skip, split_a, split_b, first_blk);
   if (hipGetLastError() != hipSuccess) return VGG_ERR_HIP;
@@ -1149,8 +1172,8 @@ static int enqueue(double* A, double* b, int n, double* inv_blocks, int32_t* dev
 int cholesky_solve_enqueue(double* A, double* b, int n, double* inv_blocks, int32_t* device_fail, const int32_t* skip,
                            hipStream_t st, const CholOverlap* overlap, int split_a, int split_b, const int32_t* first_blk) {
   if (!inv_blocks) return VGG_ERR_INVALID_ARGUMENT;
-  if (!overlap && b == A + (size_t)n * n && use_dataflow(n))
-    return enqueue_dataflow(A, b, n, inv_blocks, device_fail, skip, st, split_a, split_b, first_blk);
+  if ((!overlap || overlap->dev_flags) && b == A + (size_t)n * n && use_dataflow(n))
+    return enqueue_dataflow(A, b, n, inv_blocks, device_fail, skip, st, split_a, split_b, first_blk, overlap);
   return enqueue<32>(A, b, n, inv_blocks, device_fail, skip, st, overlap, split_a, split_b);
 }
 

@@ -67,6 +67,15 @@ struct CholOverlap {
   int num_waits;
   int wait_col[8];
   hipEvent_t wait_ev[8];
+  const int32_t* dev_flags = nullptr;   // device [num_waits]: flag k != 0 <=> event k has happened (dataflow factorisation:
+                                        // one launch, so it waits on the device; set by a kernel behind each tile batch)
+};
+// by-value kernel argument of the dataflow factorisation
+struct DfOverlap {
+  const double* S2;
+  const int32_t* flags;
+  int first_col, num_waits;
+  int wait_col[8];
 };
 
 }  // namespace vgg

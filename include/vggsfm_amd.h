@@ -318,6 +318,12 @@ int vgg_fmat_residuals(const double* points1, const double* points2, const uint8
  * kernel_id: 0 cam_pass<linearize> 1 point_pass 2 cam_pass<rhs> 3 schur_tile<off-diagonal tiles> 4 cholesky (all
  * launches of one solve) 5 point_step 6 schur_tile<diagonal tiles>.  vgg_ba_profile_read synchronises on the
  * recorded events. */
+/* Launch choices the solver otherwise makes from the problem's shape (process-wide; for tests and measurements):
+ * lanes_per_point 8 | 16 | 32 | 64 (0 = from the mean track length) -- lanes of a wavefront that share one point in the point
+ * passes; long_tracks 1 / 0 (-1 = automatic) -- the variants that prefetch four observations per lane and keep no cached
+ * Jacobians; cam_workgroups / point_workgroups (0 = automatic) -- total workgroups of the camera / point passes.  Every
+ * combination computes the same iteration up to the order of its sums. */
+int vgg_ba_tuning(int lanes_per_point, int long_tracks, int cam_workgroups, int point_workgroups);
 int vgg_ba_profile(int enable, int max_launches_per_kernel);
 int vgg_ba_profile_read(int kernel_id, double* total_ms, int* launches, int reset);
 

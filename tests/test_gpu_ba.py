@@ -219,6 +219,36 @@ def test_ba_super_tiles_match_tiles(monkeypatch, S, N, cam):
             np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-7, atol=1e-7)
 
 
+@pytest.mark.parametrize("S,N,cam,shared", [(60, 3000, "SIMPLE_RADIAL", True), (24, 1500, "SIMPLE_PINHOLE", False), (90, 2500, "SIMPLE_RADIAL", False)])
+def test_ba_launch_variants_agree(S, N, cam, shared):
+    """Every launch variant of the observation passes (vgg_ba_tuning: 8 / 16 / 32 / 64 lanes per point, the long-track
+    versions with four prefetched observations and no cached Jacobians, other workgroup counts of the camera and point
+    passes) computes the same LM iteration up to the order of its sums: same trajectory as the automatic choice."""
+    sc = make_scene(S, N, cam, shared_camera=shared, seed=23)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=23)
+    opt = BundleAdjustmentOptions()
+    opt.solver_options.max_num_iterations = 8
+    L = _lib.lib()
+
+    def solve():
+        return BA.bundle_adjustment(D(pts0), D(ext0), D(K0), D(sc.tracks), D(sc.mask), None, D(extra0), shared, cam, opt)
+    try:
+        assert L.vgg_ba_tuning(0, -1, 0, 0) == 0
+        ref = solve()
+        for lpp, longt, cw, pw in [(8, 0, 0, 0), (8, 1, 0, 0), (16, 0, 0, 0), (16, 1, 0, 0), (32, 0, 0, 0), (32, 1, 300, 64),
+                                   (64, 0, 0, 0), (64, 1, 2048, 2048), (0, -1, 128, 7)]:
+            assert L.vgg_ba_tuning(lpp, longt, cw, pw) == 0
+            a = solve()
+            assert a[4]["num_iterations"] == ref[4]["num_iterations"], (lpp, longt)
+            assert abs(a[4]["final_cost"] - ref[4]["final_cost"]) <= 1e-9 * ref[4]["final_cost"], (lpp, longt)
+            for x, y in zip(a[:4], ref[:4]):
+                if x is not None:
+                    np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-7, atol=1e-7, err_msg=str((lpp, longt, cw, pw)))
+        assert L.vgg_ba_tuning(5, 0, 0, 0) != 0                          # not a lane count
+    finally:
+        L.vgg_ba_tuning(0, -1, 0, 0)
+
+
 def test_cholesky_flags_indefinite():
     A = np.eye(40)
     A[17, 17] = -1.0

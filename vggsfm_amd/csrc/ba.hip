@@ -531,13 +531,22 @@ __global__ void damping_kernel(Ws w, vgg_ba_options opt, int n_red) {
 // its serial work (reductions, 3 x 3 factorisation), which outweighs the sweeps over its observations up to ~70 of them:
 // measured per LM iteration, point_pass + point_step -- c2 (mean 12.5 observations) 64: 0.112, 32: 0.075, 16: 0.065,
 // 8: 0.059 ms; c3 (mean 50) 64: 0.674, 32: 0.549, 16: 0.499, 8: 0.535 ms; one c4 shard (mean 100) 32: 0.509, 16: 0.544 ms.
+// overrides of the automatic launch choices (vgg_ba_tuning; the environment variables seed them): 0 / -1 = automatic
+struct Tuning { int lpp, longt, cam_wgs, point_wgs; };
+static Tuning g_tuning = [] {
+  auto env = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+  return Tuning{env("VGG_LPP", 0), env("VGG_PP_LONGT", -1), env("VGG_CAM_WGS", 0), env("VGG_POINT_WGS", 0)};
+}();
 static int lanes_per_point(int P, int O) {
-  static const int forced = [] { const char* e = getenv("VGG_LPP"); return e ? atoi(e) : 0; }();
+  const int forced = g_tuning.lpp;
   if (forced == 8 || forced == 16 || forced == 32 || forced == 64) return forced;
   const double mean = P > 0 ? (double)O / P : 64.0;
   return mean <= 72.0 ? 16 : 32;
 }
-static const int g_pp_longt = [] { const char* e = getenv("VGG_PP_LONGT"); return e ? atoi(e) : -1; }();   // experiment switch: 0 / 1 forces
+// long-track variants of the point passes (four prefetched observations per lane, no cached Jacobians)
+static bool long_tracks(int lpp, int P, int O) {
+  return g_tuning.longt >= 0 ? g_tuning.longt != 0 : (double)O > 1.5 * lpp * (double)P;
+}
 static const bool g_fused_point_pass = [] { const char* e = getenv("VGG_SPLIT_POINT_PASS"); return !(e && e[0] == '1'); }();
 
 // ---------------------------------------------------------------------------------------------
@@ -1866,8 +1875,7 @@ __global__ __launch_bounds__(256) void pack_lower_kernel(Ws w, int n, int unpack
 // thread; 2048 workgroups cost 0.117 + 0.131 ms, 1024: 0.099 + 0.128, 512: 0.105 + 0.146), at least ~2048 observations per
 // workgroup for a small one (c2: 512 workgroups 0.025 + 0.019 ms, 1024: 0.038 + 0.026).  VGG_CAM_WGS overrides the total.
 static inline int cam_split_for(int C, int O) {
-  static const int forced = [] { const char* e = getenv("VGG_CAM_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
-  const int target = forced ? forced : min(1024, max(256, O / 2048));
+  const int target = g_tuning.cam_wgs > 0 ? g_tuning.cam_wgs : min(1024, max(256, O / 2048));
   const int s = target / (C > 0 ? C : 1);
   return s < 1 ? 1 : (s > kCamSplitMax ? kCamSplitMax : s);
 }
@@ -1977,7 +1985,7 @@ static void phase_schur(const Launch& L) {
     } else {
       auto launch = [&](auto lpp) {
         constexpr int LPP = decltype(lpp)::value;
-        const bool longt = g_pp_longt >= 0 ? g_pp_longt != 0 : (double)L.d.O > 1.5 * LPP * (double)L.d.P;
+        const bool longt = long_tracks(LPP, L.d.P, L.d.O);
         if (longt && LPP <= 32) {
           if (cam_lds <= 64 * 1024) point_pass_kernel<KD, true, true, LPP, (LPP <= 32)><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w, L.opt);
           else point_pass_kernel<KD, false, true, LPP, (LPP <= 32)><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w, L.opt);
@@ -2050,7 +2058,7 @@ static int phase_step(const Launch& L) {
     const size_t cam_lds = sizeof(double) * 31 * (size_t)d.C;
     auto launch = [&](auto lpp) {
       constexpr int LPP = decltype(lpp)::value;
-      const bool longt = g_pp_longt >= 0 ? g_pp_longt != 0 : (double)L.d.O > 1.5 * LPP * (double)L.d.P;
+      const bool longt = long_tracks(LPP, L.d.P, L.d.O);
       if (longt && LPP <= 32) {
         if (cam_lds <= 64 * 1024) point_step_kernel<KD, true, LPP, (LPP <= 32)><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w);
         else point_step_kernel<KD, false, LPP, (LPP <= 32)><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w);
@@ -2087,11 +2095,8 @@ static int make_launch(const vgg_ba_problem* pb, const vgg_ba_options* opt, void
   L->opt = *opt;
   L->st = st;
   L->lpp = lanes_per_point(L->d.P, L->d.O);
-  {
-    static const int forced = [] { const char* e = getenv("VGG_POINT_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
-    // (c3: 512 or 1024 workgroups 2.18 ms per iteration, 2048: 2.21 -- every workgroup fills its LDS camera cache first)
-    L->wgB = min(max(div_up(L->d.P, 4 * (64 / L->lpp)), 1), forced ? min(forced, kMaxWG) : 1024);
-  }
+  // (c3: 512 or 1024 workgroups 2.18 ms per iteration, 2048: 2.21 -- every workgroup fills its LDS camera cache first)
+  L->wgB = min(max(div_up(L->d.P, 4 * (64 / L->lpp)), 1), g_tuning.point_wgs > 0 ? min(g_tuning.point_wgs, kMaxWG) : 1024);
   L->chunk_desc = pb->chunk_desc; L->entries = pb->entries; L->num_chunks = pb->num_chunks;
   L->block_chunk = pb->block_chunk;
   L->super_tiles = pb->super_tiles; L->quad_mask = pb->quad_mask;
@@ -2164,6 +2169,14 @@ static int finish(const Launch& L, int max_iters, vgg_ba_summary* summary, vgg_b
 using namespace vgg;
 
 extern "C" {
+
+int vgg_ba_tuning(int lanes_per_point, int long_tracks, int cam_workgroups, int point_workgroups) {
+  if (!(lanes_per_point == 0 || lanes_per_point == 8 || lanes_per_point == 16 || lanes_per_point == 32 || lanes_per_point == 64))
+    return VGG_ERR_INVALID_ARGUMENT;
+  vgg::g_tuning = vgg::Tuning{lanes_per_point, long_tracks < 0 ? -1 : (long_tracks ? 1 : 0), cam_workgroups > 0 ? cam_workgroups : 0,
+                              point_workgroups > 0 ? point_workgroups : 0};
+  return VGG_OK;
+}
 
 int vgg_ba_profile(int enable, int max_launches_per_kernel) {
   for (int k = 0; k < kProfCount; ++k) {

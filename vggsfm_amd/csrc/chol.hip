@@ -193,6 +193,163 @@ __device__ __forceinline__ void factor_diag_lds4(double* D, double* Tl, double* 
   __syncthreads();
 }
 
+// factor_diag_lds4 with LOOK-AHEAD: the pivot chain of a step (four dependent reciprocals, ~700 cycles that every thread
+// used to repeat before anything else could start) is computed for step j + 1 by the LAST wavefront while the other three
+// apply the trailing update of step j.  That wavefront first brings the next 4 x 4 pivot block up to date itself (the same
+// rank-4 expressions, in the same order, that the trailing update would have applied -- the factor stays bit-identical),
+// runs the chain and leaves the 13 numbers every thread needs (reciprocals, multipliers, eliminated block entries) in a
+// small LDS record.  Per step: barrier, read the record, panel rows, barrier, {chain | update}.
+// MEASURED SLOWER (opt-in, -DVGG_CHOL_LOOKAHEAD): c3 factorisation 0.505 -> 0.548 ms, c2 0.208 -> 0.221, a c4 shard 1.36 ->
+// 1.46.  The trailing update it takes off the critical path is the cheap part of a step; the chain + the panel rows are
+// the step, and the record adds LDS round trips (record write -> barrier -> read; U / V / D reads of the chain wavefront)
+// to exactly that path.  Same factor (tests/test_gpu_ba.py::test_cholesky_* pass with it).
+// scratch: 2 * ROWS * 4 doubles (U, V) + 16 (pivot record).
+template <int NB, bool WITH_T, int LD = NB + 1>
+__device__ __forceinline__ void factor_diag_lds4_la(double* D, double* Tl, double* rdiag, double* scratch, int32_t* fail_flag) {
+  static_assert(NB % 4 == 0 && NB <= 64, "block of 4-column steps");
+  constexpr int ROWS = WITH_T ? 2 * NB : NB;
+  constexpr int UT = 192;                          // threads of the trailing update (wavefronts 0..2)
+  constexpr int STRIDE = UT / NB, CNT = (NB + STRIDE - 1) / STRIDE;
+  static_assert(UT % NB == 0 && ROWS <= UT, "update layout");
+  double* U = scratch;                             // [ROWS][4] unnormalised panel entries u_rt
+  double* V = scratch + ROWS * 4;                  // [ROWS][4] u_rt / d_t
+  double* PR = scratch + 2 * ROWS * 4;             // pivot record: r0..r3, m10 m20 m30 m21 m31 m32, d1 u21 d2 u31 u32 d3 (16)
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = tid % NB, i0 = tid / NB;           // (update threads only: tid < UT)
+  bool bad = false;
+  constexpr double HUGE_ = 1.7976931348623157e308;
+  if (WITH_T) {
+    for (int e = tid; e < NB * NB; e += 256) Tl[(e / NB) * LD + (e % NB)] = (e / NB == e % NB) ? 1.0 : 0.0;
+  }
+  // pivot chain of the 4 x 4 block (values given) -> record; every lane of the calling wavefront computes the same
+  auto chain = [&](double d0, double u10, double p11, double u20, double p21, double p22, double u30, double p31, double p32, double p33) {
+    const double r0 = fast_rcp<1>((d0 > 0.0) ? d0 : 1.0);
+    const double m10 = u10 * r0, m20 = u20 * r0, m30 = u30 * r0;
+    const double d1 = p11 - u10 * m10;
+    const double u21 = p21 - u20 * m10, u31 = p31 - u30 * m10;
+    const double r1 = fast_rcp<1>((d1 > 0.0) ? d1 : 1.0);
+    const double m21 = u21 * r1, m31 = u31 * r1;
+    const double d2 = (p22 - u20 * m20) - u21 * m21;
+    const double u32 = (p32 - u30 * m20) - u31 * m21;
+    const double r2 = fast_rcp<1>((d2 > 0.0) ? d2 : 1.0);
+    const double m32 = u32 * r2;
+    const double d3 = ((p33 - u30 * m30) - u31 * m31) - u32 * m32;
+    const double r3 = fast_rcp<1>((d3 > 0.0) ? d3 : 1.0);
+    if (!(d0 > 0.0) || !(d0 < HUGE_) || !(d1 > 0.0) || !(d1 < HUGE_) || !(d2 > 0.0) || !(d2 < HUGE_) || !(d3 > 0.0) || !(d3 < HUGE_))
+      bad = true;
+    if ((tid & 63) == 0) {
+      PR[0] = r0; PR[1] = r1; PR[2] = r2; PR[3] = r3;
+      PR[4] = m10; PR[5] = m20; PR[6] = m30; PR[7] = m21; PR[8] = m31; PR[9] = m32;
+      PR[10] = d1; PR[11] = u21; PR[12] = d2; PR[13] = u31; PR[14] = u32; PR[15] = d3;
+    }
+  };
+  __syncthreads();
+  if (wave == 3) {                                 // record of step 0: the block as it stands
+    const double* P = D;
+    chain(P[0], P[LD], P[LD + 1], P[2 * LD], P[2 * LD + 1], P[2 * LD + 2], P[3 * LD], P[3 * LD + 1], P[3 * LD + 2], P[3 * LD + 3]);
+  }
+  for (int j0 = 0; j0 < NB; j0 += 4) {
+    __syncthreads();                               // record of this step written; all earlier updates applied
+    const double r0 = PR[0], r1 = PR[1], r2 = PR[2], r3 = PR[3];
+    const double m10 = PR[4], m20 = PR[5], m30 = PR[6], m21 = PR[7], m31 = PR[8], m32 = PR[9];
+    const double d1 = PR[10], u21 = PR[11], d2 = PR[12], u31 = PR[13], u32 = PR[14], d3 = PR[15];
+    // one thread per row: the row's four panel entries through the pivot block
+    if (tid < ROWS) {
+      const bool trow = WITH_T && tid >= NB;
+      const int r = trow ? tid - NB : tid;
+      const double* X = (trow ? Tl : D) + r * LD + j0;
+      const bool live = trow ? (r < j0 + 4) : (r >= j0 + 4);
+      double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
+      if (live) {
+        x0 = X[0];
+        x1 = X[1] - x0 * m10;
+        x2 = (X[2] - x0 * m20) - x1 * m21;
+        x3 = ((X[3] - x0 * m30) - x1 * m31) - x2 * m32;
+      }
+      double* Ur = U + tid * 4;
+      double* Vr = V + tid * 4;
+      Ur[0] = x0; Ur[1] = x1; Ur[2] = x2; Ur[3] = x3;
+      Vr[0] = x0 * r0; Vr[1] = x1 * r1; Vr[2] = x2 * r2; Vr[3] = x3 * r3;
+    }
+    __syncthreads();                               // panel in place; everybody has read the record
+    const int jn = j0 + 4;                         // first column of the NEXT pivot block
+    if (wave == 3) {
+      if (jn < NB) {
+        // next pivot block: apply this step's rank-4 update to its 10 entries (as the trailing update does), store, chain
+        double q[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b <= a; ++b) {
+            const double* Ua = U + (jn + a) * 4;
+            const double* Vb = V + (jn + b) * 4;
+            double v = D[(jn + a) * LD + jn + b];
+            v -= Ua[0] * Vb[0]; v -= Ua[1] * Vb[1]; v -= Ua[2] * Vb[2]; v -= Ua[3] * Vb[3];
+            q[a][b] = v;
+          }
+        if ((tid & 63) == 0) {
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b <= a; ++b) D[(jn + a) * LD + jn + b] = q[a][b];
+        }
+        chain(q[0][0], q[1][0], q[1][1], q[2][0], q[2][1], q[2][2], q[3][0], q[3][1], q[3][2], q[3][3]);
+      }
+    } else {
+      // rank-4 trailing update (columns beyond the panel; the next pivot block belongs to the other wavefront)
+      if (c >= jn) {
+        const double v0 = V[c * 4], v1 = V[c * 4 + 1], v2 = V[c * 4 + 2], v3 = V[c * 4 + 3];
+#pragma unroll
+        for (int m = 0; m < CNT; ++m) {
+          const int i = i0 + STRIDE * m;
+          if (i < NB && i >= c && !(i < jn + 4 && c < jn + 4)) {
+            const double* Ui = U + i * 4;
+            double a = D[i * LD + c];
+            a -= Ui[0] * v0; a -= Ui[1] * v1; a -= Ui[2] * v2; a -= Ui[3] * v3;
+            D[i * LD + c] = a;
+          }
+          if (WITH_T && i < NB && i < jn) {
+            const double* Ui = U + (NB + i) * 4;
+            double a = Tl[i * LD + c];
+            a -= Ui[0] * v0; a -= Ui[1] * v1; a -= Ui[2] * v2; a -= Ui[3] * v3;
+            Tl[i * LD + c] = a;
+          }
+        }
+      }
+      // the panel columns themselves: rows below the pivot block get u_rt; the pivot block its own entries
+      if (tid < ROWS) {
+        const bool trow = WITH_T && tid >= NB;
+        const int r = trow ? tid - NB : tid;
+        double* X = (trow ? Tl : D) + r * LD + j0;
+        const double* Ur = U + tid * 4;
+        if (trow ? (r < j0 + 4) : (r >= j0 + 4)) { X[0] = Ur[0]; X[1] = Ur[1]; X[2] = Ur[2]; X[3] = Ur[3]; }
+      }
+      if (tid == 0) {
+        double* Pw = D + j0 * LD + j0;
+        Pw[LD + 1] = d1; Pw[2 * LD + 1] = u21; Pw[2 * LD + 2] = d2; Pw[3 * LD + 1] = u31; Pw[3 * LD + 2] = u32; Pw[3 * LD + 3] = d3;
+      }
+    }
+  }
+  __syncthreads();
+  // scale column c by 1/sqrt(d_c): all 256 threads again
+  constexpr int STRIDE2 = 256 / NB, CNT2 = NB / STRIDE2;
+  const int c2 = tid % NB, i02 = tid / NB;
+  const double dc = D[c2 * LD + c2];
+  const double sd = sqrt((dc > 0.0) ? dc : 1.0);
+  const double rs = 1.0 / sd;
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < CNT2; ++m) {
+    const int i = i02 + STRIDE2 * m;
+    if (i > c2) D[i * LD + c2] *= rs;
+    else if (i == c2) { D[i * LD + c2] = sd; rdiag[c2] = rs; }
+    if (WITH_T && i <= c2) Tl[i * LD + c2] *= rs;
+  }
+  if (bad && (tid & 63) == 0 && fail_flag) *fail_flag = 1;
+  __syncthreads();
+}
+
 // One double of lane `src` (compile-time constant after unrolling) as a wave-uniform value: two v_readlane_b32.
 __device__ __forceinline__ double readlane_f64(double v, int src) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -756,10 +913,15 @@ __device__ __forceinline__ void mm32_lds(FA opA, FB opB, FO out) {
 // Tl, as two 32 x 32 factorisations (factor_diag_lds4) glued by four small matrix-core products:
 //   L21 = D21 T11,  D22 -= L21 L21^T,  T12 = -T11 (L21^T T22).
 // (One 64-wide factor_diag_lds4 was measured at 40 us: its rank-4 trailing updates are LDS-issue bound.)
+#ifdef VGG_CHOL_LOOKAHEAD                          // opt-in experiment (measured slower, see factor_diag_lds4_la)
+#define FACTOR32(Dp, Tp, rdp, scrp, failp) factor_diag_lds4_la<H, true, LD>(Dp, Tp, rdp, scrp, failp)
+#else
+#define FACTOR32(Dp, Tp, rdp, scrp, failp) factor_diag_lds4<H, true, LD>(Dp, Tp, rdp, scrp, failp)
+#endif
 __device__ __forceinline__ void factor64(double* D, double* Tl, double* rd, double* scr, int32_t* fail) {
   constexpr int LD = DFB + 1, H = 32;
   const int tid = threadIdx.x;
-  factor_diag_lds4<H, true, LD>(D, Tl, rd, scr, fail);
+  FACTOR32(D, Tl, rd, scr, fail);
   double v[4];
   int vi[4], vj[4], cnt = 0;
   mm32_lds([&](int i, int k) { return D[(H + i) * LD + k]; }, [&](int j, int k) { return Tl[k * LD + j]; },
@@ -771,7 +933,7 @@ __device__ __forceinline__ void factor64(double* D, double* Tl, double* rd, doub
   __syncthreads();
   mm32_lds([&](int i, int k) { return D[(H + i) * LD + k]; }, [&](int j, int k) { return D[(H + j) * LD + k]; },
            [&](int i, int j, double x) { if (j <= i) D[(H + i) * LD + H + j] -= x; });
-  factor_diag_lds4<H, true, LD>(D + H * LD + H, Tl + H * LD + H, rd + H, scr, fail);
+  FACTOR32(D + H * LD + H, Tl + H * LD + H, rd + H, scr, fail);
   double* W = scr;                                       // 32 x 32
   mm32_lds([&](int i, int k) { return D[(H + k) * LD + i]; }, [&](int j, int k) { return Tl[(H + k) * LD + H + j]; },
            [&](int i, int j, double x) { W[i * H + j] = x; });

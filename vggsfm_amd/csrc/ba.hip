@@ -424,12 +424,18 @@ __global__ __launch_bounds__(256, (MODE == 1) ? VGG_CP_OCC_RHS : VGG_CP_OCC) voi
 
 // sums the `split` slices of a camera in order and stores U, g, cost (MODE 0) or T (MODE 1)
 template <int KD, int MODE>
-__global__ __launch_bounds__(64) void cam_reduce_kernel(DevProblem pb, Ws w, int split) {
+__global__ __launch_bounds__(64) void cam_reduce_kernel(DevProblem pb, Ws w, int split, int point_parts) {
   constexpr int BD = 6 + KD;
   constexpr int NU = BD * (BD + 1) / 2;
   constexpr int NV = (MODE == 0) ? (NU + BD + 1) : (BD * (1 + KD));
   if (w.ctl->done) return;
   if (MODE == 0 && !w.ctl->need_lin) return;
+  if (MODE == 1 && blockIdx.x == 0) {            // (rides along: max of the point passes' per-workgroup gradient norms)
+    double m = 0;
+    for (int i = threadIdx.x; i < point_parts; i += 64) m = fmax(m, w.part_B[i]);
+    m = wave_max(m);
+    if (threadIdx.x == 0) w.gmax_pts[0] = m;
+  }
   const Dims& d = pb.d;
   const int c = blockIdx.x, kdsh = d.kdsh;
   if (threadIdx.x >= NV) return;
@@ -457,11 +463,9 @@ __global__ __launch_bounds__(64) void cam_reduce_kernel(DevProblem pb, Ws w, int
 
 // after (the all-reduce of) buffer 0: column norms, Jacobi scaling (first time), camera-side gradient max, cost
 template <int KD>
-__global__ __launch_bounds__(256) void prep_kernel(DevProblem pb, Ws w, vgg_ba_options opt) {
+__device__ __forceinline__ void prep_body(const DevProblem& pb, const Ws& w, const vgg_ba_options& opt, double* red) {
   constexpr int BD = 6 + KD;
-  __shared__ double red[256];
   Ctl* ctl = w.ctl;
-  if (ctl->done || !ctl->need_lin) return;
   const Dims& d = pb.d;
   const bool first = !ctl->scale_ready;
   double gmax = 0.0, cost = 0.0;
@@ -511,15 +515,24 @@ __global__ __launch_bounds__(256) void prep_kernel(DevProblem pb, Ws w, vgg_ba_o
   }
 }
 
-// LM damping of the reduced columns for the current radius
-__global__ void damping_kernel(Ws w, vgg_ba_options opt, int n_red) {
-  if (w.ctl->done) return;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n_red) return;
-  const double s = w.scale_c[j];
-  double dd = w.colsq_c[j] * s * s;
-  dd = fmin(fmax(dd, opt.min_lm_diagonal), opt.max_lm_diagonal);
-  w.dsq_c[j] = dd / w.ctl->radius;
+
+// after (the all-reduce of) buffer 0: prep_body when a new linearisation is in place, then -- every iteration -- the LM
+// damping of the reduced columns for the current radius (one launch: both are a few hundred elements)
+template <int KD>
+__global__ __launch_bounds__(256) void prep_kernel(DevProblem pb, Ws w, vgg_ba_options opt) {
+  __shared__ double red[256];
+  Ctl* ctl = w.ctl;
+  if (ctl->done) return;
+  if (ctl->need_lin) prep_body<KD>(pb, w, opt, red);       // (uniform branch: the body synchronises the workgroup)
+  __syncthreads();
+  const int n_red = pb.d.n_red;
+  const double radius = ctl->radius;
+  for (int j = threadIdx.x; j < n_red; j += 256) {
+    const double sc = w.scale_c[j];
+    double dd = w.colsq_c[j] * sc * sc;
+    dd = fmin(fmax(dd, opt.min_lm_diagonal), opt.max_lm_diagonal);
+    w.dsq_c[j] = dd / radius;
+  }
 }
 
 // VGG_SPLIT_POINT_PASS=1 in the environment selects the split form of the point pass -- wave-per-point reductions without
@@ -842,20 +855,9 @@ __global__ __launch_bounds__(256, 4) void y_write_kernel(DevProblem pb, Ws w) {
   }
 }
 
-__global__ __launch_bounds__(256) void reduce_gmax_kernel(Ws w, int nparts) {
-  __shared__ double red[256];
-  if (w.ctl->done) return;
-  double m = 0;
-  for (int i = threadIdx.x; i < nparts; i += 256) m = fmax(m, w.part_B[i]);
-  red[threadIdx.x] = m; __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]); __syncthreads(); }
-  if (threadIdx.x == 0) w.gmax_pts[0] = red[0];
-}
-
 // start-of-iteration checks (Ceres FinalizeIterationAndCheckIfMinimizerCanContinue)
-__global__ void begin_iteration_kernel(Ws w, vgg_ba_options opt) {
+__device__ __forceinline__ void begin_iteration(const Ws& w, const vgg_ba_options& opt) {
   Ctl* c = w.ctl;
-  if (c->done) return;
   if (c->need_lin) {
     c->gmax = fmax(c->gmax_cams, w.gmax_pts[0]);
     w.log[c->iteration].gradient_max_norm = c->gmax;
@@ -872,6 +874,19 @@ __global__ void begin_iteration_kernel(Ws w, vgg_ba_options opt) {
   c->scale_ready = 1;
   c->need_lin = 0;
   c->iteration += 1;
+}
+
+
+// one workgroup: thread 0 runs the checks; then the constant / unobserved columns of the reduced system get a unit
+// diagonal and a zero right-hand side (their Jacobian columns are zero)
+__global__ __launch_bounds__(256) void begin_iteration_kernel(Ws w, vgg_ba_options opt, int n) {
+  if (w.ctl->done) return;
+  if (threadIdx.x == 0) begin_iteration(w, opt);
+  for (int j = threadIdx.x; j < n; j += 256) {
+    if (w.active[j]) continue;
+    w.S[(size_t)j * n + j] = 1.0;
+    w.rhs[j] = 0.0;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1534,15 +1549,6 @@ __global__ __launch_bounds__(64) void assemble_kernel(DevProblem pb, Ws w) {
   }
 }
 
-// constant / unobserved columns: unit diagonal, zero right-hand side (their Jacobian columns are zero)
-__global__ void fix_constant_kernel(Ws w, int n) {
-  if (w.ctl->done) return;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n || w.active[j]) return;
-  w.S[(size_t)j * n + j] = 1.0;
-  w.rhs[j] = 0.0;
-}
-
 // ---------------------------------------------------------------------------------------------
 // candidate cameras: x (+) (-s o y); also the camera-side part of |step| and |x|
 template <int KD>
@@ -1759,7 +1765,7 @@ __global__ __launch_bounds__(256) void reduce_step_kernel(Ws w, int nparts) {
 // Ceres' trust-region decision (TrustRegionMinimizer::Minimize body + LevenbergMarquardtStrategy)
 __global__ __launch_bounds__(64) void control_kernel(Ws w, vgg_ba_options opt, int C) {
   Ctl* c = w.ctl;
-  if (c->done) return;
+  if (c->done) { if (threadIdx.x == 0) c->accept = 0; return; }   // (no-op iterations behind the end must not commit again)
   double step_c = 0, xn_c = 0;
   for (int i = threadIdx.x; i <= C; i += 64) { step_c += w.cam_part[2 * i]; xn_c += w.cam_part[2 * i + 1]; }
   step_c = wave_sum(step_c); xn_c = wave_sum(xn_c);
@@ -1819,7 +1825,6 @@ __global__ void commit_kernel(Ws w, double* cam_q, double* cam_t, double* intr, 
   if (i < (size_t)3 * C) cam_t[i] = w.cand_t[i];
   if (i < (size_t)4 * NI) intr[i] = w.cand_intr[i];
 }
-__global__ void clear_accept_kernel(Ws w) { if (w.ctl->done) w.ctl->accept = 0; }
 
 // ---------------------------------------------------------------------------------------------
 // host side
@@ -1885,7 +1890,7 @@ static void phase_linearize(const Launch& L) {
   ProfScope ps(kProfLinearize, L.st);
   const int split = cam_split_for(L.d.C, L.d.O);
   cam_pass_kernel<KD, 0><<<dim3(L.d.C, split), 256, 0, L.st>>>(L.dp, L.w);
-  cam_reduce_kernel<KD, 0><<<L.d.C, 64, 0, L.st>>>(L.dp, L.w, split);
+  cam_reduce_kernel<KD, 0><<<L.d.C, 64, 0, L.st>>>(L.dp, L.w, split, 0);
 }
 
 // one batch of Schur tiles: the off-diagonal launch, the diagonal launch, and the ordered sum of their chunks into
@@ -1973,7 +1978,6 @@ template <int KD>
 static void phase_schur(const Launch& L) {
   const Dims& d = L.d;
   prep_kernel<KD><<<1, 256, 0, L.st>>>(L.dp, L.w, L.opt);
-  damping_kernel<<<div_up(d.n_red, 256), 256, 0, L.st>>>(L.w, L.opt, d.n_red);
   {
     ProfScope ps(kProfPointPass, L.st);
     // cameras (q, t, pose scales, constant flags: 14 doubles each) cached in LDS when they fit beside 2 workgroups/CU
@@ -1998,12 +2002,11 @@ static void phase_schur(const Launch& L) {
       else launch(std::integral_constant<int, 64>{});
     }
   }
-  reduce_gmax_kernel<<<1, 256, 0, L.st>>>(L.w, L.wgB);
   {
     ProfScope ps(kProfCamRhs, L.st);
     const int split = cam_split_for(d.C, d.O);
     cam_pass_kernel<KD, 1><<<dim3(d.C, split), 256, 0, L.st>>>(L.dp, L.w);
-    cam_reduce_kernel<KD, 1><<<d.C, 64, 0, L.st>>>(L.dp, L.w, split);
+    cam_reduce_kernel<KD, 1><<<d.C, 64, 0, L.st>>>(L.dp, L.w, split, L.wgB);
   }
   (void)hipMemsetAsync(L.w.sys, 0, sizeof(double) * L.w.sys_count, L.st);
   if (L.num_chunks > 0) {
@@ -2021,8 +2024,7 @@ static void phase_schur(const Launch& L) {
 template <int KD>
 static int phase_step(const Launch& L) {
   const Dims& d = L.d;
-  begin_iteration_kernel<<<1, 1, 0, L.st>>>(L.w, L.opt);
-  fix_constant_kernel<<<div_up(d.n_red, 256), 256, 0, L.st>>>(L.w, d.n_red);
+  begin_iteration_kernel<<<1, 256, 0, L.st>>>(L.w, L.opt, d.n_red);
   int rc;
   if (OverlapCtx* oc = overlap_ctx(L)) {
     (void)hipMemsetAsync(L.w.batch_flags, 0, 64, L.st);
@@ -2081,7 +2083,6 @@ static void phase_update(const Launch& L) {
   if ((size_t)4 * d.C > nmax) nmax = (size_t)4 * d.C;
   if ((size_t)4 * d.NI > nmax) nmax = (size_t)4 * d.NI;
   commit_kernel<<<div_up((long)nmax, 256), 256, 0, L.st>>>(L.w, L.cam_q, L.cam_t, L.intr, L.pts, d.C, d.NI, d.P);
-  clear_accept_kernel<<<1, 1, 0, L.st>>>(L.w);
 }
 
 static int make_launch(const vgg_ba_problem* pb, const vgg_ba_options* opt, void* workspace, hipStream_t st, Launch* L) {

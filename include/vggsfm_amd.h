@@ -186,6 +186,11 @@ typedef struct {
                                    tile_desc   [num_tiles,4] = superI, superJ, chunk_begin, chunk_end
                                    tile_batches one row (0, 0, num_chunks, 0, num_tiles, 0); block_chunk unused */
   const int32_t* quad_mask;
+  const int32_t* tile_sched;     /* device, optional: explicit BATCH SCHEDULE of the 16-camera tile chunks.  When set, fields 4 and 5
+                                 of a chunk_desc row are (offset into tile_sched, number of batches) instead of (j, J), and batch b
+                                 of the chunk multiplies the quad tile_sched[offset + b] of its tile (quad q = entries
+                                 tile_entry_begin + 4 q .. + 3).  Every quad of a tile must appear in exactly one of its chunks.
+                                 The host side uses it to walk the points range by range on every XCD (ba.py: xcd_range_schedule) */
 } vgg_ba_problem;
 
 typedef struct {

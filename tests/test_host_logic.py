@@ -235,6 +235,46 @@ def test_supertile_list_covers_every_camera_pair_once(S, N, max_wgs, monkeypatch
     assert prob.quad_mask is None and prob.chunk_desc.shape[1] == 6 and prob.c_struct().super_tiles == 0
 
 
+def test_xcd_range_schedule_covers_every_quad_once():
+    """ba.xcd_range_schedule (opt-in batch schedule of the tile chunks): every quad of every tile appears in exactly one
+    chunk of that tile, chunks of a tile are consecutive, the launch map is a permutation inside each launch, the chunks at
+    the positions = x (mod 8) of a launch work on part x of the sweep, and inside a chunk the positions ascend."""
+    sc = make_scene(120, 6000, "SIMPLE_RADIAL", shared_camera=True, seed=3)
+    m = torch.from_numpy(sc.mask)
+    pm = torch.nonzero(m.t())
+    obs_cam = pm[:, 1].to(torch.int32)
+    row_ptr = torch.zeros(m.shape[1] + 1, dtype=torch.int32)
+    row_ptr[1:] = torch.cumsum(m.sum(0), 0).to(torch.int32)
+    cd, ent, td, slot, nseg, bd, bc = BA.build_schur_tiles(row_ptr, obs_cam, max_chunks=(96, 128))
+    res = BA.xcd_range_schedule(ent, cd, td, bd, (96, 128), range_points=64)
+    assert res is not None
+    ncd, ntd, nbd, nbc, sched = (t.numpy() for t in res)
+    e = ent.numpy()
+    c0, cm, c1 = (int(v) for v in nbd[0, :3])
+    assert c0 == 0 and c1 == len(ncd) and cm == 96 and c1 - cm == 128
+    assert sorted(nbc[:cm].tolist()) == list(range(cm)) and sorted(nbc[cm:].tolist()) == list(range(cm, c1))
+    for gI, gJ, a, b in ntd:
+        tb, te = ncd[a, 2], ncd[a, 3]
+        seen = np.zeros((te - tb + 3) // 4, int)
+        for c in range(a, b):
+            assert ncd[c, 0] == gI and ncd[c, 1] == gJ and ncd[c, 2] == tb and ncd[c, 3] == te
+            q = sched[ncd[c, 4]:ncd[c, 4] + ncd[c, 5]]
+            seen[q] += 1
+            assert (np.diff(e[tb + 4 * q, 0]) > 0).all()                 # ascending sweep positions inside a chunk
+        assert (seen == 1).all()
+    assert ntd[0, 2] == 0 and ntd[-1, 3] == len(ncd) and (ntd[1:, 2] == ntd[:-1, 3]).all()
+    # position p of the off-diagonal launch: part p % 8 -- the position ranges of different residues do not interleave
+    span = {}
+    for p in range(cm):
+        c = nbc[p]
+        q = sched[ncd[c, 4]:ncd[c, 4] + ncd[c, 5]]
+        pos = e[ncd[c, 2] + 4 * q, 0]
+        lo, hi = span.get(p % 8, (pos.min(), pos.max()))
+        span[p % 8] = (min(lo, pos.min()), max(hi, pos.max()))
+    order = sorted(span.values())
+    assert all(order[i][1] <= order[i + 1][0] + 3 for i in range(len(order) - 1))      # (quads straddle a cut by < 4 positions)
+
+
 @pytest.mark.parametrize("xcds", [1, 8])
 @pytest.mark.parametrize("num_batches", [1, 2, 3])
 @pytest.mark.parametrize("max_chunks", [1, 7, 40, 100000])

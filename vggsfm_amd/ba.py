@@ -118,6 +118,7 @@ class DeviceProblem:
     block_chunk: Optional[torch.Tensor] = None      # (num_chunks,) int32 device: launch position -> chunk (XCD placement; None = identity)
     obs_pt: Optional[torch.Tensor] = None           # (O,) int32 device: point of every point-major observation (None = fused Y pass)
     quad_mask: Optional[torch.Tensor] = None        # (Q,2) int32 device: set <=> chunk_desc / entries / tile_desc are SUPER-TILES
+    tile_sched: Optional[torch.Tensor] = None       # (B,) int32 device: batch schedule of the tile chunks (xcd_range_schedule)
 
     @property
     def num_obs(self):
@@ -130,7 +131,7 @@ class DeviceProblem:
         P.camera_model, P.refine_focal, P.refine_extra = self.camera_model, int(self.refine_focal), int(self.refine_extra)
         P.loss, P.loss_scale = self.loss, self.loss_scale
         for name in ("cam_q", "cam_t", "intr", "pts", "row_ptr", "obs_cam", "obs_uv", "col_ptr", "cobs_pt", "cobs_uv",
-                     "cam_const", "intr_const", "pt_const", "chunk_desc", "entries", "tile_desc", "obs_slot", "obs_pt", "quad_mask"):
+                     "cam_const", "intr_const", "pt_const", "chunk_desc", "entries", "tile_desc", "obs_slot", "obs_pt", "quad_mask", "tile_sched"):
             t = getattr(self, name)
             setattr(P, name, None if t is None else t.data_ptr())
         P.num_chunks = self.chunk_desc.shape[0]
@@ -327,6 +328,112 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     block_chunk = torch.tensor(block_chunk, dtype=torch.int32, device=dev)
     return (chunk_desc.contiguous(), entries.contiguous(), tile_desc.contiguous(), obs_slot.contiguous(), int(nseg),
             batch_desc.contiguous(), block_chunk)
+
+
+XCD_SCHEDULE = os.environ.get("VGGSFM_XCD_SCHEDULE", "0") == "1"   # opt-in: xcd_range_schedule for large single-batch problems
+XCD_RANGE_POINTS = 128
+
+
+def xcd_range_schedule(entries, chunk_desc, tile_desc, batch_desc, wgs, range_points=XCD_RANGE_POINTS, xcds=8):
+    """Explicit batch schedule of the 16-camera tile chunks (`vgg_ba_problem.tile_sched`): every XCD walks ITS eighth of
+    the points RANGE BY RANGE with all the tiles those points touch, so that the re-reads of a segment by the tiles that
+    need it meet in that XCD's L2 instead of coming through the fabric once per tile.
+
+    Workgroup b of a launch runs on XCD b % 8 and the workgroups of an XCD are dispatched in order.  For each launch
+    (off-diagonal tiles, diagonal tiles; `wgs` = (workgroups of the off-diagonal launch, of the diagonal launch), multiples
+    of `xcds`): the quads (four consecutive entries, aligned to the tile's begin) are cut by sweep position into `xcds`
+    parts of equal size; inside part x every tile with quads gets a workgroup and the rest go one by one to the tile with
+    the most quads per workgroup; the part's position interval is cut into ranges of `range_points` positions and the quads of
+    (tile, range) are dealt round-robin to the tile's workgroups -- every workgroup of the XCD therefore works on range r
+    at about the same time.  Returns (chunk_desc (n,6) = gI, gJ, tile_entry_begin, tile_entry_end, sched offset, batches;
+    tile_desc; batch_desc; block_chunk; sched (int32)) or None when a part touches more tiles than it has workgroups."""
+    import numpy as np
+    dev = entries.device
+    ent = entries.cpu().numpy()
+    cd = chunk_desc.cpu().numpy()
+    td = tile_desc.cpu().numpy()
+    bd = batch_desc.numpy()
+    if bd.shape[0] != 1:
+        return None
+    new_cd, new_td, sched_all, block_chunk = [], [], [], []
+    first_diag_chunk = None
+    sched_off = 0
+    for diag, W_total in ((False, wgs[0]), (True, wgs[1])):
+        tiles = [t for t in range(td.shape[0]) if (td[t, 0] == td[t, 1]) == diag]
+        if diag:
+            first_diag_chunk = len(new_cd)
+        if not tiles:
+            continue
+        W = max(1, W_total // xcds)
+        tb = np.array([cd[td[t, 2], 2] for t in tiles]); te = np.array([cd[td[t, 2], 3] for t in tiles])
+        nq = (te - tb + 3) // 4
+        qtile = np.repeat(np.arange(len(tiles)), nq)
+        qloc = np.arange(nq.sum()) - np.repeat(np.cumsum(nq) - nq, nq)
+        qpos = ent[tb[qtile] + 4 * qloc, 0].astype(np.int64)
+        # parts of equal quad counts by position
+        order = np.argsort(qpos, kind="stable")
+        cuts = qpos[order[(np.arange(1, xcds) * len(order)) // xcds]]
+        part = np.searchsorted(cuts, qpos, side="right")
+        part_lo = np.concatenate([[qpos.min()], cuts])
+        rng = (qpos - part_lo[part]) // range_points
+        # workgroups per (tile, part): largest remainder, at least one for a tile with quads in the part
+        cnt = np.zeros((len(tiles), xcds), np.int64)
+        np.add.at(cnt, (qtile, part), 1)
+        J = np.zeros_like(cnt)
+        for x in range(xcds):
+            act = np.nonzero(cnt[:, x])[0]
+            if len(act) == 0:
+                continue
+            if len(act) > W:
+                return None
+            # one workgroup each, then the rest one by one to the tile with the most quads per workgroup (minimises the
+            # largest load; a proportional rounding left single workgroups with twice the average)
+            import heapq
+            j = np.ones(len(act), np.int64)
+            heap = [(-float(cnt[a, x]), k) for k, a in enumerate(act)]
+            heapq.heapify(heap)
+            for _ in range(W - len(act)):
+                _, k = heapq.heappop(heap)
+                j[k] += 1
+                heapq.heappush(heap, (-float(cnt[act[k], x]) / j[k], k))
+            J[act, x] = j
+        # rank of a quad inside its (tile, part, range) run (quads of a tile are ascending in position)
+        key = (qtile * xcds + part) * (rng.max() + 1) + rng
+        run_start = np.concatenate([[True], key[1:] != key[:-1]])
+        rank = np.arange(len(key)) - np.maximum.accumulate(np.where(run_start, np.arange(len(key)), 0))
+        wg = (rank + rng) % J[qtile, part]
+        # chunk id: tile-major, then part, then workgroup
+        chunk_of = np.cumsum(J.reshape(-1)) - J.reshape(-1)               # first chunk of (tile, part)
+        cid = chunk_of[qtile * xcds + part] + wg
+        nchunks = int(J.sum())
+        o2 = np.argsort(cid, kind="stable")                                # positions ascending inside a chunk
+        nbat = np.bincount(cid, minlength=nchunks)
+        offs = np.cumsum(nbat) - nbat + sched_off
+        sched_all.append(qloc[o2].astype(np.int32))
+        sched_off += len(o2)
+        base = len(new_cd)
+        ct = np.repeat(np.arange(len(tiles)), J.sum(1))                     # tile of every chunk
+        for c in range(nchunks):
+            t = tiles[ct[c]]
+            new_cd.append([td[t, 0], td[t, 1], tb[ct[c]], te[ct[c]], offs[c], nbat[c]])
+        first = np.cumsum(J.sum(1)) - J.sum(1)
+        for k, t in enumerate(tiles):
+            new_td.append([td[t, 0], td[t, 1], base + first[k], base + first[k] + J[k].sum()])
+        # launch position p -> chunk: XCD p % xcds takes the workgroups of part p % xcds in tile order
+        cpart = np.concatenate([np.repeat(np.arange(xcds), J[k]) for k in range(len(tiles))])
+        lists = [list(base + np.nonzero(cpart == x)[0]) for x in range(xcds)]
+        heads = [0] * xcds
+        for pos in range(nchunks):
+            x = pos % xcds
+            if heads[x] >= len(lists[x]):
+                x = max(range(xcds), key=lambda y: len(lists[y]) - heads[y])
+            block_chunk.append(lists[x][heads[x]])
+            heads[x] += 1
+    n = len(new_cd)
+    i32 = lambda a: torch.tensor(np.asarray(a, dtype=np.int32).reshape(len(a), -1) if len(a) else np.zeros((0, 6), np.int32), dtype=torch.int32, device=dev)
+    batch = torch.tensor([[0, first_diag_chunk if first_diag_chunk is not None else n, n, 0, len(new_td), 0]], dtype=torch.int32)
+    sched = torch.from_numpy(np.concatenate(sched_all)).to(dev)
+    return (i32(new_cd).contiguous(), i32(new_td).contiguous(), batch, torch.tensor(block_chunk, dtype=torch.int32, device=dev), sched.contiguous())
 
 
 SUPER_BATCH_OVERHEAD = 12.0  # cost of a batch besides its matrix instructions, in matrix instructions of one SIMD (barrier, operand fetch)
@@ -689,9 +796,15 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
     else:
         chunk_desc, entries, tile_desc, obs_slot, nseg, batch_desc, block_chunk = build_schur_tiles(
             row_ptr, obs_cam, max_chunks=slots, num_batches=nb, later_scale=(cus - CHOL_CUS) / cus)
+    tile_sched = None
+    if XCD_SCHEDULE and quad_mask is None and nb == 1 and int(obs_cam.shape[0]) >= OVERLAP_MIN_OBS:
+        res = xcd_range_schedule(entries, chunk_desc, tile_desc, batch_desc, (slots[0] // 8 * 8, slots[1] // 8 * 8))
+        if res is not None:
+            chunk_desc, tile_desc, batch_desc, block_chunk, tile_sched = res
     prob = DeviceProblem(cam_q, cam_t, intr, pts, row_ptr, obs_cam, obs_uv, col_ptr, cobs_pt, cobs_uv, chunk_desc,
                          entries, tile_desc, obs_slot, nseg, MODEL_ID[camera_type], cam_const=cam_const,
                          batch_desc=batch_desc, chol_split=chol_split, cam_perm=cam_perm, block_chunk=block_chunk, quad_mask=quad_mask,
+                         tile_sched=tile_sched,
                          obs_pt=pm[:, 0].to(torch.int32).contiguous())
     if first_group is not None:
         kd = 2 if camera_type == "SIMPLE_RADIAL" else 1              # upper bound of the intrinsics unknowns per block

@@ -924,7 +924,8 @@ __device__ __forceinline__ uint32_t block_slot_bits(int blk) {
 template <int BD, bool DIAG>
 __global__ __launch_bounds__(256, (BD == 6 ? (DIAG ? 4 : VGG_OFFDIAG_OCC) : 2)) void schur_tile_kernel(Ws w, const int32_t* __restrict__ chunk_desc,
                                                          const int32_t* __restrict__ entries, int chunk0, int zero_seg,
-                                                         const int32_t* __restrict__ block_chunk) {
+                                                         const int32_t* __restrict__ block_chunk,
+                                                         const int32_t* __restrict__ sched) {
   constexpr int YS = BD * 3;                      // doubles per Y block
   constexpr int SEG = kGroup * YS;                // doubles per segment (16 slots)
   constexpr int R = kGroup * BD;                  // rows / cols of the tile
@@ -950,8 +951,14 @@ __global__ __launch_bounds__(256, (BD == 6 ? (DIAG ? 4 : VGG_OFFDIAG_OCC) : 2)) 
   const int cj = chunk_desc[6 * chunk + 4], cJ = chunk_desc[6 * chunk + 5];
   constexpr int BPS = kSub / 4;                   // batches of 4 entries per sub-chunk
   const int nsub = (e1 - e0 + kSub - 1) / kSub;
-  const int nb = ((nsub - cj + cJ - 1) / cJ) * BPS;             // batches of this workgroup
-  auto ebase = [&](int b) -> int { return e0 + ((b / BPS) * cJ + cj) * kSub + (b % BPS) * 4; };
+  // With a batch schedule (vgg_ba_problem.tile_sched) fields 4, 5 of the chunk are (offset into sched, number of batches)
+  // and batch b of the workgroup is the quad sched[offset + b] of its tile -- any order the host wants; batches past the
+  // end point behind the tile's list (zero segments).
+  const int nb = sched ? cJ : ((nsub - cj + cJ - 1) / cJ) * BPS;             // batches of this workgroup
+  auto ebase = [&](int b) -> int {
+    if (sched) return (b < nb) ? e0 + 4 * sched[cj + b] : e1;
+    return e0 + ((b / BPS) * cJ + cj) * kSub + (b % BPS) * 4;
+  };
   f64x4_t acc[NH][NH];
 #pragma unroll
   for (int i = 0; i < NH; ++i)
@@ -1854,6 +1861,7 @@ struct Launch {
   int lpp;                                      // lanes per point of the point passes: 16, 32 or 64 (lanes_per_point)
   const int32_t* chunk_desc; const int32_t* entries; int num_chunks, num_segments;
   const int32_t* block_chunk;                   // launch position -> chunk (XCD placement) or NULL
+  const int32_t* tile_sched;                    // batch schedule of the tile chunks (vgg_ba_problem.tile_sched) or NULL
   int super_tiles; const int32_t* quad_mask;    // 2 x 2 super-tiles (vgg_ba_problem.super_tiles)
   const int32_t* tile_desc; int num_tiles;
   const int32_t* batches; int num_batches;      // HOST table [num_batches][6], see vgg_ba_problem.tile_batches
@@ -1916,11 +1924,11 @@ static void launch_schur_batch(const Launch& L, int batch, hipStream_t st, doubl
   }
   if (cm > c0) {
     ProfScope ps(kProfSchurTile, st);
-    schur_tile_kernel<BD, false><<<cm - c0, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, c0, L.num_segments, L.block_chunk);
+    schur_tile_kernel<BD, false><<<cm - c0, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, c0, L.num_segments, L.block_chunk, L.tile_sched);
   }
   if (c1 > cm) {
     ProfScope ps(kProfSchurTileDiag, st);
-    schur_tile_kernel<BD, true><<<c1 - cm, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, cm, L.num_segments, L.block_chunk);
+    schur_tile_kernel<BD, true><<<c1 - cm, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, cm, L.num_segments, L.block_chunk, L.tile_sched);
   }
   if (t1 > t0)
     tile_reduce_kernel<BD><<<dim3(div_up(kGroup * BD * kGroup * BD, 256), t1 - t0), 256, 0, st>>>(L.w, L.d.n_red, L.d.C, L.d.kd,
@@ -2100,6 +2108,7 @@ static int make_launch(const vgg_ba_problem* pb, const vgg_ba_options* opt, void
   L->wgB = min(max(div_up(L->d.P, 4 * (64 / L->lpp)), 1), g_tuning.point_wgs > 0 ? min(g_tuning.point_wgs, kMaxWG) : 1024);
   L->chunk_desc = pb->chunk_desc; L->entries = pb->entries; L->num_chunks = pb->num_chunks;
   L->block_chunk = pb->block_chunk;
+  L->tile_sched = pb->tile_sched;
   L->super_tiles = pb->super_tiles; L->quad_mask = pb->quad_mask;
   if (pb->super_tiles && (!pb->quad_mask || pb->num_tile_batches != 1 || !(L->d.shared || L->d.kd == 0))) return VGG_ERR_INVALID_ARGUMENT;
   L->num_segments = pb->num_segments;

@@ -249,6 +249,29 @@ def test_ba_launch_variants_agree(S, N, cam, shared):
         L.vgg_ba_tuning(0, -1, 0, 0)
 
 
+@pytest.mark.parametrize("shared,cam", [(True, "SIMPLE_RADIAL"), (False, "SIMPLE_PINHOLE")])
+def test_ba_xcd_schedule_matches_default(monkeypatch, shared, cam):
+    """The opt-in explicit batch schedule of the tile chunks (ba.XCD_SCHEDULE: every XCD walks its part of the points range
+    by range) against the default strided sub-chunks: same trajectory to rounding (only the order of the sums changes)."""
+    sc = make_scene(160, 8000, cam, shared_camera=shared, seed=29)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=29)
+    opt = BundleAdjustmentOptions()
+    opt.solver_options.max_num_iterations = 10
+
+    def solve():
+        return BA.bundle_adjustment(D(pts0), D(ext0), D(K0), D(sc.tracks), D(sc.mask), None, D(extra0), shared, cam, opt)
+    ref = solve()
+    monkeypatch.setattr(BA, "XCD_SCHEDULE", True)
+    monkeypatch.setattr(BA, "OVERLAP_MIN_OBS", 1000)
+    monkeypatch.setattr(BA, "SUPER_TILES", False)
+    a = solve()
+    assert a[4]["num_iterations"] == ref[4]["num_iterations"]
+    assert abs(a[4]["final_cost"] - ref[4]["final_cost"]) <= 1e-9 * ref[4]["final_cost"]
+    for x, y in zip(a[:4], ref[:4]):
+        if x is not None:
+            np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-7, atol=1e-7)
+
+
 def test_cholesky_flags_indefinite():
     A = np.eye(40)
     A[17, 17] = -1.0

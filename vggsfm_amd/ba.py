@@ -785,6 +785,8 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
     # resident schur_tile workgroups per CU (occupancy of the kernel variant): off-diagonal launch 3 (BD = 6) or 2,
     # diagonal launch 4 or 2 -- one full round each
     slots = (cus * 3, cus * 4) if shared_camera else (cus * 2, cus * 2)
+    if os.environ.get("VGGSFM_TILE_SLOTS"):         # experiment (with VGG_TILE_MERGED=1: one launch, the slots shared by both kinds)
+        slots = tuple(int(v) for v in os.environ["VGGSFM_TILE_SLOTS"].split(","))
     # three batches when the factorisation can overlap the later ones (enough camera groups, enough work per batch)
     overlap = OVERLAP_FACTORIZATION if overlap is None else bool(overlap)
     nb = TILE_BATCHES if (overlap and int(obs_cam.shape[0]) >= OVERLAP_MIN_OBS and S >= OVERLAP_MIN_FRAMES) else 1

@@ -560,6 +560,7 @@ static int lanes_per_point(int P, int O) {
 static bool long_tracks(int lpp, int P, int O) {
   return g_tuning.longt >= 0 ? g_tuning.longt != 0 : (double)O > 1.5 * lpp * (double)P;
 }
+static const bool g_tile_merged = [] { const char* e = getenv("VGG_TILE_MERGED"); return e && e[0] == '1'; }();   // experiment: one tile launch
 static const bool g_fused_point_pass = [] { const char* e = getenv("VGG_SPLIT_POINT_PASS"); return !(e && e[0] == '1'); }();
 
 // ---------------------------------------------------------------------------------------------
@@ -922,10 +923,9 @@ __device__ __forceinline__ uint32_t block_slot_bits(int blk) {
 }
 
 template <int BD, bool DIAG>
-__global__ __launch_bounds__(256, (BD == 6 ? (DIAG ? 4 : VGG_OFFDIAG_OCC) : 2)) void schur_tile_kernel(Ws w, const int32_t* __restrict__ chunk_desc,
-                                                         const int32_t* __restrict__ entries, int chunk0, int zero_seg,
-                                                         const int32_t* __restrict__ block_chunk,
-                                                         const int32_t* __restrict__ sched) {
+__device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __restrict__ chunk_desc,
+                                                const int32_t* __restrict__ entries, int chunk, int zero_seg,
+                                                const int32_t* __restrict__ sched, double* __restrict__ ops) {
   constexpr int YS = BD * 3;                      // doubles per Y block
   constexpr int SEG = kGroup * YS;                // doubles per segment (16 slots)
   constexpr int R = kGroup * BD;                  // rows / cols of the tile
@@ -937,8 +937,7 @@ __global__ __launch_bounds__(256, (BD == 6 ? (DIAG ? 4 : VGG_OFFDIAG_OCC) : 2)) 
   // (lane group lk = entry), so the four 128-byte runs one operand fetch touches fall two and two into the
   // two halves of the LDS banks (conflict-free ds_read_b64).
   constexpr int SWZ = ((SEG * 8) % 256 == 0) ? 16 : 0;
-  __shared__ __attribute__((aligned(16))) double Ops[2][DIAG ? 1 : 2][4][SEG];
-  if (w.ctl->done) return;
+  constexpr int SIDES = DIAG ? 1 : 2;             // LDS image: ops[buffer][side][entry of the batch][SEG]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: MFMAs only behind scalar control flow
   // chunk = the j-th of the J workgroups of tile (gI,gJ).  The tile's entry list [e0,e1) is sorted by point;
@@ -946,7 +945,6 @@ __global__ __launch_bounds__(256, (BD == 6 ? (DIAG ? 4 : VGG_OFFDIAG_OCC) : 2)) 
   // the point range at the same relative rate and the (up to ~G) re-reads of one point's segments by
   // different tiles fall close together in time (they hit the L2 / Infinity Cache instead of HBM).
   // launch position -> chunk (XCD placement: the chunks of one point range share an XCD and its L2; vggsfm_amd.h)
-  const int chunk = block_chunk ? block_chunk[chunk0 + blockIdx.x] : chunk0 + blockIdx.x;
   const int e0 = chunk_desc[6 * chunk + 2], e1 = chunk_desc[6 * chunk + 3];
   const int cj = chunk_desc[6 * chunk + 4], cJ = chunk_desc[6 * chunk + 5];
   constexpr int BPS = kSub / 4;                   // batches of 4 entries per sub-chunk
@@ -989,7 +987,7 @@ __global__ __launch_bounds__(256, (BD == 6 ? (DIAG ? 4 : VGG_OFFDIAG_OCC) : 2)) 
     for (int i = 0; i < NV; ++i) { const int off = l32 + TPS * i; sv[i] = (off < V) ? src[off] : make_double2(0.0, 0.0); }
   };
   auto write_lds = [&](const double2 (&sv)[NV], int buf) __attribute__((always_inline)) {
-    double2* dst = reinterpret_cast<double2*>(&Ops[buf][sside][se][0]);
+    double2* dst = reinterpret_cast<double2*>(ops + (size_t)((buf * SIDES + sside) * 4 + se) * SEG);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int off = l32 + TPS * i;
@@ -1058,8 +1056,8 @@ __global__ __launch_bounds__(256, (BD == 6 ? (DIAG ? 4 : VGG_OFFDIAG_OCC) : 2)) 
       bitsB[i] = block_slot_bits<BD>(wc + 2 * i) << 16;
     }
     sweep([&](int buf, uint32_t qm) {
-      const double* As = &Ops[buf][0][0][0];
-      const double* Bs = &Ops[buf][1][0][0];
+      const double* As = ops + (size_t)(buf * SIDES) * 4 * SEG;
+      const double* Bs = ops + (size_t)(buf * SIDES + 1) * 4 * SEG;
       bool ra[NH], cb[NH];
 #pragma unroll
       for (int i = 0; i < NH; ++i) { ra[i] = (qm & bitsA[i]) != 0; cb[i] = (qm & bitsB[i]) != 0; }
@@ -1103,7 +1101,7 @@ __global__ __launch_bounds__(256, (BD == 6 ? (DIAG ? 4 : VGG_OFFDIAG_OCC) : 2)) 
       }
     }
     sweep([&](int buf, uint32_t qm) {
-      const double* As = &Ops[buf][0][0][0];
+      const double* As = ops + (size_t)(buf * SIDES) * 4 * SEG;
       bool on[PER];
 #pragma unroll
       for (int t = 0; t < PER; ++t) on[t] = (qm & bitsR[t]) != 0 && (qm & bitsC[t]) != 0;
@@ -1122,6 +1120,31 @@ __global__ __launch_bounds__(256, (BD == 6 ? (DIAG ? 4 : VGG_OFFDIAG_OCC) : 2)) 
     for (int t = 0; t < PER; ++t)
       if (t < nmine) store_subtile(rbs[t], cbs[t], acc[t / NH][t % NH]);
   }
+}
+
+// the two launches of a tile batch (off-diagonal tiles, diagonal tiles) ...
+template <int BD, bool DIAG>
+__global__ __launch_bounds__(256, (BD == 6 ? (DIAG ? 4 : VGG_OFFDIAG_OCC) : 2)) void schur_tile_kernel(Ws w, const int32_t* __restrict__ chunk_desc,
+                                                         const int32_t* __restrict__ entries, int chunk0, int zero_seg,
+                                                         const int32_t* __restrict__ block_chunk,
+                                                         const int32_t* __restrict__ sched) {
+  __shared__ __attribute__((aligned(16))) double ops[2 * (DIAG ? 1 : 2) * 4 * kGroup * BD * 3];
+  if (w.ctl->done) return;
+  const int chunk = block_chunk ? block_chunk[chunk0 + blockIdx.x] : chunk0 + blockIdx.x;
+  schur_tile_body<BD, DIAG>(w, chunk_desc, entries, chunk, zero_seg, sched, ops);
+}
+// ... or ONE launch for both (vgg_ba_tuning / VGG_TILE_MERGED): the diagonal tiles then sweep the points together with the
+// off-diagonal ones and find the segments those have just brought into the Infinity Cache
+template <int BD>
+__global__ __launch_bounds__(256, (BD == 6 ? VGG_OFFDIAG_OCC : 2)) void schur_tile_merged_kernel(Ws w, const int32_t* __restrict__ chunk_desc,
+                                                         const int32_t* __restrict__ entries, int chunk0, int zero_seg,
+                                                         const int32_t* __restrict__ block_chunk,
+                                                         const int32_t* __restrict__ sched) {
+  __shared__ __attribute__((aligned(16))) double ops[2 * 2 * 4 * kGroup * BD * 3];
+  if (w.ctl->done) return;
+  const int chunk = block_chunk ? block_chunk[chunk0 + blockIdx.x] : chunk0 + blockIdx.x;
+  if (chunk_desc[6 * chunk] == chunk_desc[6 * chunk + 1]) schur_tile_body<BD, true>(w, chunk_desc, entries, chunk, zero_seg, sched, ops);
+  else schur_tile_body<BD, false>(w, chunk_desc, entries, chunk, zero_seg, sched, ops);
 }
 
 // S[(cI,a,i),(cJ,b,j)] = - sum over the chunks of tile (gI,gJ) of the partial tiles (plain stores: every
@@ -1922,11 +1945,14 @@ static void launch_schur_batch(const Launch& L, int batch, hipStream_t st, doubl
     }
     return;
   }
-  if (cm > c0) {
+  if (g_tile_merged && c1 > c0) {
+    ProfScope ps(kProfSchurTile, st);
+    schur_tile_merged_kernel<BD><<<c1 - c0, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, c0, L.num_segments, L.block_chunk, L.tile_sched);
+  } else if (cm > c0) {
     ProfScope ps(kProfSchurTile, st);
     schur_tile_kernel<BD, false><<<cm - c0, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, c0, L.num_segments, L.block_chunk, L.tile_sched);
   }
-  if (c1 > cm) {
+  if (!g_tile_merged && c1 > cm) {
     ProfScope ps(kProfSchurTileDiag, st);
     schur_tile_kernel<BD, true><<<c1 - cm, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, cm, L.num_segments, L.block_chunk, L.tile_sched);
   }

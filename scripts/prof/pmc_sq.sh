@@ -7,12 +7,12 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_sq
 CTRS=${1:-"SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT"}
 (cd $ROOT && rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d /tmp/pmc_sq -- \
-    python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_sq.log 2>&1)
+    python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-strong-leg > $OUT/bench_sq.log 2>&1)
 python $ROOT/scripts/prof/pmc_aggregate.py $OUT/pmc_sq.json /tmp/pmc_sq > /dev/null
 python - <<PY
 import json
 d = json.load(open("$OUT/pmc_sq.json"))
 for k, v in d.items():
-    if "schur_tile" in k or "point_pass" in k or "chol_panel" in k:
+    if "vgg::" in k:
         print(k[:70], {c: round(x["mean"]) for c, x in v.items()})
 PY

@@ -346,48 +346,51 @@ __global__ __launch_bounds__(256, (MODE == 1) ? VGG_CP_OCC_RHS : VGG_CP_OCC) voi
   const int j_begin = pb.col_ptr[c], j_count = pb.col_ptr[c + 1] - j_begin;
   const int per = (j_count + split - 1) / split;
   const int j0 = j_begin + (int)blockIdx.y * per, j1 = min(j0 + per, j_begin + j_count);
-  // Software pipeline over this thread's observations: (point index, pixel) are loaded TWO iterations ahead, the point
-  // coordinates (and, MODE 1, its back-substitution terms) -- a gather that depends on the index -- ONE iteration ahead:
-  // the two dependent memory round trips of an observation overlap the arithmetic of the two before it.  (Without it the
-  // pass ran 5x off its instruction-issue bound at 3-4 wavefronts per SIMD.)
+  // Software pipeline over this thread's observations: (point index, pixel) are loaded AHEAD + 1 iterations ahead, the point
+  // coordinates (and, MODE 1, its back-substitution terms) -- a gather that depends on the index -- AHEAD iterations ahead:
+  // the two dependent memory round trips of an observation overlap the arithmetic of the observations before it.
+  // (Without it the pass ran 5x off its instruction-issue bound at 3-4 wavefronts per SIMD; one stage less: 52 % of the
+  // wave cycles still waiting.)
   constexpr int KM = (KD > 0) ? KD : 1;
-  int j = j0 + threadIdx.x;
-  int p2 = 0; float2 uv2 = make_float2(0.f, 0.f);
-  if (j < j1) { p2 = pb.cobs_pt[j]; uv2 = pb.cobs_uv[j]; }
-  int p1 = p2; float2 uv1 = uv2;
-  double X1[3] = {0, 0, 0}, h1[3] = {0, 0, 0}, M1[3 * KM];
-#pragma unroll
-  for (int i = 0; i < 3 * KM; ++i) M1[i] = 0;
-  bool c1 = false;
-  auto gather = [&](int p) __attribute__((always_inline)) {
-    X1[0] = pb.pts[3 * p]; X1[1] = pb.pts[3 * p + 1]; X1[2] = pb.pts[3 * p + 2];
-    c1 = pb.pt_const ? pb.pt_const[p] != 0 : false;
+  struct Gathered { double X[3], h[3], M[3 * KM]; float2 uv; bool c; };
+  auto gather = [&](Gathered& g, int p, float2 uv) __attribute__((always_inline)) {
+    g.uv = uv;
+    g.X[0] = pb.pts[3 * p]; g.X[1] = pb.pts[3 * p + 1]; g.X[2] = pb.pts[3 * p + 2];
+    g.c = pb.pt_const ? pb.pt_const[p] != 0 : false;
     if (MODE == 1) {
-      h1[0] = w.hs[3 * p]; h1[1] = w.hs[3 * p + 1]; h1[2] = w.hs[3 * p + 2];
+      g.h[0] = w.hs[3 * p]; g.h[1] = w.hs[3 * p + 1]; g.h[2] = w.hs[3 * p + 2];
 #pragma unroll
       for (int m = 0; m < KD; ++m)
         if (m < kdsh) {
           const double* M = w.Ms + ((size_t)p * kdsh + m) * 3;
-          M1[3 * m] = M[0]; M1[3 * m + 1] = M[1]; M1[3 * m + 2] = M[2];
+          g.M[3 * m] = M[0]; g.M[3 * m + 1] = M[1]; g.M[3 * m + 2] = M[2];
         }
     }
   };
-  if (j < j1) gather(p1);
-  if (j + 256 < j1) { p2 = pb.cobs_pt[j + 256]; uv2 = pb.cobs_uv[j + 256]; }
+  // (MODE 1 carries more per observation and runs out of registers with the second gather stage: 16 bytes of scratch and
+  //  0.133 -> 0.136 ms at c3, while MODE 0 goes from 0.099 to 0.087 ms -- so one stage there, two here)
+  constexpr int AHEAD = (MODE == 0 && KD > 0) ? 2 : 1;     // gather stages (KD = 0, MODE 0: the second stage would cost the third wavefront per SIMD)
+  Gathered g1 = {}, g2 = {};
+  int j = j0 + threadIdx.x;
+  int p3 = 0; float2 uv3 = make_float2(0.f, 0.f);
+  if (j < j1) gather(g1, pb.cobs_pt[j], pb.cobs_uv[j]);
+  if (AHEAD == 2 && j + 256 < j1) gather(g2, pb.cobs_pt[j + 256], pb.cobs_uv[j + 256]);
+  if (j + 256 * AHEAD < j1) { p3 = pb.cobs_pt[j + 256 * AHEAD]; uv3 = pb.cobs_uv[j + 256 * AHEAD]; }
   for (; j < j1; j += 256) {
-    const int p = p1;
-    const float2 uv = uv1;
-    const double X[3] = {X1[0], X1[1], X1[2]};
-    const bool pt_c = c1;
-    const double h0 = h1[0], h1v = h1[1], h2 = h1[2];
+    const Gathered cur = g1;
+    const float2 uv = cur.uv;
+    const double X[3] = {cur.X[0], cur.X[1], cur.X[2]};
+    const bool pt_c = cur.c;
+    const double h0 = cur.h[0], h1v = cur.h[1], h2 = cur.h[2];
     double Mc[3 * KM];
 #pragma unroll
-    for (int i = 0; i < 3 * KM; ++i) Mc[i] = M1[i];
-    // advance the pipeline: gather for iteration j + 256 (its index arrived an iteration ago), index for j + 512
-    p1 = p2; uv1 = uv2;
-    if (j + 256 < j1) gather(p1);
-    if (j + 512 < j1) { p2 = pb.cobs_pt[j + 512]; uv2 = pb.cobs_uv[j + 512]; }
-    (void)p;
+    for (int i = 0; i < 3 * KM; ++i) Mc[i] = cur.M[i];
+    // advance the pipeline: gather for iteration j + 512 (its index arrived an iteration ago), index for j + 768
+    if (AHEAD == 2) {
+      g1 = g2;
+      if (j + 512 < j1) gather(g2, p3, uv3);
+    } else if (j + 256 < j1) gather(g1, p3, uv3);
+    if (j + 256 * (AHEAD + 1) < j1) { p3 = pb.cobs_pt[j + 256 * (AHEAD + 1)]; uv3 = pb.cobs_uv[j + 256 * (AHEAD + 1)]; }
     double r[2], F[2 * BD], E[6];
     const double rho0 = eval_full<KD>(d, q, t, in4, X, uv, camflag, intr_c, pt_c, r, F, E);
     if (MODE == 0) {

@@ -191,6 +191,9 @@ typedef struct {
                                  of the chunk multiplies the quad tile_sched[offset + b] of its tile (quad q = entries
                                  tile_entry_begin + 4 q .. + 3).  Every quad of a tile must appear in exactly one of its chunks.
                                  The host side uses it to walk the points range by range on every XCD (ba.py: xcd_range_schedule) */
+  int32_t merged_tile_launch;    /* 1: the off-diagonal and the diagonal chunks of a batch run in ONE launch (the host sized them for
+                                 one shared resident round) -- small problems, where the second launch costs more than the
+                                 lower occupancy of the merged kernel */
 } vgg_ba_problem;
 
 typedef struct {

@@ -31,7 +31,7 @@ class BAProblem(ctypes.Structure):
                 ("entries", ctypes.c_void_p), ("num_segments", ctypes.c_int32), ("obs_slot", ctypes.c_void_p), ("obs_pt", ctypes.c_void_p),
                 ("num_tiles", ctypes.c_int32), ("tile_desc", ctypes.c_void_p), ("tile_batches", ctypes.c_void_p),
                 ("chol_split_a", ctypes.c_int32), ("chol_split_b", ctypes.c_int32), ("chol_first_blk", ctypes.c_void_p), ("block_chunk", ctypes.c_void_p),
-                ("super_tiles", ctypes.c_int32), ("quad_mask", ctypes.c_void_p), ("tile_sched", ctypes.c_void_p)]
+                ("super_tiles", ctypes.c_int32), ("quad_mask", ctypes.c_void_p), ("tile_sched", ctypes.c_void_p), ("merged_tile_launch", ctypes.c_int32)]
 
 
 class BAOptions(ctypes.Structure):

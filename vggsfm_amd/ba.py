@@ -119,6 +119,7 @@ class DeviceProblem:
     obs_pt: Optional[torch.Tensor] = None           # (O,) int32 device: point of every point-major observation (None = fused Y pass)
     quad_mask: Optional[torch.Tensor] = None        # (Q,2) int32 device: set <=> chunk_desc / entries / tile_desc are SUPER-TILES
     tile_sched: Optional[torch.Tensor] = None       # (B,) int32 device: batch schedule of the tile chunks (xcd_range_schedule)
+    merged_tile_launch: bool = False                # off-diagonal and diagonal tile chunks in one launch (small problems)
 
     @property
     def num_obs(self):
@@ -136,6 +137,7 @@ class DeviceProblem:
             setattr(P, name, None if t is None else t.data_ptr())
         P.num_chunks = self.chunk_desc.shape[0]
         P.super_tiles = int(self.quad_mask is not None)
+        P.merged_tile_launch = int(self.merged_tile_launch)
         if self.quad_mask is not None:
             self.batch_desc = torch.tensor([[0, 0, self.chunk_desc.shape[0], 0, self.tile_desc.shape[0], 0]], dtype=torch.int32)
         if self.batch_desc is None:                 # a hand-built problem: one batch, off-diagonal chunks first
@@ -153,7 +155,8 @@ class DeviceProblem:
         return P
 
 
-def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=None, num_batches=1, later_scale=1.0, xcds=XCDS):
+def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=None, num_batches=1, later_scale=1.0, xcds=XCDS,
+                      merged_slots=None):
     """Block-sparse Schur work list (device, torch ops; structure is fixed for the whole solve).
 
     A *segment* is the run of one point's observations that falls into one group of `group`
@@ -180,7 +183,10 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     per part, and the returned `block_chunk` (num_chunks,) int32 maps launch position -> chunk such that the chunks of
     part x sit at positions = x (mod xcds).  All tiles then process a given point on the same XCD and its segments come
     through the fabric once per iteration instead of once per tile -- in principle; see the note at XCDS (measured:
-    no pay-off, default 1 part)."""
+    no pay-off, default 1 part).
+
+    `merged_slots`: the off-diagonal and the diagonal chunks will run in ONE launch (vgg_ba_problem.merged_tile_launch) with
+    that many resident workgroups in all; the split between the two kinds follows their entry counts."""
     dev = obs_cam.device
     O = obs_cam.shape[0]
     P = row_ptr.shape[0] - 1
@@ -260,6 +266,13 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
         # one resident round per launch: the smallest chunk size (multiple of SUB, >= MIN_CHUNK) whose workgroup
         # count fits the device (CUs x workgroups per CU), so no workgroup starts late and runs alone on its CU
         caps = max_chunks if isinstance(max_chunks, (tuple, list)) else (max_chunks, max_chunks)
+        if merged_slots is not None:
+            # ONE launch for both kinds of tiles (small problems): its resident slots are shared in proportion to the
+            # staged bytes (two segments per off-diagonal entry, one per diagonal entry)
+            e_off, e_diag = float(kcounts[~is_diag].sum().item()), float(kcounts[is_diag].sum().item())
+            n_off = int(round(merged_slots * 2.0 * e_off / max(2.0 * e_off + e_diag, 1.0)))
+            n_off = min(max(n_off, 1 if e_off else 0), merged_slots - (1 if e_diag else 0))
+            caps = (max(n_off, 1), max(merged_slots - n_off, 1))
         for b in range(nb):
             scale = 1.0 if b == 0 else later_scale
             for sel, cap in ((~is_diag & (tbatch == b), int(caps[0] * scale)), (is_diag & (tbatch == b), int(caps[1] * scale))):
@@ -332,6 +345,7 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
 
 XCD_SCHEDULE = os.environ.get("VGGSFM_XCD_SCHEDULE", "0") == "1"   # opt-in: xcd_range_schedule for large single-batch problems
 XCD_RANGE_POINTS = 128
+MERGED_TILE_MAX_OBS = 1_000_000   # below: off-diagonal and diagonal tiles share one launch
 
 
 def xcd_range_schedule(entries, chunk_desc, tile_desc, batch_desc, wgs, range_points=XCD_RANGE_POINTS, xcds=8):
@@ -791,13 +805,17 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
     overlap = OVERLAP_FACTORIZATION if overlap is None else bool(overlap)
     nb = TILE_BATCHES if (overlap and int(obs_cam.shape[0]) >= OVERLAP_MIN_OBS and S >= OVERLAP_MIN_FRAMES) else 1
     quad_mask = None
+    merged = False
     if SUPER_TILES and shared_camera and nb == 1 and int(obs_cam.shape[0]) > 0:
         # 6 x 6 camera blocks: 2 x 2 super-tiles, one workgroup of 8 wavefronts per CU, one launch
         chunk_desc, entries, quad_mask, tile_desc, obs_slot, nseg = build_schur_supertiles(row_ptr, obs_cam, max_wgs=cus)
         batch_desc, block_chunk = None, None
     else:
+        # small problems: one tile launch (c2, 0.25 M observations: 0.101 -> 0.068 ms for the tiles; c3, 5 M: 0.84 -> 0.90 ms)
+        merged = nb == 1 and int(obs_cam.shape[0]) < MERGED_TILE_MAX_OBS and not os.environ.get("VGGSFM_TILE_SLOTS")
         chunk_desc, entries, tile_desc, obs_slot, nseg, batch_desc, block_chunk = build_schur_tiles(
-            row_ptr, obs_cam, max_chunks=slots, num_batches=nb, later_scale=(cus - CHOL_CUS) / cus)
+            row_ptr, obs_cam, max_chunks=slots, num_batches=nb, later_scale=(cus - CHOL_CUS) / cus,
+            merged_slots=(slots[0] if merged else None))
     tile_sched = None
     if XCD_SCHEDULE and quad_mask is None and nb == 1 and int(obs_cam.shape[0]) >= OVERLAP_MIN_OBS:
         res = xcd_range_schedule(entries, chunk_desc, tile_desc, batch_desc, (slots[0] // 8 * 8, slots[1] // 8 * 8))
@@ -806,7 +824,7 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
     prob = DeviceProblem(cam_q, cam_t, intr, pts, row_ptr, obs_cam, obs_uv, col_ptr, cobs_pt, cobs_uv, chunk_desc,
                          entries, tile_desc, obs_slot, nseg, MODEL_ID[camera_type], cam_const=cam_const,
                          batch_desc=batch_desc, chol_split=chol_split, cam_perm=cam_perm, block_chunk=block_chunk, quad_mask=quad_mask,
-                         tile_sched=tile_sched,
+                         tile_sched=tile_sched, merged_tile_launch=(quad_mask is None and tile_sched is None and merged),
                          obs_pt=pm[:, 0].to(torch.int32).contiguous())
     if first_group is not None:
         kd = 2 if camera_type == "SIMPLE_RADIAL" else 1              # upper bound of the intrinsics unknowns per block

@@ -1888,6 +1888,7 @@ struct Launch {
   const int32_t* chunk_desc; const int32_t* entries; int num_chunks, num_segments;
   const int32_t* block_chunk;                   // launch position -> chunk (XCD placement) or NULL
   const int32_t* tile_sched;                    // batch schedule of the tile chunks (vgg_ba_problem.tile_sched) or NULL
+  int merged_tile_launch;
   int super_tiles; const int32_t* quad_mask;    // 2 x 2 super-tiles (vgg_ba_problem.super_tiles)
   const int32_t* tile_desc; int num_tiles;
   const int32_t* batches; int num_batches;      // HOST table [num_batches][6], see vgg_ba_problem.tile_batches
@@ -1948,14 +1949,14 @@ static void launch_schur_batch(const Launch& L, int batch, hipStream_t st, doubl
     }
     return;
   }
-  if (g_tile_merged && c1 > c0) {
+  if ((g_tile_merged || L.merged_tile_launch) && c1 > c0) {
     ProfScope ps(kProfSchurTile, st);
     schur_tile_merged_kernel<BD><<<c1 - c0, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, c0, L.num_segments, L.block_chunk, L.tile_sched);
   } else if (cm > c0) {
     ProfScope ps(kProfSchurTile, st);
     schur_tile_kernel<BD, false><<<cm - c0, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, c0, L.num_segments, L.block_chunk, L.tile_sched);
   }
-  if (!g_tile_merged && c1 > cm) {
+  if (!(g_tile_merged || L.merged_tile_launch) && c1 > cm) {
     ProfScope ps(kProfSchurTileDiag, st);
     schur_tile_kernel<BD, true><<<c1 - cm, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, cm, L.num_segments, L.block_chunk, L.tile_sched);
   }
@@ -2138,6 +2139,7 @@ static int make_launch(const vgg_ba_problem* pb, const vgg_ba_options* opt, void
   L->chunk_desc = pb->chunk_desc; L->entries = pb->entries; L->num_chunks = pb->num_chunks;
   L->block_chunk = pb->block_chunk;
   L->tile_sched = pb->tile_sched;
+  L->merged_tile_launch = pb->merged_tile_launch;
   L->super_tiles = pb->super_tiles; L->quad_mask = pb->quad_mask;
   if (pb->super_tiles && (!pb->quad_mask || pb->num_tile_batches != 1 || !(L->d.shared || L->d.kd == 0))) return VGG_ERR_INVALID_ARGUMENT;
   L->num_segments = pb->num_segments;

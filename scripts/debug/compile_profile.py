@@ -1,17 +1,24 @@
-"""Where does ba.compile_problem spend its time at 200 x 100k?  (torch profiler, top ops by device+host time)"""
-import os, sys, time
-import numpy as np, torch
+"""cProfile of ba.compile_problem on a window-sized problem (host overhead of the torch ops and their synchronisations)."""
+import cProfile, os, pstats, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import torch
 from vggsfm_amd import ba as BA
 from vggsfm_amd.scene import make_scene, perturb_for_ba
-D = lambda x: None if x is None else torch.from_numpy(np.ascontiguousarray(x)).cuda()
-sc = make_scene(200, 100000, "SIMPLE_RADIAL", shared_camera=True, seed=0)
-ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=0)
-args = (D(pts0), D(ext0), D(K0), D(sc.tracks), D(sc.mask), D(extra0), True, "SIMPLE_RADIAL")
-for _ in range(2):
-    torch.cuda.synchronize(); t0 = time.perf_counter(); BA.compile_problem(*args); torch.cuda.synchronize()
-    print("compile_problem", round(time.perf_counter() - t0, 4))
-import torch.profiler as tp
-with tp.profile(activities=[tp.ProfilerActivity.CPU, tp.ProfilerActivity.CUDA]) as prof:
-    BA.compile_problem(*args); torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=14, max_name_column_width=45))
+
+dev = torch.device("cuda:0")
+sc = make_scene(33, 8000, "SIMPLE_RADIAL", shared_camera=True, seed=1)
+ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=1)
+T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+args = (T(pts0), T(ext0), T(K0), T(sc.tracks), T(sc.mask), T(extra0), True, "SIMPLE_RADIAL")
+for _ in range(3):
+    BA.compile_problem(*args)
+torch.cuda.synchronize()
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(20):
+    BA.compile_problem(*args)
+torch.cuda.synchronize()
+pr.disable()
+st = pstats.Stats(pr)
+st.sort_stats("tottime").print_stats(28)

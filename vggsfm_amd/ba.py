@@ -48,6 +48,9 @@ XCDS = 1             # point-range parts for XCD placement of the Schur tile chu
 # ------------------------------------------------------------------ rotations (Eigen conventions)
 def rotmat_to_quat(R):
     """(…,3,3) -> unit quaternion (x,y,z,w), Eigen's Quaternion(Matrix3) branch structure."""
+    if R.is_cuda and R.numel() <= 9 * 8192:
+        # a few hundred cameras: ~70 tiny launches cost 0.5 ms of every problem set-up; the same formulas on the host
+        return _rotmat_to_quat_host(R)
     R = R.to(torch.float64)
     m00, m11, m22 = R[..., 0, 0], R[..., 1, 1], R[..., 2, 2]
     tr = m00 + m11 + m22
@@ -71,6 +74,32 @@ def rotmat_to_quat(R):
     q_neg = torch.where(i2[..., None], outs[2], torch.where(i1[..., None], outs[1], outs[0]))
     q = torch.where((tr > 0)[..., None], q_tr, q_neg)
     return q / q.norm(dim=-1, keepdim=True)
+
+
+def _rotmat_to_quat_host(R):
+    import numpy as np
+    M = R.detach().to(torch.float64).cpu().numpy()
+    m00, m11, m22 = M[..., 0, 0], M[..., 1, 1], M[..., 2, 2]
+    tr = m00 + m11 + m22
+    t0 = np.sqrt(np.maximum(tr + 1.0, 1e-300))
+    q_tr = np.stack([(M[..., 2, 1] - M[..., 1, 2]) * (0.5 / t0), (M[..., 0, 2] - M[..., 2, 0]) * (0.5 / t0),
+                     (M[..., 1, 0] - M[..., 0, 1]) * (0.5 / t0), 0.5 * t0], -1)
+    outs = []
+    for i in range(3):
+        j, k = (i + 1) % 3, (i + 2) % 3
+        t = np.sqrt(np.maximum(M[..., i, i] - M[..., j, j] - M[..., k, k] + 1.0, 1e-300))
+        q = [None] * 4
+        q[i] = 0.5 * t
+        q[3] = (M[..., k, j] - M[..., j, k]) * (0.5 / t)
+        q[j] = (M[..., j, i] + M[..., i, j]) * (0.5 / t)
+        q[k] = (M[..., k, i] + M[..., i, k]) * (0.5 / t)
+        outs.append(np.stack(q, -1))
+    i1 = m11 > m00
+    i2 = m22 > np.where(i1, m11, m00)
+    q_neg = np.where(i2[..., None], outs[2], np.where(i1[..., None], outs[1], outs[0]))
+    q = np.where((tr > 0)[..., None], q_tr, q_neg)
+    q = q / np.linalg.norm(q, axis=-1, keepdims=True)
+    return torch.from_numpy(np.ascontiguousarray(q)).to(R.device)
 
 
 def quat_to_rotmat(q):
@@ -269,24 +298,29 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
         if merged_slots is not None:
             # ONE launch for both kinds of tiles (small problems): its resident slots are shared in proportion to the
             # staged bytes (two segments per off-diagonal entry, one per diagonal entry)
-            e_off, e_diag = float(kcounts[~is_diag].sum().item()), float(kcounts[is_diag].sum().item())
+            kc0, dg0 = kcounts.cpu(), is_diag.cpu()
+            e_off, e_diag = float(kc0[~dg0].sum()), float(kc0[dg0].sum())
             n_off = int(round(merged_slots * 2.0 * e_off / max(2.0 * e_off + e_diag, 1.0)))
             n_off = min(max(n_off, 1 if e_off else 0), merged_slots - (1 if e_diag else 0))
             caps = (max(n_off, 1), max(merged_slots - n_off, 1))
+        # (the search runs on host copies of the per-tile counts: one synchronisation instead of one per probe)
+        kc_h, diag_h, tb_h = kcounts.cpu(), is_diag.cpu(), tbatch.cpu()
+        csize_h = torch.full_like(kc_h, chunk)
         for b in range(nb):
             scale = 1.0 if b == 0 else later_scale
-            for sel, cap in ((~is_diag & (tbatch == b), int(caps[0] * scale)), (is_diag & (tbatch == b), int(caps[1] * scale))):
+            for sel, cap in ((~diag_h & (tb_h == b), int(caps[0] * scale)), (diag_h & (tb_h == b), int(caps[1] * scale))):
                 if not bool(sel.any()):
                     continue
-                kc = kcounts[sel]
-                lo, hi = MIN_CHUNK // SUB, max(MIN_CHUNK // SUB, int(-(-int(kc.max().item()) // SUB)))
-                fits = lambda c: int(((kc + c * SUB - 1) // (c * SUB)).sum().item()) <= cap
+                kc = kc_h[sel]
+                lo, hi = MIN_CHUNK // SUB, max(MIN_CHUNK // SUB, int(-(-int(kc.max()) // SUB)))
+                fits = lambda c: int(((kc + c * SUB - 1) // (c * SUB)).sum()) <= cap
                 if not fits(hi):
                     lo = hi                         # more tiles than slots: one workgroup per tile
                 while lo < hi:
                     mid = (lo + hi) // 2
                     lo, hi = (lo, mid) if fits(mid) else (mid + 1, hi)
-                csize[sel] = lo * SUB
+                csize_h[sel] = lo * SUB
+        csize = csize_h.to(dev)
     nchunks = (kcounts + csize - 1) // csize
     ctile = torch.repeat_interleave(torch.arange(ukeys.shape[0], device=dev), nchunks)          # unit of every chunk
     cfirst = torch.cumsum(nchunks, 0) - nchunks

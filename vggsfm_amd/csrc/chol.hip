@@ -951,6 +951,7 @@ struct DfShared {
 };
 
 // flags: ready[(nbk + 1) * nbk] (tile (r, c) final), then tready[nbk]; all zero on entry.
+template <bool OVERLAP>
 __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__ A, int n, int nbk, double* __restrict__ Tinv,
                                                             int32_t* __restrict__ flags, int32_t* fail, const int32_t* skip,
                                                             int split_a, int split_b, const int32_t* __restrict__ first_blk,
@@ -983,7 +984,7 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
   // ov.first_col are still being summed into S2 by another stream when this launch starts; flag k says that everything
   // for the columns >= ov.wait_col[k] has landed.  A tile waits for the last flag its columns need and adds S2.
   const double* S2 = nullptr;
-  if (ov.S2 && r < nbk && c0 + vc > ov.first_col) {
+  if (OVERLAP && ov.S2 && r < nbk && c0 + vc > ov.first_col) {
     int need = -1;
     for (int k = 0; k < ov.num_waits; ++k)
       if (ov.wait_col[k] < c0 + vc) need = k;
@@ -1001,7 +1002,7 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
         const int i = 32 * wy + 16 * m + lk + 4 * reg, j = 32 * wx + 16 * q + li;
         const bool in = i < vr && j < vc && (!diag || j <= i);
         a0[m][q][reg] = in ? A[(size_t)(r0 + i) * n + c0 + j] : 0.0;
-        if (S2 && in) a0[m][q][reg] += ld_agent(&S2[(size_t)(r0 + i) * n + c0 + j]);
+        if (OVERLAP && S2 && in) a0[m][q][reg] += ld_agent(&S2[(size_t)(r0 + i) * n + c0 + j]);
         acc[m][q][reg] = 0.0;
       }
 
@@ -1236,7 +1237,9 @@ static int enqueue_dataflow(double* A, double* b, int n, double* ws, int32_t* de
   if (hipMemsetAsync(flags, 0, dataflow_flag_count(n) * sizeof(int32_t), st) != hipSuccess) return VGG_ERR_HIP;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_dataflow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_dataflow_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sizeof(DfShared)) != hipSuccess) return VGG_ERR_HIP;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_dataflow_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)sizeof(DfShared)) != hipSuccess) return VGG_ERR_HIP;
     attr_set = true;
   }
@@ -1247,7 +1250,8 @@ static int enqueue_dataflow(double* A, double* b, int n, double* ws, int32_t* de
     ov.S2 = overlap->S2; ov.flags = overlap->dev_flags; ov.first_col = overlap->first_col; ov.num_waits = overlap->num_waits;
     for (int k = 0; k < overlap->num_waits && k < 8; ++k) ov.wait_col[k] = overlap->wait_col[k];
   }
-  chol_dataflow_kernel<<<tiles, 256, sizeof(DfShared), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b, first_blk, ov);
+  if (ov.S2) chol_dataflow_kernel<true><<<tiles, 256, sizeof(DfShared), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b, first_blk, ov);
+  else chol_dataflow_kernel<false><<<tiles, 256, sizeof(DfShared), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b, first_blk, ov);
   int32_t* xready = flags + (size_t)(nbk + 1) * nbk + nbk;
   chol_backward_dataflow_kernel<<<nbk, 256, 0, st>>>(A, b, n, nbk, Tinv, xready, device_fail, skip, split_a, split_b, first_blk);
   if (hipGetLastError() != hipSuccess) return VGG_ERR_HIP;

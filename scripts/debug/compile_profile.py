@@ -7,17 +7,19 @@ from vggsfm_amd import ba as BA
 from vggsfm_amd.scene import make_scene, perturb_for_ba
 
 dev = torch.device("cuda:0")
-sc = make_scene(33, 8000, "SIMPLE_RADIAL", shared_camera=True, seed=1)
+S_, N_ = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (33, 8000)
+sc = make_scene(S_, N_, "SIMPLE_RADIAL", shared_camera=True, seed=1)
 ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=1)
 T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 args = (T(pts0), T(ext0), T(K0), T(sc.tracks), T(sc.mask), T(extra0), True, "SIMPLE_RADIAL")
-for _ in range(3):
-    BA.compile_problem(*args)
+for _ in range(2):
+    BA.compile_problem(*args, camera_split=True)
 torch.cuda.synchronize()
 pr = cProfile.Profile()
 pr.enable()
-for _ in range(20):
-    BA.compile_problem(*args)
+REPS = 20 if N_ < 50000 else 5
+for _ in range(REPS):
+    BA.compile_problem(*args, camera_split=True)
 torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)

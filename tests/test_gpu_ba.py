@@ -174,14 +174,16 @@ def test_ba_kway_camera_order_matches_frame_order(monkeypatch):
     np.testing.assert_array_equal(a[1][0].cpu().numpy(), ext0[0])
 
 
+@pytest.mark.parametrize("density_cut", [0.05, 2.0])    # compile_problem: grid filtered in place / observation list
 @pytest.mark.parametrize("shared,N", [(True, 8000), (False, 5000)])
-def test_ba_camera_split_matches_unsplit(monkeypatch, shared, N):
+def test_ba_camera_split_matches_unsplit(monkeypatch, shared, N, density_cut):
     """Sliding-window visibility at 160 frames: bundle_adjustment orders the cameras [A, B, rest] and factorises A and B
     side by side.  Against the same solve without the re-ordering: same trajectory to rounding (the summation order of
     the reduced system changes), outputs in the order of the input frames."""
     sc = make_scene(160, N, "SIMPLE_RADIAL", shared_camera=shared, seed=13)
     ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=13)
     assert BA.find_camera_split(D(sc.mask))[0] is not None
+    monkeypatch.setattr(BA, "SPARSE_GRID_DENSITY", density_cut)
     opt = BundleAdjustmentOptions()
     opt.solver_options.max_num_iterations = 12
 

@@ -57,9 +57,11 @@ def test_quaternion_conversion_matches_oracle():
     np.testing.assert_allclose(BA.quat_to_rotmat(T(q)).numpy(), R, atol=1e-14)
 
 
+@pytest.mark.parametrize("density_cut", [0.0, 2.0])    # in-place filtering of the grid / the observation-list construction
 @pytest.mark.parametrize("S,N", [(5, 40), (40, 300), (70, 150)])
-def test_compile_problem_matches_oracle_construction(S, N, monkeypatch):
+def test_compile_problem_matches_oracle_construction(S, N, density_cut, monkeypatch):
     monkeypatch.setattr(BA, "SUPER_TILES", False)        # (the 2 x 2 super-tile list has its own test below)
+    monkeypatch.setattr(BA, "SPARSE_GRID_DENSITY", density_cut)
     sc = make_scene(S, N, "SIMPLE_RADIAL", shared_camera=True, seed=S)
     ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=S)
     masks = sc.mask.copy()

@@ -139,3 +139,32 @@ def test_two_view_stage_feeds_the_triangulator():
     # the outliers the two-view stage rejected never vote in the initial pair selection; the final model rejects them too
     bad = sc.outlier[:, valid_tracks.cpu().numpy()]
     assert (m & bad).sum() < 0.1 * bad.sum()
+
+
+@pytest.mark.gpu
+def test_sampson_distance_and_inlier_mask_match_oracle():
+    """two_view_geo.utils.sampson_epipolar_distance_batched / inlier_by_fundamental (vgg_fmat_residuals) against the numpy
+    restatement of the reference's formula (oracle/fundamental.py: sampson_sq), float64: 1e-12 relative."""
+    from oracle import fundamental as OF
+    from vggsfm_amd.two_view_geo.utils import inlier_by_fundamental, sampson_epipolar_distance_batched
+    rng = np.random.default_rng(11)
+    B, K, N = 3, 4, 500
+    p1 = rng.uniform(0, 1000, size=(B, N, 2))
+    p2 = p1 + rng.normal(0, 5, size=(B, N, 2))
+    Fm = rng.normal(size=(B, K, 3, 3))
+    dev = torch.device("cuda:0")
+    T = lambda x: torch.from_numpy(x).to(dev)
+    got = sampson_epipolar_distance_batched(T(p1), T(p2), T(Fm)).cpu().numpy()
+    for b in range(B):
+        np.testing.assert_allclose(got[b], OF.sampson_sq(Fm[b], p1[b], p2[b]), rtol=1e-11, atol=1e-300)
+    unsq = sampson_epipolar_distance_batched(T(p1), T(p2), T(Fm), squared=False).cpu().numpy()
+    np.testing.assert_allclose(unsq, np.sqrt(got + 1e-8), rtol=1e-14)
+    # inlier_by_fundamental: tracks (1,S,N,2), one F per pair (frame 0, frame s)
+    S = B + 1
+    tracks = np.concatenate([p1[0:1], p2[0:1], p1[1:2] * 0 + p1[0:1] + rng.normal(0, 3, size=(1, N, 2)),
+                             p1[0:1] + rng.normal(0, 3, size=(1, N, 2))])[None]
+    F = rng.normal(size=(1, S - 1, 3, 3))
+    mask = inlier_by_fundamental(T(F), T(tracks), max_error=40.0).cpu().numpy()
+    for s_ in range(1, S):
+        ref = OF.sampson_sq(F[0, s_ - 1][None], tracks[0, 0], tracks[0, s_])[0] <= 40.0 ** 2
+        assert np.array_equal(mask[0, s_ - 1], ref)

@@ -99,6 +99,21 @@ def test_winner_selection_matches_reference():
             assert np.array_equal(num[b].numpy(), cnt) and np.array_equal(mask[b].numpy(), inl)
 
 
+def test_residual_indicator_mirror_equals_reference():
+    """vggsfm_amd.two_view_geo.utils.calculate_residual_indicator (plain tensor ops) = the reference's function, bit for
+    bit (same operations in the same order)."""
+    rf, ru = _reference_modules()
+    from vggsfm_amd.two_view_geo.utils import calculate_residual_indicator
+    rng = np.random.default_rng(5)
+    for trial in range(10):
+        res = torch.from_numpy(rng.uniform(0, 3, size=(2, 17, 50)))
+        res[:, 4] = 9.0                                                              # a hypothesis without inliers
+        a = calculate_residual_indicator(res, 1.0)
+        b = ru.calculate_residual_indicator(res, 1.0)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+
+
 def test_seven_point_pencil_matches_reference_modulo_the_cubic_solver():
     """run_7point (fundamental.py:339-469) with kornia's normalize_points restated and its solve_cubic replaced by
     numpy.roots (real roots, zeros elsewhere): the null-space pencil, the cubic's coefficients, the F[2,2] = 1 scaling and

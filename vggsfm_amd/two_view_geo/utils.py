@@ -1,5 +1,12 @@
-"""Host helpers of the two-view stage (vggsfm/two_view_geo/utils.py)."""
+"""Helpers of the two-view stage under the reference's names (vggsfm/two_view_geo/utils.py): the sample generator, the
+Sampson distance and the inlier test on the device (``vgg_fmat_residuals``), the hypothesis score, and the re-exports
+of the helpers `estimate_preliminary_cameras` uses."""
+import ctypes
+
 import numpy as np
+import torch
+
+from .. import _lib
 
 
 def generate_samples(N, target_num, sample_num, expand_ratio=2):
@@ -10,3 +17,55 @@ def generate_samples(N, target_num, sample_num, expand_ratio=2):
     srt = np.sort(draw, axis=1)
     distinct = (srt[:, 1:] != srt[:, :-1]).all(axis=1)
     return draw[distinct][:target_num]
+
+
+def calculate_residual_indicator(residuals, max_residual, nanvalue=1e6):
+    """utils.py:63-87: score of every hypothesis = its inlier count + a term in [0, 1) that prefers the smaller mean inlier
+    residual (normalised by the largest mean of the whole tensor, so it never changes the order by count).
+    residuals (B,S,N) -> (indicator (B,S) f64, inlier_num (B,S) i64, inlier_mask (B,S,N) bool).  Plain tensor ops: the
+    RANSAC kernels compute the same ranking on the fly (vgg_fmat_score + the selection in `estimate_fundamental`)."""
+    inlier_mask = residuals <= max_residual
+    inlier_num = inlier_mask.sum(dim=-1)
+    ind = (inlier_mask.float() * residuals).sum(dim=-1) / inlier_num
+    ind = torch.nan_to_num(ind, nan=nanvalue, posinf=nanvalue, neginf=nanvalue)
+    thres = ind.max() + 1e-6
+    ind = (thres - ind) / thres
+    return ind.double() + inlier_num.double(), inlier_num, inlier_mask
+
+
+def sampson_epipolar_distance_batched(pts1, pts2, Fm, squared=True, eps=1e-8):
+    """utils.py:90-173: Sampson distance of the matches pts1 (B,N,2) <-> pts2 (B,N,2) under the fundamental matrices
+    Fm (B,K,3,3) -> (B,K,N); squared by default.  One launch of `vgg_fmat_residuals` over the B K (pair, hypothesis)
+    combinations, in float64."""
+    _lib.require_gpu(pts1, pts2, Fm)
+    B, N = pts1.shape[0], pts1.shape[1]
+    K = Fm.shape[1]
+    p1 = pts1[..., :2].to(torch.float64)[:, None].expand(-1, K, -1, -1).reshape(B * K, N, 2).contiguous()
+    p2 = pts2[..., :2].to(torch.float64)[:, None].expand(-1, K, -1, -1).reshape(B * K, N, 2).contiguous()
+    F = Fm.to(torch.float64).reshape(B * K, 9).contiguous()
+    vm = torch.ones((B * K, N), dtype=torch.uint8, device=pts1.device)
+    res = torch.empty((B * K, N), dtype=torch.float64, device=pts1.device)
+    _lib.check(_lib.lib().vgg_fmat_residuals(_lib.ptr(p1), _lib.ptr(p2), _lib.ptr(vm), _lib.ptr(F), B * K, N, _lib.ptr(res),
+                                             _lib.stream_ptr()), "vgg_fmat_residuals")
+    res = res.reshape(B, K, N)
+    return res if squared else (res + eps).sqrt()
+
+
+def inlier_by_fundamental(fmat, tracks, max_error=0.5):
+    """utils.py:300-322: fmat (B,S-1,3,3) of the pairs (frame 0, frame s), tracks (B,S,N,2) -> inlier mask (B,S-1,N):
+    squared Sampson distance <= max_error^2."""
+    B, S, N, _ = tracks.shape
+    left = tracks[:, 0:1].expand(-1, S - 1, -1, -1).reshape(B * (S - 1), N, 2)
+    right = tracks[:, 1:].reshape(B * (S - 1), N, 2)
+    res = sampson_epipolar_distance_batched(left, right, fmat.reshape(B * (S - 1), 1, 3, 3), squared=True)[:, 0]
+    return (res <= max_error ** 2).reshape(B, S - 1, N)
+
+
+def get_default_intri(width, height, device, dtype, ratio=1.0):
+    from .estimate_preliminary import get_default_intri as f
+    return f(width, height, device, dtype, ratio)
+
+
+def remove_cheirality(R, t, points1, points2, focal_length=None, principal_point=None):
+    from .estimate_preliminary import remove_cheirality as f
+    return f(R, t, points1, points2, focal_length, principal_point)

@@ -168,3 +168,25 @@ def test_sampson_distance_and_inlier_mask_match_oracle():
     for s_ in range(1, S):
         ref = OF.sampson_sq(F[0, s_ - 1][None], tracks[0, 0], tracks[0, s_])[0] <= 40.0 ** 2
         assert np.array_equal(mask[0, s_ - 1], ref)
+
+
+@pytest.mark.gpu
+def test_cheirality_helpers_on_a_known_pose():
+    """two_view_geo.utils.check_cheirality_batch / triangulate_point_batch (pair-triangulation kernel): with the true
+    relative pose every match triangulates in front of both cameras and lands on the ground-truth point; with the
+    pose mirrored (t -> -t) none does."""
+    from scipy.spatial.transform import Rotation
+    from vggsfm_amd.two_view_geo.utils import check_cheirality_batch
+    rng = np.random.default_rng(4)
+    N = 300
+    X = np.array([0.0, 0.0, 5.0]) + rng.uniform(-1, 1, size=(N, 3))
+    R = Rotation.from_rotvec([0.02, -0.1, 0.03]).as_matrix()
+    t = np.array([0.5, 0.05, 0.1])
+    x1 = X[:, :2] / X[:, 2:3]
+    Y = X @ R.T + t
+    x2 = Y[:, :2] / Y[:, 2:3]
+    dev = torch.device("cuda:0")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    nums, pts = check_cheirality_batch(T(np.stack([R, R])), T(np.stack([t, -t])), T(np.stack([x1, x1])), T(np.stack([x2, x2])))
+    assert nums.tolist() == [N, 0]
+    np.testing.assert_allclose(pts[0].cpu().numpy(), X, rtol=0, atol=1e-9)

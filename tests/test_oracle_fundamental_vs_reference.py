@@ -114,6 +114,16 @@ def test_residual_indicator_mirror_equals_reference():
             assert torch.equal(x, y)
 
 
+def test_depth_helper_mirror_equals_reference():
+    """vggsfm_amd.two_view_geo.utils.calculate_depth_batch = the reference's (triangulation.py imports it), bit for bit."""
+    rf, ru = _reference_modules()
+    from vggsfm_amd.two_view_geo.utils import calculate_depth_batch
+    rng = np.random.default_rng(6)
+    P = torch.from_numpy(rng.normal(size=(4, 3, 4)))
+    X = torch.from_numpy(rng.normal(size=(4, 33, 3)))
+    assert torch.equal(calculate_depth_batch(P, X), ru.calculate_depth_batch(P, X))
+
+
 def test_seven_point_pencil_matches_reference_modulo_the_cubic_solver():
     """run_7point (fundamental.py:339-469) with kornia's normalize_points restated and its solve_cubic replaced by
     numpy.roots (real roots, zeros elsewhere): the null-space pencil, the cubic's coefficients, the F[2,2] = 1 scaling and

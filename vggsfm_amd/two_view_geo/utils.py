@@ -69,3 +69,40 @@ def get_default_intri(width, height, device, dtype, ratio=1.0):
 def remove_cheirality(R, t, points1, points2, focal_length=None, principal_point=None):
     from .estimate_preliminary import remove_cheirality as f
     return f(R, t, points1, points2, focal_length, principal_point)
+
+
+def calculate_depth_batch(proj_matrices, points3D):
+    """utils.py:398-412: proj_matrices (B,3,4), points3D (B,N,3) -> depth (B,N) = third row of P [X; 1] (the operations of
+    the reference, in its order)."""
+    B, N, _ = points3D.shape
+    homo = torch.cat((points3D, torch.ones(B, N, 1, dtype=points3D.dtype, device=points3D.device)), dim=-1)
+    return torch.einsum("bij,bkj->bki", proj_matrices, homo)[..., 2]
+
+
+def triangulate_point_batch(cam1_from_world, cam2_from_world, points1, points2):
+    """utils.py:366-395: two-view DLT of the matches points1 / points2 (B,N,2, normalised image coordinates) under the
+    (B,3,4) camera pairs -> (B,N,3).  The 4 x 4 systems go through the pair-triangulation kernel
+    (``vgg_triangulate_by_pair``: smallest eigenvector of A^T A by Jacobi sweeps) instead of a batched SVD: the same
+    point up to rounding, one launch per pair."""
+    from ..utils.triangulation import triangulate_by_pair
+    out = []
+    for b in range(points1.shape[0]):
+        ext = torch.stack([cam1_from_world[b], cam2_from_world[b]]).to(torch.float64)[None]
+        trk = torch.stack([points1[b], points2[b]]).to(torch.float64)[None]
+        out.append(triangulate_by_pair(ext, trk)[0][0])
+    return torch.stack(out)
+
+
+def check_cheirality_batch(R, t, points1, points2):
+    """utils.py:415-448: for the B relative poses (R (B,3,3), t (B,3)) of the second camera, how many of the N matches
+    triangulate to a depth in (eps, 1000 x baseline) in both cameras -> (valid_nums (B,), points3D (B,N,3))."""
+    B = points1.shape[0]
+    R64, t64 = R.to(torch.float64), t.to(torch.float64)
+    P1 = torch.eye(3, 4, dtype=torch.float64, device=R.device).expand(B, -1, -1)
+    P2 = torch.cat([R64, t64[:, :, None]], dim=-1)
+    k_min = torch.finfo(torch.float64).eps
+    max_depth = 1000.0 * torch.linalg.norm(R64.transpose(-2, -1) @ t64[:, :, None], dim=1)
+    X = triangulate_point_batch(P1, P2, points1, points2)
+    d1, d2 = calculate_depth_batch(P1, X), calculate_depth_batch(P2, X)
+    valid = (d1 > k_min) & (d1 < max_depth) & (d2 > k_min) & (d2 < max_depth)
+    return valid.sum(dim=-1), X

@@ -32,7 +32,7 @@ int main(int argc, char** argv) {
         for (int k = 0; k < 4; ++k) hipMemsetAsync(d0 + 0, 0, 0, st);
       }
       hipEventRecord(e0, st);
-      vgg::cholesky_solve_enqueue(dA, dA + (size_t)n * n, n, ws, fail, nullptr, st, nullptr, split_a, split_b, nullptr);
+      vgg::cholesky_solve_enqueue(dA, dA + (size_t)n * n, n, ws, fail, nullptr, st, nullptr, split_a, split_b, nullptr, false);
       hipEventRecord(e1, st);
       hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -48,7 +48,7 @@ int main(int argc, char** argv) {
     unsigned long long* tr; hipMalloc(&tr, (size_t)tiles * 8 * 8); hipMemset(tr, 0, (size_t)tiles * 8 * 8);
     hipMemcpyToSymbol(HIP_SYMBOL(vgg::g_chol_trace), &tr, sizeof(tr));
     hipMemcpyAsync(dA, d0, A.size() * 8, hipMemcpyDeviceToDevice, st);
-    vgg::cholesky_solve_enqueue(dA, dA + (size_t)n * n, n, ws, fail, nullptr, st, nullptr, split_a, split_b, nullptr);
+    vgg::cholesky_solve_enqueue(dA, dA + (size_t)n * n, n, ws, fail, nullptr, st, nullptr, split_a, split_b, nullptr, false);
     hipStreamSynchronize(st);
     std::vector<unsigned long long> h((size_t)tiles * 8);
     hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost);

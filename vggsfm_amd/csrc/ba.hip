@@ -32,7 +32,9 @@
 namespace vgg {
 
 int cholesky_solve_enqueue(double* A, double* b, int n, double* inv_blocks, int32_t* device_fail, const int32_t* skip_flag,
-                           hipStream_t st, const CholOverlap* overlap, int split_a, int split_b, const int32_t* first_blk);
+                           hipStream_t st, const CholOverlap* overlap, int split_a, int split_b, const int32_t* first_blk,
+                           bool flags_cleared);
+int32_t* cholesky_dataflow_flags(double* ws, int n, size_t* count);
 size_t cholesky_workspace_bytes(int n);
 void dataflow_signal(int32_t* flag, hipStream_t st);
 
@@ -325,6 +327,14 @@ __global__ __launch_bounds__(256, (MODE == 1) ? VGG_CP_OCC_RHS : VGG_CP_OCC) voi
   __shared__ double tot[NV];
   if (w.ctl->done) return;
   if (MODE == 0 && !w.ctl->need_lin) return;
+  if (MODE == 1) {
+    // Zero the reduced system S | rhs for the tile sums and assemble_kernel that follow (nothing touches it in between, and
+    // the previous iteration is done with it): a few 16-byte stores per thread here instead of a fill launch
+    const size_t me = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x, nth = (size_t)gridDim.x * gridDim.y * 256;
+    double2* z = reinterpret_cast<double2*>(w.sys);
+    for (size_t i = me; i < w.sys_count / 2; i += nth) z[i] = make_double2(0.0, 0.0);
+    if (me == 0 && (w.sys_count & 1)) w.sys[w.sys_count - 1] = 0.0;
+  }
   const Dims& d = pb.d;
   // grid (C, split): a camera's observations are cut into `split` contiguous slices, one workgroup each (one
   // workgroup per camera left 200 workgroups = 0.8 wavefronts per SIMD on the chip); cam_reduce_kernel adds the
@@ -883,8 +893,10 @@ __device__ __forceinline__ void begin_iteration(const Ws& w, const vgg_ba_option
 
 // one workgroup: thread 0 runs the checks; then the constant / unobserved columns of the reduced system get a unit
 // diagonal and a zero right-hand side (their Jacobian columns are zero)
-__global__ __launch_bounds__(256) void begin_iteration_kernel(Ws w, vgg_ba_options opt, int n) {
+__global__ __launch_bounds__(256) void begin_iteration_kernel(Ws w, vgg_ba_options opt, int n, int32_t* chol_flags, int chol_flag_count) {
   if (w.ctl->done) return;
+  // the hand-off flags of the factorisation that follows (chol.hip, cholesky_dataflow_flags): cleared here, not by a fill launch
+  for (int j = threadIdx.x; j < chol_flag_count; j += 256) chol_flags[j] = 0;
   if (threadIdx.x == 0) begin_iteration(w, opt);
   for (int j = threadIdx.x; j < n; j += 256) {
     if (w.active[j]) continue;
@@ -1172,10 +1184,19 @@ __global__ __launch_bounds__(256) void tile_reduce_kernel(Ws w, int n_red, int C
   if (gI == gJ && col > row) return;             // diagonal tile is symmetric: the lower half is the unique source
   const int ri = (i < 6) ? 6 * ca + i : 6 * C + KD * ca + (i - 6);
   const int cj = (j < 6) ? 6 * cb + j : 6 * C + KD * cb + (j - 6);
+  // (eight loads in flight per thread; the order of the additions -- even chunks into s0, odd ones into s1 -- is fixed)
   double s0 = 0.0, s1 = 0.0;
   int ch = c0;
-  for (; ch + 1 < c1; ch += 2) { s0 += w.tile_part[(size_t)ch * R * R + e]; s1 += w.tile_part[(size_t)(ch + 1) * R * R + e]; }
-  if (ch < c1) s0 += w.tile_part[(size_t)ch * R * R + e];
+  const double* src = w.tile_part + e;
+  for (; ch + 7 < c1; ch += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(ch + u) * R * R];
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) { s0 += v[u]; s1 += v[u + 1]; }
+  }
+  for (; ch + 1 < c1; ch += 2) { s0 += src[(size_t)ch * R * R]; s1 += src[(size_t)(ch + 1) * R * R]; }
+  if (ch < c1) s0 += src[(size_t)ch * R * R];
   const int hi = ri > cj ? ri : cj, lo = ri > cj ? cj : ri;
   dst[(size_t)hi * n + lo] = -(s0 + s1);
 }
@@ -2046,7 +2067,7 @@ static void phase_schur(const Launch& L) {
     cam_pass_kernel<KD, 1><<<dim3(d.C, split), 256, 0, L.st>>>(L.dp, L.w);
     cam_reduce_kernel<KD, 1><<<d.C, 64, 0, L.st>>>(L.dp, L.w, split, L.wgB);
   }
-  (void)hipMemsetAsync(L.w.sys, 0, sizeof(double) * L.w.sys_count, L.st);
+  // (the reduced system was zeroed by cam_pass_kernel<KD, 1>: no fill launch)
   if (L.num_chunks > 0) {
     if (overlap_ctx(L)) {
       // only the first batch here; the others are enqueued by phase_step beside the factorisation and land in S2
@@ -2062,7 +2083,9 @@ static void phase_schur(const Launch& L) {
 template <int KD>
 static int phase_step(const Launch& L) {
   const Dims& d = L.d;
-  begin_iteration_kernel<<<1, 256, 0, L.st>>>(L.w, L.opt, d.n_red);
+  size_t chol_flag_count = 0;
+  int32_t* chol_flags = cholesky_dataflow_flags(L.w.chol_inv, d.n_red, &chol_flag_count);
+  begin_iteration_kernel<<<1, 256, 0, L.st>>>(L.w, L.opt, d.n_red, chol_flags, chol_flags ? (int)chol_flag_count : 0);
   int rc;
   if (OverlapCtx* oc = overlap_ctx(L)) {
     (void)hipMemsetAsync(L.w.batch_flags, 0, 64, L.st);
@@ -2082,14 +2105,14 @@ static int phase_step(const Launch& L) {
     {
       ProfScope ps(kProfCholesky, oc->st_chol);
       rc = cholesky_solve_enqueue(L.w.S, L.w.rhs, d.n_red, L.w.chol_inv, &L.w.ctl->linear_fail, &L.w.ctl->done, oc->st_chol, &ov,
-                                  L.chol_split_a, L.chol_split_b, L.chol_first_blk);
+                                  L.chol_split_a, L.chol_split_b, L.chol_first_blk, chol_flags != nullptr);
     }
     (void)hipEventRecord(oc->chol_done, oc->st_chol);
     (void)hipStreamWaitEvent(L.st, oc->chol_done, 0);
   } else {
     ProfScope ps(kProfCholesky, L.st);
     rc = cholesky_solve_enqueue(L.w.S, L.w.rhs, d.n_red, L.w.chol_inv, &L.w.ctl->linear_fail, &L.w.ctl->done, L.st, nullptr,
-                                L.chol_split_a, L.chol_split_b, L.chol_first_blk);
+                                L.chol_split_a, L.chol_split_b, L.chol_first_blk, chol_flags != nullptr);
   }
   if (rc != VGG_OK) return rc;
   cam_update_kernel<KD><<<div_up(d.C + 1, 64), 64, 0, L.st>>>(L.dp, L.w);

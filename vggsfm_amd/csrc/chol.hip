@@ -875,7 +875,10 @@ __device__ __forceinline__ void df_wait(const int32_t* flag, int32_t* fail) {
     int spins = 0;
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
       __builtin_amdgcn_s_sleep(4);
-      if (++spins > kSpinLimit) { if (fail) *fail = 2; break; }
+      ++spins;
+      // (a launch that has already failed is not waited out flag by flag)
+      const bool lost = fail && (spins & 1023) == 0 && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2;
+      if (spins > kSpinLimit || lost) { if (fail) __hip_atomic_store(fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
   }
   __syncthreads();
@@ -889,10 +892,11 @@ __device__ __forceinline__ void df_publish(int32_t* flag) {
 
 #ifdef VGG_CHOL_TRACE
 __device__ unsigned long long* g_chol_trace = nullptr;      // [tiles][8] wall-clock stamps (100 MHz), scripts/ubench/chol_bench
-#define DF_STAMP(slot) do { if (g_chol_trace && threadIdx.x == 0) g_chol_trace[(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
+#define DF_STAMP_AT(tile, slot) do { if (g_chol_trace && threadIdx.x == 0) g_chol_trace[(size_t)(tile) * 8 + (slot)] = wall_clock64(); } while (0)
 #else
-#define DF_STAMP(slot) do { } while (0)
+#define DF_STAMP_AT(tile, slot) do { } while (0)
 #endif
+#define DF_STAMP(slot) DF_STAMP_AT(blockIdx.x, slot)
 
 // 32 x 32 x 32 product on the matrix cores by the four wavefronts of a workgroup, operands read from LDS through
 // accessors: out(i, j) <- sum_k opA(i, k) * opB(j, k); wavefront w owns the 16 x 16 tile (w >> 1, w & 1).
@@ -951,11 +955,21 @@ struct DfShared {
 };
 
 // flags: ready[(nbk + 1) * nbk] (tile (r, c) final), then tready[nbk]; all zero on entry.
+//
+// CHAIN (chain != 0): the pivot chain  factor(c) -> L[c+1][c] = tile T_c -> last update of the diagonal tile (c+1,c+1) ->
+// factor(c+1)  used to cross two workgroup hand-offs per block column: T_c to the workgroup of tile (c+1,c), and its
+// product on to the workgroup of the diagonal tile (store, drain, flag, poll, reload: ~4 us of a 30 us step at n = 1202).
+// Where column c+1 couples to column c (first_of(c+1) <= c) the workgroup of tile (c+1,c) now finishes the diagonal tile
+// (c+1,c+1) as well: while it waits for T_c it accumulates the updates k < c of BOTH tiles (the diagonal's operand
+// L[c+1][k] is the one it stages anyway), and once X = L[c+1][c] exists in its registers it goes straight on to X X^T, the
+// subtraction from A and the factorisation -- the same operations in the same order as before, bit for bit.  The
+// diagonal tile's own workgroup returns at once.  A column that starts a decoupled block (camera split, envelope) keeps
+// its own workgroup, so the side-by-side chains remain.
 template <bool OVERLAP>
 __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__ A, int n, int nbk, double* __restrict__ Tinv,
                                                             int32_t* __restrict__ flags, int32_t* fail, const int32_t* skip,
                                                             int split_a, int split_b, const int32_t* __restrict__ first_blk,
-                                                            DfOverlap ov) {
+                                                            DfOverlap ov, int chain) {
   extern __shared__ double df_smem[];
   DfShared& sh = *reinterpret_cast<DfShared*>(df_smem);
   constexpr int LD = DFB + 1;
@@ -969,7 +983,14 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
     return (split_b > 0 && br < nbk && DFB * br >= split_a && DFB * (br + 1) <= split_a + split_b) ? split_a / DFB : 0;
   };
   if (c < first_of(r)) return;                          // structurally zero tile (block-diagonal leading part)
+  const bool diag = (r == c);
+  // the diagonal tile of column x is finished by the workgroup of tile (x, x - 1)
+  const bool chain_on = !OVERLAP && chain != 0;
+  auto chained = [&](int x) { return chain_on && x >= 1 && x < nbk && first_of(x) <= x - 1; };
+  if (diag && chained(c)) return;
+  const bool merged = !diag && r == c + 1 && chained(r);
   const int kfirst = max(first_of(r), first_of(c));
+  const int kstart = merged ? first_of(r) : kfirst;     // (the diagonal tile (r,r) starts at the row's own envelope)
   int32_t* ready = flags;
   int32_t* tready = flags + (size_t)(nbk + 1) * nbk;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -977,7 +998,8 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
   const int wy = wave >> 1, wx = wave & 1, li = lane & 15, lk = lane >> 4;
   const int r0 = (r == nbk) ? n : DFB * r, c0 = DFB * c;
   const int vr = (r == nbk) ? 1 : min(DFB, n - r0), vc = min(DFB, n - c0);
-  const bool diag = (r == c);
+  const int dtile = r * (nbk + 1) - r * (r - 1) / 2;    // launch position of diagonal tile r (trace of a merged workgroup)
+  (void)dtile;
   DF_STAMP(0);
 
   // Overlap with the Schur tile batches (ba.hip, options.overlap_factorization): the contributions to the columns >=
@@ -991,8 +1013,9 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
     if (need >= 0) df_wait(&ov.flags[need], fail);
     S2 = ov.S2;
   }
-  // the tile of A (C layout: row = 32 wy + 16 m + lk + 4 reg, col = 32 wx + 16 q + li) and the product accumulators
-  f64x4 acc[2][2], a0[2][2];
+  // the tile of A (C layout: row = 32 wy + 16 m + lk + 4 reg, col = 32 wx + 16 q + li) and the product accumulators;
+  // a merged workgroup carries the diagonal tile (r,r) along (a0d, accd)
+  f64x4 acc[2][2], a0[2][2], accd[2][2], a0d[2][2];
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -1004,33 +1027,13 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
         a0[m][q][reg] = in ? A[(size_t)(r0 + i) * n + c0 + j] : 0.0;
         if (OVERLAP && S2 && in) a0[m][q][reg] += ld_agent(&S2[(size_t)(r0 + i) * n + c0 + j]);
         acc[m][q][reg] = 0.0;
+        a0d[m][q][reg] = (merged && i < vr && j < vr && j <= i) ? A[(size_t)(r0 + i) * n + r0 + j] : 0.0;
+        accd[m][q][reg] = 0.0;
       }
 
-  // left-looking updates: acc -= L[r][k] L[c][k]^T.  k-index permutation of the MFMA steps: lane group lk supplies the 16
-  // consecutive columns 16 lk .. 16 lk + 15 of the operand row (same permutation for both operands)
-  for (int k = kfirst; k < c; ++k) {
-    df_wait(&ready[(size_t)r * nbk + k], fail);
-    if (!diag) df_wait(&ready[(size_t)c * nbk + k], fail);
-    const int k0 = DFB * k;
-    // stage the two operand tiles through LDS: coalesced row reads (one 512-byte row per wavefront instruction)
-    double* bufA = sh.D;
-    double* bufB = diag ? sh.D : sh.T;
-    {
-      double va[16], vb[16];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = (tid >> 6) + 4 * q, col = lane;
-        va[q] = (row < vr) ? ld_agent(&A[(size_t)(r0 + row) * n + k0 + col]) : 0.0;
-        if (!diag) vb[q] = (row < vc) ? ld_agent(&A[(size_t)(c0 + row) * n + k0 + col]) : 0.0;
-      }
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = (tid >> 6) + 4 * q, col = lane;
-        bufA[row * LD + col] = va[q];
-        if (!diag) bufB[row * LD + col] = vb[q];
-      }
-    }
-    __syncthreads();
+  // sum += (rows of bufA) (rows of bufB)^T over the 64 columns staged in LDS.  k-index permutation of the MFMA steps: lane
+  // group lk supplies the 16 consecutive columns 16 lk .. 16 lk + 15 of the operand row (same permutation for both operands)
+  auto multiply_staged = [&](const double* bufA, const double* bufB, f64x4 (&sum)[2][2]) __attribute__((always_inline)) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       double a[2][8], b[2][8];
@@ -1049,8 +1052,37 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
         for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int q = 0; q < 2; ++q)
-            acc[m][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][s8], b[q][s8], acc[m][q], 0, 0, 0);
+            sum[m][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][s8], b[q][s8], sum[m][q], 0, 0, 0);
     }
+  };
+
+  // left-looking updates: acc += L[r][k] L[c][k]^T  (merged: and accd += L[r][k] L[r][k]^T)
+  for (int k = kstart; k < c; ++k) {
+    const bool do_tile = k >= kfirst;
+    df_wait(&ready[(size_t)r * nbk + k], fail);
+    if (!diag && do_tile) df_wait(&ready[(size_t)c * nbk + k], fail);
+    const int k0 = DFB * k;
+    // stage the two operand tiles through LDS: coalesced row reads (one 512-byte row per wavefront instruction)
+    double* bufA = sh.D;
+    double* bufB = diag ? sh.D : sh.T;
+    {
+      double va[16], vb[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = (tid >> 6) + 4 * q, col = lane;
+        va[q] = (row < vr) ? ld_agent(&A[(size_t)(r0 + row) * n + k0 + col]) : 0.0;
+        if (!diag) vb[q] = (do_tile && row < vc) ? ld_agent(&A[(size_t)(c0 + row) * n + k0 + col]) : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = (tid >> 6) + 4 * q, col = lane;
+        bufA[row * LD + col] = va[q];
+        if (!diag) bufB[row * LD + col] = vb[q];
+      }
+    }
+    __syncthreads();
+    if (do_tile) multiply_staged(bufA, bufB, acc);
+    if (merged) multiply_staged(bufA, bufA, accd);
     __syncthreads();                                     // operands consumed: the buffers may be refilled
   }
 
@@ -1069,26 +1101,30 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
       }
   __syncthreads();
 
-  if (diag) {
+  // the factorisation of the diagonal block in sh.D, then T first -- the tiles of the column wait for it -- and L_bb
+  // (which nobody waits for: it only matters through T_b and as output)
+  auto factor_and_publish = [&](int bc, int b0, int vb, int trace_tile) __attribute__((always_inline)) {
+    (void)trace_tile;
     factor64(sh.D, sh.T, sh.rd, sh.scr, fail);
-    DF_STAMP(2);                                         // factored
-    // T_c first -- the tiles of this column wait for it -- then the flag, then L_cc (which nobody waits for: it only
-    // matters through T_c and as output)
+    DF_STAMP_AT(trace_tile, 2);                          // factored
     for (int e = tid; e < DFB * DFB; e += 256) {
       const int i = e / DFB, j = e % DFB;
-      st_agent(&Tinv[(size_t)c * DFB * DFB + e], (j >= i) ? sh.T[i * LD + j] : 0.0);
+      st_agent(&Tinv[(size_t)bc * DFB * DFB + e], (j >= i) ? sh.T[i * LD + j] : 0.0);
     }
-    df_publish(&tready[c]);
-    DF_STAMP(3);                                         // published
+    df_publish(&tready[bc]);
+    DF_STAMP_AT(trace_tile, 3);                          // published
     for (int e = tid; e < DFB * DFB; e += 256) {
       const int i = e / DFB, j = e % DFB;
 #ifdef VGG_DF_L_AGENT
-      if (j <= i && i < vc) st_agent(&A[(size_t)(c0 + i) * n + c0 + j], sh.D[i * LD + j]);
+      if (j <= i && i < vb) st_agent(&A[(size_t)(b0 + i) * n + b0 + j], sh.D[i * LD + j]);
 #else
-      if (j <= i && i < vc) A[(size_t)(c0 + i) * n + c0 + j] = sh.D[i * LD + j];
+      if (j <= i && i < vb) A[(size_t)(b0 + i) * n + b0 + j] = sh.D[i * LD + j];
 #endif
     }
-    // (ready[c][c] is never waited for: L_cc only matters through T_c)
+    // (ready[b][b] is never waited for: L_bb only matters through T_b)
+  };
+  if (diag) {
+    factor_and_publish(c, c0, vc, blockIdx.x);
     return;
   }
 
@@ -1121,6 +1157,7 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
         for (int q = 0; q < 2; ++q)
           x[m][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][s8], b[q][s8], x[m][q], 0, 0, 0);
   }
+  if (merged) __syncthreads();                           // the tile value in sh.D is consumed: X goes there
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -1129,10 +1166,33 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
       for (int reg = 0; reg < 4; ++reg) {
         const int i = 32 * wy + 16 * m + lk + 4 * reg, j = 32 * wx + 16 * q + li;
         if (i < vr && j < vc) st_agent(&A[(size_t)(r0 + i) * n + c0 + j], x[m][q][reg]);
+        if (merged) sh.D[i * LD + j] = x[m][q][reg];     // (rows past the end of the matrix are zero)
       }
   DF_STAMP(4);                                           // product done, stores issued
-  df_publish(&ready[(size_t)r * nbk + c]);
+  if (!merged) {
+    df_publish(&ready[(size_t)r * nbk + c]);
+    DF_STAMP(3);
+    return;
+  }
+  // merged: the last update of the diagonal tile (r,r) with the X just formed, then its factorisation
+  __syncthreads();
+  multiply_staged(sh.D, sh.D, accd);
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int i = 32 * wy + 16 * m + lk + 4 * reg, j = 32 * wx + 16 * q + li;
+        double v = a0d[m][q][reg] - accd[m][q][reg];
+        if (i >= vr || j >= vr) v = (i == j) ? 1.0 : 0.0;
+        sh.D[i * LD + j] = v;
+      }
+  df_publish(&ready[(size_t)r * nbk + c]);               // (X was stored two products ago: the drain is short; + barrier)
   DF_STAMP(3);
+  DF_STAMP_AT(dtile, 1);                                 // diagonal tile r: updates applied
+  factor_and_publish(r, r0, vr, dtile);
 }
 
 // Backward substitution L^T x = z in dataflow form: one workgroup per 64-column block c (launched last block first, so
@@ -1229,12 +1289,26 @@ static bool use_dataflow(int n) {
 __global__ void df_signal_kernel(int32_t* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 void dataflow_signal(int32_t* flag, hipStream_t st) { df_signal_kernel<<<1, 1, 0, st>>>(flag); }
 
+// The flags of the dataflow factorisation inside `ws` (nullptr when a system of n unknowns takes the multi-launch path).  A
+// caller that zeroes them itself -- *count int32, any time between the previous solve in this workspace and the next one
+// (bundle adjustment: in a kernel it launches anyway) -- passes flags_cleared = true and saves the fill launch.
+int32_t* cholesky_dataflow_flags(double* ws, int n, size_t* count) {
+  if (!ws || !use_dataflow(n)) return nullptr;
+  if (count) *count = dataflow_flag_count(n);
+  return reinterpret_cast<int32_t*>(ws + (size_t)div_up(n, DFB) * DFB * DFB);
+}
+
 static int enqueue_dataflow(double* A, double* b, int n, double* ws, int32_t* device_fail, const int32_t* skip, hipStream_t st,
-                            int split_a, int split_b, const int32_t* first_blk, const CholOverlap* overlap = nullptr) {
+                            int split_a, int split_b, const int32_t* first_blk, const CholOverlap* overlap, bool flags_cleared) {
   const int nbk = div_up(n, DFB);
   double* Tinv = ws;
   int32_t* flags = reinterpret_cast<int32_t*>(ws + (size_t)nbk * DFB * DFB);
-  if (hipMemsetAsync(flags, 0, dataflow_flag_count(n) * sizeof(int32_t), st) != hipSuccess) return VGG_ERR_HIP;
+  // VGG_CHOL_CHAIN=0 / 1 in the environment: every diagonal tile in a workgroup of its own / chained (A/B measurements)
+  // (default: chained up to 64 block columns -- beyond, the dense left-looking update queue of a late column's workgroup
+  // is what the chain waits for, and a merged workgroup carries two of them; measured in DESIGN.md section 6)
+  static const int chain_env = [] { const char* e = getenv("VGG_CHOL_CHAIN"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
+  const int chain = chain_env >= 0 ? chain_env : (nbk <= 64 ? 1 : 0);
+  if (!flags_cleared && hipMemsetAsync(flags, 0, dataflow_flag_count(n) * sizeof(int32_t), st) != hipSuccess) return VGG_ERR_HIP;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_dataflow_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1250,8 +1324,8 @@ static int enqueue_dataflow(double* A, double* b, int n, double* ws, int32_t* de
     ov.S2 = overlap->S2; ov.flags = overlap->dev_flags; ov.first_col = overlap->first_col; ov.num_waits = overlap->num_waits;
     for (int k = 0; k < overlap->num_waits && k < 8; ++k) ov.wait_col[k] = overlap->wait_col[k];
   }
-  if (ov.S2) chol_dataflow_kernel<true><<<tiles, 256, sizeof(DfShared), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b, first_blk, ov);
-  else chol_dataflow_kernel<false><<<tiles, 256, sizeof(DfShared), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b, first_blk, ov);
+  if (ov.S2) chol_dataflow_kernel<true><<<tiles, 256, sizeof(DfShared), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b, first_blk, ov, chain);
+  else chol_dataflow_kernel<false><<<tiles, 256, sizeof(DfShared), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b, first_blk, ov, chain);
   int32_t* xready = flags + (size_t)(nbk + 1) * nbk + nbk;
   chol_backward_dataflow_kernel<<<nbk, 256, 0, st>>>(A, b, n, nbk, Tinv, xready, device_fail, skip, split_a, split_b, first_blk);
   if (hipGetLastError() != hipSuccess) return VGG_ERR_HIP;
@@ -1336,10 +1410,11 @@ static int enqueue(double* A, double* b, int n, double* inv_blocks, int32_t* dev
 }
 
 int cholesky_solve_enqueue(double* A, double* b, int n, double* inv_blocks, int32_t* device_fail, const int32_t* skip,
-                           hipStream_t st, const CholOverlap* overlap, int split_a, int split_b, const int32_t* first_blk) {
+                           hipStream_t st, const CholOverlap* overlap, int split_a, int split_b, const int32_t* first_blk,
+                           bool flags_cleared) {
   if (!inv_blocks) return VGG_ERR_INVALID_ARGUMENT;
   if ((!overlap || overlap->dev_flags) && b == A + (size_t)n * n && use_dataflow(n))
-    return enqueue_dataflow(A, b, n, inv_blocks, device_fail, skip, st, split_a, split_b, first_blk, overlap);
+    return enqueue_dataflow(A, b, n, inv_blocks, device_fail, skip, st, split_a, split_b, first_blk, overlap, flags_cleared);
   return enqueue<32>(A, b, n, inv_blocks, device_fail, skip, st, overlap, split_a, split_b);
 }
 
@@ -1350,19 +1425,19 @@ size_t vgg_cholesky_workspace_bytes(int n) { return n > 0 ? vgg::cholesky_worksp
 
 int vgg_cholesky_solve(double* A, double* b, int n, void* workspace, int32_t* device_fail, void* stream) {
   if (n <= 0 || !A || !b || !workspace) return VGG_ERR_INVALID_ARGUMENT;
-  return vgg::cholesky_solve_enqueue(A, b, n, (double*)workspace, device_fail, nullptr, (hipStream_t)stream, nullptr, 0, 0, nullptr);
+  return vgg::cholesky_solve_enqueue(A, b, n, (double*)workspace, device_fail, nullptr, (hipStream_t)stream, nullptr, 0, 0, nullptr, false);
 }
 
 int vgg_cholesky_solve_envelope(double* A, double* b, int n, const int32_t* first_blk, void* workspace, int32_t* device_fail,
                                 void* stream) {
   if (n <= 0 || !A || !b || !workspace || !first_blk) return VGG_ERR_INVALID_ARGUMENT;
-  return vgg::cholesky_solve_enqueue(A, b, n, (double*)workspace, device_fail, nullptr, (hipStream_t)stream, nullptr, 0, 0, first_blk);
+  return vgg::cholesky_solve_enqueue(A, b, n, (double*)workspace, device_fail, nullptr, (hipStream_t)stream, nullptr, 0, 0, first_blk, false);
 }
 
 int vgg_cholesky_solve_split(double* A, double* b, int n, int split_a, int split_b, void* workspace, int32_t* device_fail,
                              void* stream) {
   if (n <= 0 || !A || !b || !workspace || split_a < 0 || split_b < 0 || split_a + split_b > n) return VGG_ERR_INVALID_ARGUMENT;
   return vgg::cholesky_solve_enqueue(A, b, n, (double*)workspace, device_fail, nullptr, (hipStream_t)stream, nullptr, split_a,
-                                     split_b, nullptr);
+                                     split_b, nullptr, false);
 }
 }

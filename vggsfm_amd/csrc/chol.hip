@@ -947,11 +947,14 @@ __device__ __forceinline__ void factor64(double* D, double* Tl, double* rd, doub
   __syncthreads();
 }
 
+constexpr int kDfOrderMax = 64;               // block columns up to which the chain and the update order below are used
+
 struct DfShared {
   double D[DFB * (DFB + 1)];
   double T[DFB * (DFB + 1)];
   double scr[2 * 2 * DFB * 4];
   double rd[DFB];
+  int32_t depth[kDfOrderMax], order[kDfOrderMax];
 };
 
 // flags: ready[(nbk + 1) * nbk] (tile (r, c) final), then tready[nbk]; all zero on entry.
@@ -965,11 +968,12 @@ struct DfShared {
 // subtraction from A and the factorisation -- the same operations in the same order as before, bit for bit.  The
 // diagonal tile's own workgroup returns at once.  A column that starts a decoupled block (camera split, envelope) keeps
 // its own workgroup, so the side-by-side chains remain.
-template <bool OVERLAP>
+template <bool OVERLAP, bool CHAIN>
 __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__ A, int n, int nbk, double* __restrict__ Tinv,
                                                             int32_t* __restrict__ flags, int32_t* fail, const int32_t* skip,
                                                             int split_a, int split_b, const int32_t* __restrict__ first_blk,
-                                                            DfOverlap ov, int chain) {
+                                                            DfOverlap ov) {
+  static_assert(!(OVERLAP && CHAIN), "the chained form does not take the overlap flags");
   extern __shared__ double df_smem[];
   DfShared& sh = *reinterpret_cast<DfShared*>(df_smem);
   constexpr int LD = DFB + 1;
@@ -985,10 +989,9 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
   if (c < first_of(r)) return;                          // structurally zero tile (block-diagonal leading part)
   const bool diag = (r == c);
   // the diagonal tile of column x is finished by the workgroup of tile (x, x - 1)
-  const bool chain_on = !OVERLAP && chain != 0;
-  auto chained = [&](int x) { return chain_on && x >= 1 && x < nbk && first_of(x) <= x - 1; };
+  auto chained = [&](int x) { return CHAIN && x >= 1 && x < nbk && first_of(x) <= x - 1; };
   if (diag && chained(c)) return;
-  const bool merged = !diag && r == c + 1 && chained(r);
+  const bool merged = CHAIN && !diag && r == c + 1 && chained(r);
   const int kfirst = max(first_of(r), first_of(c));
   const int kstart = merged ? first_of(r) : kfirst;     // (the diagonal tile (r,r) starts at the row's own envelope)
   int32_t* ready = flags;
@@ -1056,8 +1059,41 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
     }
   };
 
+  // ORDER of the left-looking updates.  Where decoupled blocks meet (camera split [A, B, rest], k-way envelope) a tile of
+  // the rows behind them has update columns from several pivot chains that finish at different times; taken in ascending
+  // order, the columns of the chain that started later (B: available long ago) queue behind the last column of the longer
+  // one (A), and that queue sits on the critical path (c3: four updates, ~20 us, after A's last column).  So the columns
+  // are taken by DEPTH in the dependence graph -- depth(k) = 1 + max depth over the block columns row k couples to, a
+  // stand-in for "when column k completes" -- then by index: a fixed order (a function of the envelope alone: results are
+  // reproducible run to run), equal to the ascending one for a dense matrix.  Every workgroup derives it for itself
+  // (~3 us at 50 block columns, hidden behind its first wait); past kDfOrderMax block columns the launch is bound by the
+  // number of resident workgroups and those microseconds would add up (c5, 94 block columns: +6 %), so the order stays
+  // ascending there.
+  const int nupd = c - kstart;
+  const bool by_depth = CHAIN && nupd >= 2 && nbk <= kDfOrderMax;
+  if (by_depth) {
+    if (wave == 0) {
+      volatile int32_t* dep = sh.depth;              // (lane 0 writes what the other lanes read one step later)
+      for (int k = 0; k < c; ++k) {
+        const int f = first_of(k);
+        int m = 0;
+        for (int j = f + lane; j < k; j += 64) m = max(m, dep[j]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
+        if (lane == 0) dep[k] = m + 1;
+      }
+      for (int idx = lane; idx < nupd; idx += 64) {
+        const int k = kstart + idx, dk = dep[k];
+        int rank = 0;
+        for (int k2 = kstart; k2 < c; ++k2) { const int d2 = dep[k2]; rank += (d2 < dk) || (d2 == dk && k2 < k); }
+        sh.order[rank] = k;
+      }
+    }
+    __syncthreads();
+  }
   // left-looking updates: acc += L[r][k] L[c][k]^T  (merged: and accd += L[r][k] L[r][k]^T)
-  for (int k = kstart; k < c; ++k) {
+  for (int t = 0; t < nupd; ++t) {
+    const int k = by_depth ? sh.order[t] : kstart + t;
     const bool do_tile = k >= kfirst;
     df_wait(&ready[(size_t)r * nbk + k], fail);
     if (!diag && do_tile) df_wait(&ready[(size_t)c * nbk + k], fail);
@@ -1307,14 +1343,15 @@ static int enqueue_dataflow(double* A, double* b, int n, double* ws, int32_t* de
   // (default: chained up to 64 block columns -- beyond, the dense left-looking update queue of a late column's workgroup
   // is what the chain waits for, and a merged workgroup carries two of them; measured in DESIGN.md section 6)
   static const int chain_env = [] { const char* e = getenv("VGG_CHOL_CHAIN"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
-  const int chain = chain_env >= 0 ? chain_env : (nbk <= 64 ? 1 : 0);
+  const int chain = chain_env >= 0 ? chain_env : (nbk <= kDfOrderMax ? 1 : 0);
   if (!flags_cleared && hipMemsetAsync(flags, 0, dataflow_flag_count(n) * sizeof(int32_t), st) != hipSuccess) return VGG_ERR_HIP;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_dataflow_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)sizeof(DfShared)) != hipSuccess) return VGG_ERR_HIP;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_dataflow_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)sizeof(DfShared)) != hipSuccess) return VGG_ERR_HIP;
+    const void* kernels[3] = {reinterpret_cast<const void*>(&chol_dataflow_kernel<false, false>),
+                              reinterpret_cast<const void*>(&chol_dataflow_kernel<false, true>),
+                              reinterpret_cast<const void*>(&chol_dataflow_kernel<true, false>)};
+    for (const void* k : kernels)
+      if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DfShared)) != hipSuccess) return VGG_ERR_HIP;
     attr_set = true;
   }
   if (!(split_a >= DFB && split_b >= DFB && split_a % DFB == 0 && split_a + split_b <= n)) split_a = split_b = 0;
@@ -1324,8 +1361,9 @@ static int enqueue_dataflow(double* A, double* b, int n, double* ws, int32_t* de
     ov.S2 = overlap->S2; ov.flags = overlap->dev_flags; ov.first_col = overlap->first_col; ov.num_waits = overlap->num_waits;
     for (int k = 0; k < overlap->num_waits && k < 8; ++k) ov.wait_col[k] = overlap->wait_col[k];
   }
-  if (ov.S2) chol_dataflow_kernel<true><<<tiles, 256, sizeof(DfShared), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b, first_blk, ov, chain);
-  else chol_dataflow_kernel<false><<<tiles, 256, sizeof(DfShared), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b, first_blk, ov, chain);
+  if (ov.S2) chol_dataflow_kernel<true, false><<<tiles, 256, sizeof(DfShared), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b, first_blk, ov);
+  else if (chain) chol_dataflow_kernel<false, true><<<tiles, 256, sizeof(DfShared), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b, first_blk, ov);
+  else chol_dataflow_kernel<false, false><<<tiles, 256, sizeof(DfShared), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b, first_blk, ov);
   int32_t* xready = flags + (size_t)(nbk + 1) * nbk + nbk;
   chol_backward_dataflow_kernel<<<nbk, 256, 0, st>>>(A, b, n, nbk, Tinv, xready, device_fail, skip, split_a, split_b, first_blk);
   if (hipGetLastError() != hipSuccess) return VGG_ERR_HIP;

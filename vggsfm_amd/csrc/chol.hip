@@ -1,8 +1,12 @@
 // Dense fp64 Cholesky solve of the reduced camera system (6C+K unknowns) on gfx950.
 //
 // In the reference this is the DENSE_SCHUR / SPARSE_SCHUR factorisation inside Ceres, reached through
-// pycolmap.bundle_adjustment (vggsfm/utils/triangulation.py:213,1050,1142).  Here: right-looking blocked
-// Cholesky, two launches per block column of NB columns:
+// pycolmap.bundle_adjustment (vggsfm/utils/triangulation.py:213,1050,1142).  Two paths:
+//   * n >= 128 with the right-hand side stored behind the matrix (what bundle adjustment passes): ONE launch, a
+//     workgroup per 64 x 64 tile, left-looking, tiles handed over through per-tile flags -- chol_dataflow_kernel and
+//     chol_backward_dataflow_kernel in the second half of this file;
+//   * otherwise (and with VGG_CHOL_LEGACY=1): the multi-launch form described next -- right-looking blocked
+//     Cholesky, two launches per block column of NB columns:
 //   panel  : every workgroup re-factors the NB x NB diagonal block in LDS (outer-product form, ONE barrier per
 //            column, reciprocal instead of divide), then solves the panel rows below by forward
 //            substitution, one row per lane with the row in NB registers; one extra workgroup pushes the
@@ -965,8 +969,8 @@ struct DfShared {
 // Where column c+1 couples to column c (first_of(c+1) <= c) the workgroup of tile (c+1,c) now finishes the diagonal tile
 // (c+1,c+1) as well: while it waits for T_c it accumulates the updates k < c of BOTH tiles (the diagonal's operand
 // L[c+1][k] is the one it stages anyway), and once X = L[c+1][c] exists in its registers it goes straight on to X X^T, the
-// subtraction from A and the factorisation -- the same operations in the same order as before, bit for bit.  The
-// diagonal tile's own workgroup returns at once.  A column that starts a decoupled block (camera split, envelope) keeps
+// subtraction from A and the factorisation -- per element the operations the two workgroups performed before, in the
+// same order.  The diagonal tile's own workgroup returns at once.  A column that starts a decoupled block (camera split, envelope) keeps
 // its own workgroup, so the side-by-side chains remain.
 template <bool OVERLAP, bool CHAIN>
 __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__ A, int n, int nbk, double* __restrict__ Tinv,

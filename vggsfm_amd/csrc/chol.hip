@@ -982,6 +982,9 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
   DfShared& sh = *reinterpret_cast<DfShared*>(df_smem);
   constexpr int LD = DFB + 1;
   if (skip && *skip) return;
+  // This launch is a latency chain with one wavefront per SIMD: whatever else is resident on the CU (a tile batch in
+  // overlap mode; DESIGN.md section 6 on the boxes where something outside the process is) must not take its issue slots
+  __builtin_amdgcn_s_setprio(3);
   // tile of this workgroup: column c holds rows c .. nbk-1 and the rhs row block nbk
   int c = 0, t = blockIdx.x;
   while (t >= nbk - c + 1) { t -= nbk - c + 1; ++c; }
@@ -1250,6 +1253,7 @@ __global__ __launch_bounds__(256) void chol_backward_dataflow_kernel(const doubl
   __shared__ double Ts[DFB * LD];
   __shared__ double xs[DFB], part[4][DFB], w[DFB];
   if (skip && *skip) return;
+  __builtin_amdgcn_s_setprio(3);                   // (as in chol_dataflow_kernel)
   const int c = nbk - 1 - (int)blockIdx.x, c0 = DFB * c, vc = min(DFB, n - c0);
   const int tid = threadIdx.x, j = tid & 63, q = tid >> 6;          // thread: column j of the tile, rows 16 q .. 16 q + 15
   auto first_of = [&](int br) {

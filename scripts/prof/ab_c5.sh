@@ -1,3 +1,4 @@
+# needs vggsfm_amd/_variants/lib_head.so: scripts/prof/build_ref_variant.sh <git-ref of the build to compare with>
 # c5 video, in-tree library against the previous build (same box)
 for v in head new head new; do
   if [ $v = head ]; then export VGGSFM_AMD_LIB=$PWD/vggsfm_amd/_variants/lib_head.so; else unset VGGSFM_AMD_LIB; fi

@@ -1,3 +1,4 @@
+# needs vggsfm_amd/_variants/lib_head.so: scripts/prof/build_ref_variant.sh <git-ref of the build to compare with>
 for i in 1 2; do
   for v in new head nochain; do
     if [ $v = head ]; then export VGGSFM_AMD_LIB=$PWD/vggsfm_amd/_variants/lib_head.so; else unset VGGSFM_AMD_LIB; fi

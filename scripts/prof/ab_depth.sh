@@ -1,4 +1,5 @@
 # depth-ordered updates: standalone factorisation, its tests, c3 / c4shard bench and the c5 video against the previous build
+# (the "head" legs need vggsfm_amd/_variants/lib_head.so: scripts/prof/build_ref_variant.sh <git-ref>)
 scripts/ubench/chol_bench 1202 384 288 | grep "mode=0\|residual"
 scripts/ubench/chol_bench 3200 1024 960 | grep "mode=0\|residual"
 scripts/ubench/chol_bench_trace 1202 384 288 | tail -12

@@ -36,8 +36,11 @@ CASES = {
     # BASELINE configs[1] at full size (50 frames x 20k tracks, per-frame SIMPLE_PINHOLE): ~40 min of reference CPU time.
     # Stored COMPACT: the inputs are regenerated from the seed by inputs() (a sha256 of them is kept), only outputs are saved.
     "pinhole_s50_c2": (50, 20000, "SIMPLE_PINHOLE", False, 35, dict(BA_iters=1, robust_refine=1)),
+    # the camera model and the view count of BASELINE configs[2] (200 frames, shared SIMPLE_RADIAL) at 3000 tracks: the
+    # 200-view regime of the triangulation kernel, the shared-intrinsics BA and the undistortion, end to end (compact)
+    "radial_shared_s200": (200, 3000, "SIMPLE_RADIAL", True, 36, dict(BA_iters=1, robust_refine=1)),
 }
-COMPACT = {"pinhole_s50_c2"}
+COMPACT = {"pinhole_s50_c2", "radial_shared_s200"}
 
 
 def input_digest(inp):

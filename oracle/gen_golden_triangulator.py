@@ -39,8 +39,11 @@ CASES = {
     # the camera model and the view count of BASELINE configs[2] (200 frames, shared SIMPLE_RADIAL) at 3000 tracks: the
     # 200-view regime of the triangulation kernel, the shared-intrinsics BA and the undistortion, end to end (compact)
     "radial_shared_s200": (200, 3000, "SIMPLE_RADIAL", True, 36, dict(BA_iters=1, robust_refine=1)),
+    # the camera model of BASELINE configs[3] (per-frame SIMPLE_RADIAL: 8 x 8 camera blocks, 128 x 128 Schur tiles) at 120
+    # frames x 2000 tracks (compact)
+    "radial_s120": (120, 2000, "SIMPLE_RADIAL", False, 37, dict(BA_iters=1, robust_refine=1)),
 }
-COMPACT = {"pinhole_s50_c2", "radial_shared_s200"}
+COMPACT = {"pinhole_s50_c2", "radial_shared_s200", "radial_s120"}
 
 
 def input_digest(inp):

@@ -1,7 +1,6 @@
 """Cost model of the Schur tile kernels on the visibility of bench workload c3 (numpy, no GPU): executed MFMAs and staged
 bytes of (a) today's kernel, (b) sub-tile skipping by per-batch presence masks, (c) 2x2 super-tiles (192 x 192, 8
 wavefronts) with skipping.  Used to decide what to build."""
-import sys
 import numpy as np
 
 S, N = 200, 100000

@@ -2,7 +2,6 @@
 restatement in oracle/ba_oracle.c on identical seeded inputs.
 Bar (BASELINE.json north_star): camera poses and 3D points within 1e-4 relative -- these tests use
 much tighter bounds because both sides are fp64 and follow the same LM trajectory."""
-import ctypes
 
 import numpy as np
 import pytest

@@ -1,7 +1,6 @@
 """COLMAP binary model writer (vggsfm_amd/pycolmap_compat.py: Reconstruction.write) vs the reference's own reader
 (vggsfm/datasets/imc_helper.py, imported through the stub harness when /root/reference exists) and vs a
 minimal independent parser of the documented layout.  CPU only."""
-import os
 import struct
 
 import numpy as np

@@ -1,8 +1,6 @@
 """Helpers of the two-view stage under the reference's names (vggsfm/two_view_geo/utils.py): the sample generator, the
 Sampson distance and the inlier test on the device (``vgg_fmat_residuals``), the hypothesis score, and the re-exports
 of the helpers `estimate_preliminary_cameras` uses."""
-import ctypes
-
 import numpy as np
 import torch
 

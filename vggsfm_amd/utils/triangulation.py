@@ -8,7 +8,6 @@ triangulation.py:712-758, 804-813), so the hypothesis view pairs are identical f
 import ctypes
 import math
 
-import numpy as np
 import torch
 
 from .. import _lib

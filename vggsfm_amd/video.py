@@ -21,7 +21,7 @@ from . import ba as _ba
 from .ba import window_bundle_adjustment  # noqa: F401  (re-export: the local BA of a window)
 from .ba_options import AbsolutePoseEstimationOptions, AbsolutePoseRefinementOptions, BundleAdjustmentOptions
 from .pose import absolute_pose_estimation_batch, pose_refinement_batch
-from .utils.triangulation import _from_intr_params, _intr_params, triangulate_tracks
+from .utils.triangulation import _intr_params, triangulate_tracks
 from .utils.triangulation_helpers import cam_from_img, filter_all_points3D
 
 

@@ -57,28 +57,9 @@ def test_quaternion_conversion_matches_oracle():
     np.testing.assert_allclose(BA.quat_to_rotmat(T(q)).numpy(), R, atol=1e-14)
 
 
-@pytest.mark.parametrize("density_cut", [0.0, 2.0])    # in-place filtering of the grid / the observation-list construction
-@pytest.mark.parametrize("S,N", [(5, 40), (40, 300), (70, 150)])
-def test_compile_problem_matches_oracle_construction(S, N, density_cut, monkeypatch):
-    monkeypatch.setattr(BA, "SUPER_TILES", False)        # (the 2 x 2 super-tile list has its own test below)
-    monkeypatch.setattr(BA, "SPARSE_GRID_DENSITY", density_cut)
-    sc = make_scene(S, N, "SIMPLE_RADIAL", shared_camera=True, seed=S)
-    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=S)
-    masks = sc.mask.copy()
-    masks[:, 3] = False
-    masks[0, 3] = True                     # single observation: not a point
-    pts0[5] = [0, 0, -2.0]                 # behind everything
-    pts0[6, 0] = 4000.0                    # >= 3000
-    masks[2:, 7] = False
-    pts0[7] = -pts0[7]
-    prob, valid_idx, deleted = BA.compile_problem(T(pts0), T(ext0), T(K0), T(sc.tracks), T(masks), T(extra0), True,
-                                                  "SIMPLE_RADIAL")
-    vi, row_ptr, obs_cam, obs_uv, dele = OB.build_observations(pts0, ext0, sc.tracks, masks)
-    assert np.array_equal(valid_idx.numpy(), vi)
-    assert np.array_equal(deleted.numpy(), dele)
-    assert np.array_equal(prob.row_ptr.numpy(), row_ptr)
-    assert np.array_equal(prob.obs_cam.numpy(), obs_cam)
-    assert np.array_equal(prob.obs_uv.numpy().astype(np.float64), obs_uv)
+def _check_views_and_work_list(prob, S, vi, row_ptr, obs_cam):
+    """Invariants of a compiled problem: the camera-major view holds the point-major observations, and the Schur work
+    list (chunks -> entries -> segments) covers every co-observing camera pair of every point exactly once."""
     # camera-major view holds the same observations
     cm = set()
     cp = prob.col_ptr.numpy()
@@ -150,6 +131,59 @@ def test_compile_problem_matches_oracle_construction(S, N, density_cut, monkeypa
             for bb in cams[i:]:
                 expect.add((p, int(a), int(bb)))
     assert set(covered) == expect and all(v == 1 for v in covered.values())
+
+@pytest.mark.parametrize("density_cut", [0.0, 2.0])    # in-place filtering of the grid / the observation-list construction
+@pytest.mark.parametrize("S,N", [(5, 40), (40, 300), (70, 150)])
+def test_compile_problem_matches_oracle_construction(S, N, density_cut, monkeypatch):
+    monkeypatch.setattr(BA, "SUPER_TILES", False)        # (the 2 x 2 super-tile list has its own test below)
+    monkeypatch.setattr(BA, "SPARSE_GRID_DENSITY", density_cut)
+    sc = make_scene(S, N, "SIMPLE_RADIAL", shared_camera=True, seed=S)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=S)
+    masks = sc.mask.copy()
+    masks[:, 3] = False
+    masks[0, 3] = True                     # single observation: not a point
+    pts0[5] = [0, 0, -2.0]                 # behind everything
+    pts0[6, 0] = 4000.0                    # >= 3000
+    masks[2:, 7] = False
+    pts0[7] = -pts0[7]
+    prob, valid_idx, deleted = BA.compile_problem(T(pts0), T(ext0), T(K0), T(sc.tracks), T(masks), T(extra0), True,
+                                                  "SIMPLE_RADIAL")
+    vi, row_ptr, obs_cam, obs_uv, dele = OB.build_observations(pts0, ext0, sc.tracks, masks)
+    assert np.array_equal(valid_idx.numpy(), vi)
+    assert np.array_equal(deleted.numpy(), dele)
+    assert np.array_equal(prob.row_ptr.numpy(), row_ptr)
+    assert np.array_equal(prob.obs_cam.numpy(), obs_cam)
+    assert np.array_equal(prob.obs_uv.numpy().astype(np.float64), obs_uv)
+    _check_views_and_work_list(prob, S, vi, row_ptr, obs_cam)
+
+
+@pytest.mark.parametrize("density_cut", [0.0, 2.0])
+@pytest.mark.parametrize("S,N,density,seed", [(2, 30, 1.0, 0), (3, 50, 0.7, 1), (16, 80, 0.3, 2), (17, 120, 0.15, 3), (33, 200, 0.08, 4),
+                                              (48, 60, 0.9, 5), (40, 150, 0.05, 6)])
+def test_compile_problem_on_irregular_visibility(S, N, density, seed, density_cut, monkeypatch):
+    """The same invariants on visibility patterns make_scene does not produce: Bernoulli masks (tracks with gaps), cameras
+    that see nothing, points seen by exactly two cameras of different groups, frame counts around the 16-camera group
+    size, per-frame intrinsics."""
+    monkeypatch.setattr(BA, "SUPER_TILES", False)
+    monkeypatch.setattr(BA, "SPARSE_GRID_DENSITY", density_cut)
+    rng = np.random.default_rng(seed)
+    sc = make_scene(S, N, "SIMPLE_RADIAL", shared_camera=False, seed=seed)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=seed)
+    masks = rng.random((S, N)) < density
+    if S > 4:
+        masks[rng.integers(2, S)] = False                   # a camera that sees nothing
+        masks[:, 0] = False
+        masks[0, 0] = masks[S - 1, 0] = True                # a point seen by the first and the last camera only
+    # keep the points in front of the cameras that observe them irrelevant: the construction only looks at masks, depth
+    # and coordinates; use the scene's own (valid) geometry and let compile_problem / the oracle filter alike
+    prob, valid_idx, deleted = BA.compile_problem(T(pts0), T(ext0), T(K0), T(sc.tracks), T(masks), T(extra0), False,
+                                                  "SIMPLE_RADIAL")
+    vi, row_ptr, obs_cam, obs_uv, dele = OB.build_observations(pts0, ext0, sc.tracks, masks)
+    assert np.array_equal(valid_idx.numpy(), vi) and np.array_equal(deleted.numpy(), dele)
+    assert np.array_equal(prob.row_ptr.numpy(), row_ptr) and np.array_equal(prob.obs_cam.numpy(), obs_cam)
+    if len(vi) == 0:
+        return
+    _check_views_and_work_list(prob, S, vi, row_ptr, obs_cam)
 
 
 def test_normalize_matches_oracle():

@@ -399,6 +399,39 @@ def test_find_camera_split_on_sliding_window_visibility():
     assert BA.find_camera_split(full)[0] is None and BA.find_camera_split(m[:40])[0] is None
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_camera_split_and_order_decouple_on_random_banded_visibility(seed):
+    """Random sequences: S frames, tracks of random length up to a random band, random frame counts (not multiples of the
+    16-camera group).  Whatever the two routines return is either None or a valid structure: a permutation with the
+    gauge frames first; for the split, no point seen from both leading blocks and A a multiple of 64 columns; for the
+    k-way order, an envelope that no co-visible camera pair violates."""
+    rng = np.random.default_rng(seed)
+    S = int(rng.integers(70, 420))
+    band = int(rng.integers(8, max(9, S // 3)))
+    P = 3000
+    start = rng.integers(0, S - 3, P)
+    ln = rng.integers(3, band + 1, P)
+    fr = np.arange(S)[:, None]
+    m = torch.from_numpy((fr >= start[None]) & (fr < (start + ln)[None]))
+    perm, (ca, cb) = BA.find_camera_split(m)
+    if perm is not None:
+        assert sorted(perm.tolist()) == list(range(S)) and perm[:2].tolist() == [0, 1]
+        assert ca % 64 == 0 and ca > 0 and cb > 0 and ca % 6 == 0 and cb % 6 == 0
+        mp = m[perm]
+        na, nb_ = ca // 6, cb // 6
+        assert not bool((mp[:na].any(0) & mp[na:na + nb_].any(0)).any())
+    perm2, fg = BA.find_camera_order(m)
+    if perm2 is not None:
+        assert sorted(perm2.tolist()) == list(range(S)) and perm2[:2].tolist() == [0, 1]
+        fb = BA.envelope_blocks(fg, S, 6 * S + 2)
+        mp = m[perm2].float()
+        covis = (mp @ mp.t()) > 0
+        first_cam = torch.tensor([int(torch.nonzero(covis[c])[0]) if bool(covis[c].any()) else c for c in range(S)])
+        first_col = 6 * first_cam[torch.arange(6 * S) // 6]
+        for r in range(0, 6 * S, 64):
+            assert int(fb[r // 64]) * 64 <= int(first_col[r:r + 64].min())
+
+
 def test_find_camera_order_kway_and_envelope():
     """Video-like visibility (1000 frames, tracks of at most 40 frames): ``find_camera_order`` returns a nested-dissection
     order -- k > 2 interior runs, then their separators -- in which the interiors do not couple, frames 0 / 1 (the gauge)

@@ -983,11 +983,12 @@ def solve(problem: DeviceProblem, options: Optional[BundleAdjustmentOptions] = N
     return out, workspace
 
 
-def normalize_reconstruction(extrinsics, points3D, alive=None, extent=5.0, p0=0.1, p1=0.9):
-    """Reconstruction.normalize(5.0, 0.1, 0.9, True) (vggsfm/utils/triangulation.py:1217) on tensors."""
+def normalization_transform(extrinsics, extent=5.0, p0=0.1, p1=0.9):
+    """The similarity of Reconstruction.normalize(extent, p0, p1, True): (scale (), mean (3,), normalised extrinsics) --
+    X -> scale (X - mean); None when there are fewer than two cameras."""
     S = extrinsics.shape[0]
     if S < 2:
-        return extrinsics, points3D
+        return None
     R, t = extrinsics[:, :, :3], extrinsics[:, :, 3]
     centers = -torch.einsum("sji,sj->si", R, t)
     c32, _ = torch.sort(centers.to(torch.float32), dim=0)
@@ -999,11 +1000,18 @@ def normalize_reconstruction(extrinsics, points3D, alive=None, extent=5.0, p0=0.
     scale = torch.where(old_extent < torch.finfo(torch.float64).eps, torch.ones_like(old_extent), extent / old_extent)
     ext = extrinsics.clone()
     ext[:, :, 3] = scale * (t + torch.einsum("sij,j->si", R, mean))
-    pts = points3D.clone()
-    if alive is None:
-        pts = scale * (pts - mean)
-    else:
-        pts[alive] = scale * (pts[alive] - mean)
+    return scale, mean, ext
+
+
+def normalize_reconstruction(extrinsics, points3D, alive=None, extent=5.0, p0=0.1, p1=0.9):
+    """Reconstruction.normalize(5.0, 0.1, 0.9, True) (vggsfm/utils/triangulation.py:1217) on tensors."""
+    tr = normalization_transform(extrinsics, extent, p0, p1)
+    if tr is None:
+        return extrinsics, points3D
+    scale, mean, ext = tr
+    pts = scale * (points3D - mean)
+    if alive is not None:          # (a select, not a masked assignment: no index list, no host synchronisation on the device)
+        pts = torch.where(alive[:, None], pts, points3D)
     return ext, pts
 
 

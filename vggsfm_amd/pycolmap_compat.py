@@ -752,15 +752,16 @@ class Reconstruction:
         (sorted as float32), scale to `extent`, centre on the mean; applied to the registered poses and every point."""
         if not use_images:
             raise NotImplementedError("normalize(use_images=False) is not used by the reference")
-        from .ba import normalize_reconstruction
+        from .ba import normalization_transform
         ids = list(self._reg)
         if len(ids) < 2:
             return
         ext = torch.from_numpy(np.stack([self.images[i].cam_from_world.matrix() for i in ids]))
-        alive = torch.from_numpy(self._alive[:self._n].copy())
-        ext2, pts2 = normalize_reconstruction(ext, torch.from_numpy(self._xyz[:self._n].copy()), alive, extent, p0, p1)
+        scale, mean, ext2 = normalization_transform(ext, extent, p0, p1)
         ext2 = ext2.numpy()
-        self._xyz[:self._n] = pts2.numpy()
+        # the points on the host arrays they live in (same two roundings per coordinate as the tensor version)
+        alive = self._alive[:self._n]
+        self._xyz[:self._n][alive] = float(scale) * (self._xyz[:self._n][alive] - mean.numpy())
         for k, i in enumerate(ids):
             self.images[i].cam_from_world = Rigid3d(Rotation3d(ext2[k, :, :3]), ext2[k, :, 3])
 

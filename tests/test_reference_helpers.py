@@ -111,3 +111,39 @@ def test_average_camera_prediction_matches_reference():
     q = U.matrix_to_quaternion_scipy(torch.from_numpy(M)).numpy()
     np.testing.assert_allclose(q, Rotation.from_matrix(M).as_quat(), rtol=0, atol=1e-14)
     np.testing.assert_allclose(U.quaternion_to_matrix_scipy(torch.from_numpy(q)).numpy(), M, rtol=0, atol=1e-14)
+
+
+def test_small_driver_helpers_match_reference():
+    """find_best_initial_pair (triangulator.py:442-476), get_valid_frame_mask (triangulation.py:1222-1242),
+    create_intri_matrix and generate_combinations (triangulation_helpers.py:590-645): the host-side mirrors against the
+    reference's own functions on random inputs, bit for bit."""
+    ref_harness.install()
+    from vggsfm.models.triangulator import find_best_initial_pair as ref_pair
+    from vggsfm.utils.triangulation import get_valid_frame_mask as ref_valid
+    from vggsfm.utils.triangulation_helpers import create_intri_matrix as ref_K
+    from vggsfm.utils.triangulation_helpers import generate_combinations as ref_comb
+    from vggsfm_amd.models.triangulator import find_best_initial_pair
+    from vggsfm_amd.utils.triangulation import get_valid_frame_mask
+    from vggsfm_amd.utils.triangulation_helpers import create_intri_matrix, generate_combinations
+    g = torch.Generator().manual_seed(0)
+    for trial in range(30):
+        S, N = int(torch.randint(3, 12, (1,), generator=g)), int(torch.randint(50, 600, (1,), generator=g))
+        dens = float(torch.rand(1, generator=g))
+        geo = torch.rand(S - 1, N, generator=g) < dens
+        che = torch.rand(S - 1, N, generator=g) < 0.9
+        ang = torch.rand(S - 1, N, generator=g, dtype=torch.float64) * float(torch.randint(1, 40, (1,), generator=g))
+        for thr in (16, 8, 3, 1):
+            a, ta = find_best_initial_pair(geo, che, ang, thr)
+            b, tb = ref_pair(geo, che, ang, thr)
+            assert torch.equal(a, b) and ta == tb
+        K = torch.zeros(S, 3, 3, dtype=torch.float64)
+        K[:, 0, 0] = torch.rand(S, generator=g, dtype=torch.float64) * 40000 - 2000
+        ext = torch.randn(S, 3, 4, generator=g, dtype=torch.float64) * 20
+        extra = torch.randn(S, 1, generator=g, dtype=torch.float64)
+        for ex in (None, extra, extra[:, 0]):
+            assert torch.equal(get_valid_frame_mask(K, ext, ex, 1024.0), ref_valid(K, ext, ex, 1024.0))
+        f, pp = torch.rand(S, 2, generator=g), torch.rand(S, 2, generator=g)
+        assert torch.equal(create_intri_matrix(f, pp), ref_K(f, pp))
+        assert torch.equal(create_intri_matrix(f[None], pp[None]), ref_K(f[None], pp[None]))
+    for S in (2, 3, 7, 24, 50):
+        assert np.array_equal(generate_combinations(S), ref_comb(S))

@@ -147,3 +147,25 @@ def test_small_driver_helpers_match_reference():
         assert torch.equal(create_intri_matrix(f[None], pp[None]), ref_K(f[None], pp[None]))
     for S in (2, 3, 7, 24, 50):
         assert np.array_equal(generate_combinations(S), ref_comb(S))
+
+
+def test_order_and_se3_helpers_match_reference():
+    """calculate_index_mappings / switch_tensor_order (utils/utils.py:167-187), closed_form_inverse_OpenCV
+    (utils/metric.py:233-268) against the reference's own functions."""
+    ref_harness.install()
+    from vggsfm.utils.metric import closed_form_inverse_OpenCV as ref_inv
+    from vggsfm.utils.utils import calculate_index_mappings as ref_map
+    from vggsfm.utils.utils import switch_tensor_order as ref_switch
+    from vggsfm_amd.utils.utils import calculate_index_mappings, closed_form_inverse_OpenCV, switch_tensor_order
+    g = torch.Generator().manual_seed(1)
+    for S in (1, 2, 5, 9):
+        for q in range(S):
+            order = calculate_index_mappings(q, S)
+            assert torch.equal(order, ref_map(q, S))
+            ts = [torch.randn(2, S, 3, generator=g), None, torch.randn(2, S, generator=g)]
+            for a, b in zip(switch_tensor_order(ts, order), ref_switch(ts, order)):
+                assert (a is None and b is None) or torch.equal(a, b)
+    se3 = torch.eye(4, dtype=torch.float64)[None].repeat(6, 1, 1)
+    se3[:, :3, :3] = _rand_rot(6, g)
+    se3[:, :3, 3] = torch.randn(6, 3, generator=g, dtype=torch.float64)
+    assert torch.equal(closed_form_inverse_OpenCV(se3), ref_inv(se3))

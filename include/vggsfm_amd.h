@@ -339,7 +339,11 @@ int vgg_ba_profile_read(int kernel_id, double* total_ms, int* launches, int rese
  * A (n,n) row-major lower triangle is overwritten by its Cholesky factor, b by the solution
  * (if b == A + n*n the forward substitution is fused into the factorisation).
  * workspace: vgg_cholesky_workspace_bytes(n) device bytes (inverse diagonal blocks).
- * *device_fail (int32, device) is set non-zero on a non-positive pivot. */
+ * *device_fail (int32, device) is set non-zero on a non-positive pivot (2: a hand-off of the single-launch form timed out).
+ * n >= 128 with b behind A runs as ONE launch (a workgroup per 64 x 64 tile, hand-offs through per-tile flags); the sums of
+ * a tile are taken in a fixed order that depends on the structure passed (split / envelope) only: the factor is reproducible
+ * run to run, and equal to the plain entry's up to the rounding of those sums (VGG_CHOL_CHAIN / VGG_CHOL_LEGACY in the
+ * environment select the other forms for measurements). */
 size_t vgg_cholesky_workspace_bytes(int n);
 int vgg_cholesky_solve(double* A, double* b, int n, void* workspace, int32_t* device_fail, void* stream);
 /* the same with a block-diagonal leading part: A[i][j] = 0 for split_a <= i < split_a + split_b, j < split_a (exposed

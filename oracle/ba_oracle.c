@@ -215,7 +215,41 @@ typedef struct {
   int n_cols;             /* n_red + 3*P */
   uint8_t* active;        /* per column */
   double* scale;          /* Jacobi scaling per column */
+  /* Reproducibility: every sum over observations that feeds a decision (cost, gradient, column norms, the
+   * reduced system, the model cost change) is formed slice by slice -- K contiguous point ranges that are a
+   * function of the PROBLEM only (balanced by observation count), each summed sequentially into its own
+   * buffer -- and the K partial results are then added in slice order.  Threads only decide who computes a
+   * slice, never the order of a floating-point addition: the iteration log is bit-identical from run to run
+   * and for every OMP_NUM_THREADS (tests/test_oracle_ba.py::test_oracle_is_bit_reproducible). */
+  int num_slices;
+  int* slice_begin;       /* [num_slices + 1] point index */
+  double* slice_lhs;      /* [num_slices][n_red * n_red] */
+  double* slice_vec;      /* [num_slices][2 * n_red] */
 } ctx_t;
+
+static void make_slices(ctx_t* c) {
+  const bao_problem_t* pb = c->pb;
+  const long O = pb->row_ptr[pb->num_pts];
+  long K = O / 2048;
+  if (K > 128) K = 128;
+  /* keep the K partial systems below ~3 GB */
+  const double per = 8.0 * (double)c->n_red * (double)c->n_red;
+  while (K > 1 && per * (double)K > 3.0e9) K /= 2;
+  if (K < 1) K = 1;
+  if (K > pb->num_pts) K = pb->num_pts > 0 ? pb->num_pts : 1;
+  c->num_slices = (int)K;
+  c->slice_begin = (int*)malloc(sizeof(int) * (K + 1));
+  int p = 0;
+  for (long s = 0; s < K; ++s) {
+    const long target = O * s / K;
+    while (p < pb->num_pts && pb->row_ptr[p] < target) ++p;
+    c->slice_begin[s] = p;
+  }
+  c->slice_begin[0] = 0;
+  c->slice_begin[K] = pb->num_pts;
+  c->slice_lhs = (double*)malloc(sizeof(double) * (size_t)K * c->n_red * c->n_red);
+  c->slice_vec = (double*)malloc(sizeof(double) * (size_t)K * 2 * c->n_red);
+}
 
 static int intr_col(const ctx_t* c, int a) { return 6 * c->pb->num_cams + c->kd * a; }
 static int pt_col(const ctx_t* c, int p) { return c->n_red + 3 * p; }
@@ -251,16 +285,23 @@ static double eval_corrected(const ctx_t* c, const double* cq, const double* ct,
 
 static double total_cost(const ctx_t* c, const double* cq, const double* ct, const double* intr, const double* pts) {
   const bao_problem_t* pb = c->pb;
-  double cost = 0;
-#pragma omp parallel for reduction(+ : cost) schedule(static)
-  for (int p = 0; p < pb->num_pts; ++p) {
-    double cp = 0;
-    for (int o = pb->row_ptr[p]; o < pb->row_ptr[p + 1]; ++o) {
-      double r[2];
-      cp += eval_corrected(c, cq, ct, intr, pts, p, o, r, NULL, NULL, NULL);
+  const int K = c->num_slices;
+  double part[128];
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int s = 0; s < K; ++s) {
+    double cs = 0;
+    for (int p = c->slice_begin[s]; p < c->slice_begin[s + 1]; ++p) {
+      double cp = 0;
+      for (int o = pb->row_ptr[p]; o < pb->row_ptr[p + 1]; ++o) {
+        double r[2];
+        cp += eval_corrected(c, cq, ct, intr, pts, p, o, r, NULL, NULL, NULL);
+      }
+      cs += cp;
     }
-    cost += cp;
+    part[s] = cs;
   }
+  double cost = 0;
+  for (int s = 0; s < K; ++s) cost += part[s];
   return 0.5 * cost;
 }
 
@@ -280,12 +321,13 @@ static void grad_and_colnorm(const ctx_t* c, const double* cq, const double* ct,
   const int nr = c->n_red;
   memset(grad, 0, sizeof(double) * c->n_cols);
   memset(colsq, 0, sizeof(double) * c->n_cols);
-#pragma omp parallel
-  {
-    double* lg = (double*)calloc(2 * (size_t)nr, sizeof(double));   /* camera-side partials of this thread */
+  const int K = c->num_slices;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int s = 0; s < K; ++s) {
+    double* lg = c->slice_vec + (size_t)s * 2 * nr;                 /* camera-side partials of this slice */
     double* lc = lg + nr;
-#pragma omp for schedule(static)
-    for (int p = 0; p < pb->num_pts; ++p)
+    memset(lg, 0, sizeof(double) * 2 * nr);
+    for (int p = c->slice_begin[s]; p < c->slice_begin[s + 1]; ++p)
       for (int o = pb->row_ptr[p]; o < pb->row_ptr[p + 1]; ++o) {
         const int cam = pb->obs_cam[o];
         double r[2], Jp[12], Ji[4], Jx[6];
@@ -297,9 +339,11 @@ static void grad_and_colnorm(const ctx_t* c, const double* cq, const double* ct,
         const int pc = pt_col(c, p);
         for (int k = 0; k < 3; ++k) { grad[pc + k] += Jx[k] * r[0] + Jx[3 + k] * r[1]; colsq[pc + k] += Jx[k] * Jx[k] + Jx[3 + k] * Jx[3 + k]; }
       }
-#pragma omp critical
+  }
+  for (int s = 0; s < K; ++s) {                                     /* slice order: fixed */
+    const double* lg = c->slice_vec + (size_t)s * 2 * nr;
+    const double* lc = lg + nr;
     for (int i = 0; i < nr; ++i) { grad[i] += lg[i]; colsq[i] += lc[i]; }
-    free(lg);
   }
 }
 
@@ -347,33 +391,20 @@ static int schur_solve(const ctx_t* c, const double* cq, const double* ct, const
                        const double* D, double* y, double* lhs, double* rhs, double* model_cost_change) {
   const bao_problem_t* pb = c->pb;
   const int n = c->n_red, P = pb->num_pts, kd = c->kd, bw = 6 + kd;
-  memset(lhs, 0, sizeof(double) * (size_t)n * n);
-  memset(rhs, 0, sizeof(double) * n);
   double* einv = (double*)malloc(sizeof(double) * 9 * (size_t)P);
   double* ge = (double*)malloc(sizeof(double) * 3 * (size_t)P);
   int fail = 0;
-#ifdef _OPENMP
-  const int nthreads = omp_get_max_threads();
-#else
-  const int nthreads = 1;
-#endif
-  double** tl = (double**)calloc(nthreads, sizeof(double*));
-  double** tr = (double**)calloc(nthreads, sizeof(double*));
-#pragma omp parallel
-  {
-#ifdef _OPENMP
-    const int tid = omp_get_thread_num();
-#else
-    const int tid = 0;
-#endif
-    double* L = tid == 0 ? lhs : (double*)calloc((size_t)n * n, sizeof(double));
-    double* Rh = tid == 0 ? rhs : (double*)calloc(n, sizeof(double));
-    tl[tid] = L; tr[tid] = Rh;
+  const int K = c->num_slices;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int s = 0; s < K; ++s) {
+    double* L = c->slice_lhs + (size_t)s * n * n;
+    double* Rh = c->slice_vec + (size_t)s * 2 * n;
+    memset(L, 0, sizeof(double) * (size_t)n * n);
+    memset(Rh, 0, sizeof(double) * n);
     int cap = 64;
     double* FtE = (double*)malloc(sizeof(double) * cap * bw * 3);
     int* cols = (int*)malloc(sizeof(int) * cap * bw);
-#pragma omp for schedule(dynamic, 64)
-    for (int p = 0; p < P; ++p) {
+    for (int p = c->slice_begin[s]; p < c->slice_begin[s + 1]; ++p) {
       const int o0 = pb->row_ptr[p], no = pb->row_ptr[p + 1] - o0;
       if (no > cap) { cap = no; FtE = (double*)realloc(FtE, sizeof(double) * cap * bw * 3); cols = (int*)realloc(cols, sizeof(int) * cap * bw); }
       const int pc = pt_col(c, p);
@@ -429,13 +460,18 @@ static int schur_solve(const ctx_t* c, const double* cq, const double* ct, const
     }
     free(FtE); free(cols);
   }
-  for (int t = 1; t < nthreads; ++t) if (tl[t]) {
+  /* the K partial systems, added in slice order (element-wise parallel: the order per element is fixed) */
 #pragma omp parallel for schedule(static)
-    for (long i = 0; i < (long)n * n; ++i) lhs[i] += tl[t][i];
-    for (int i = 0; i < n; ++i) rhs[i] += tr[t][i];
-    free(tl[t]); free(tr[t]);
+  for (long i = 0; i < (long)n * n; ++i) {
+    double a = 0;
+    for (int s = 0; s < K; ++s) a += c->slice_lhs[(size_t)s * n * n + i];
+    lhs[i] = a;
   }
-  free(tl); free(tr);
+  for (int i = 0; i < n; ++i) {
+    double a = 0;
+    for (int s = 0; s < K; ++s) a += c->slice_vec[(size_t)s * 2 * n + i];
+    rhs[i] = a;
+  }
   if (!fail) {
     for (int i = 0; i < n; ++i) {
       if (c->active[i]) lhs[(size_t)i * n + i] += D[i] * D[i];
@@ -447,9 +483,11 @@ static int schur_solve(const ctx_t* c, const double* cq, const double* ct, const
   }
   if (!fail) {
     /* back-substitution y_e = (E^T E + D_e^2)^-1 (E^T b - E^T F y_f) and model cost change */
+    double mpart[128];
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int s = 0; s < K; ++s) {
     double mcc = 0;
-#pragma omp parallel for reduction(+ : mcc) schedule(dynamic, 64)
-    for (int p = 0; p < P; ++p) {
+    for (int p = c->slice_begin[s]; p < c->slice_begin[s + 1]; ++p) {
       const int pc = pt_col(c, p);
       const int eliminate = c->active[pc] || c->active[pc + 1] || c->active[pc + 2];
       double acc[3] = {0, 0, 0};
@@ -485,6 +523,10 @@ static int schur_solve(const ctx_t* c, const double* cq, const double* ct, const
         mcc += -(m0 * (r[0] + m0 / 2.0) + m1 * (r[1] + m1 / 2.0));
       }
     }
+    mpart[s] = mcc;
+    }
+    double mcc = 0;
+    for (int s = 0; s < K; ++s) mcc += mpart[s];
     *model_cost_change = mcc;
     for (int i = 0; i < c->n_cols; ++i) if (!isfinite(y[i])) { fail = 1; break; }
   }
@@ -505,6 +547,7 @@ int bao_solve(const bao_problem_t* pb, const bao_options_t* opt, double* cam_q, 
   c.n_red = 6 * pb->num_cams + c.kd * pb->num_intr;
   c.n_cols = c.n_red + 3 * pb->num_pts;
   const int C = pb->num_cams, P = pb->num_pts, NI = pb->num_intr, n = c.n_cols;
+  make_slices(&c);
   c.active = (uint8_t*)malloc(n);
   c.scale = (double*)malloc(sizeof(double) * n);
   /* Ceres removes parameter blocks (and subset-manifold coordinates) that are constant, and
@@ -649,6 +692,7 @@ int bao_solve(const bao_problem_t* pb, const bao_options_t* opt, double* cam_q, 
   sum->final_cost = x_cost;
   sum->num_iterations = it;
   sum->n_reduced = c.n_red;
+  free(c.slice_begin); free(c.slice_lhs); free(c.slice_vec);
   free(c.active); free(c.scale); free(grad); free(colsq); free(diag); free(D); free(y); free(delta);
   free(lhs); free(rhs); free(nq); free(nt); free(ni); free(np_);
   return 0;

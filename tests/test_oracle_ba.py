@@ -227,3 +227,46 @@ def test_pycolmap_shim_round_trip_equals_dense_oracle():
     for k, pid in enumerate(range(1, len(valid) + 1)):
         if not summ["deleted"][k]:
             assert np.abs(rec.points3D[pid].xyz - p_ref[k]).max() < 1e-6
+
+
+_REPRO_SNIPPET = r"""
+import hashlib, json, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from oracle import ba as OB
+from vggsfm_amd.scene import make_scene, perturb_for_ba
+sc = make_scene(24, 3000, "SIMPLE_RADIAL", shared_camera=True, seed=5)
+ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=5)
+pts, ext, K, extra, summ = OB.bundle_adjustment(pts0, ext0, K0, sc.tracks, sc.mask, extra0, True, "SIMPLE_RADIAL",
+                                                OB.prepare_ba_options())
+h = hashlib.sha256()
+for it in summ["iterations"]:
+    h.update(np.array([it[k] for k in ("cost", "cost_change", "gradient_max_norm", "step_norm",
+                                      "relative_decrease", "radius")], np.float64).tobytes())
+for a in (pts, ext, K, extra):
+    h.update(np.ascontiguousarray(a).tobytes())
+print(json.dumps(dict(digest=h.hexdigest(), its=summ["num_iterations"], threads=OB.lib().bao_num_threads())))
+"""
+
+
+def test_oracle_is_bit_reproducible():
+    """the checker's own trajectory must not depend on the thread count or on scheduling.
+    The same solve in fresh processes with 1, 3 and all threads (twice): iteration log and result bit for bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    OB.build()
+    outs = []
+    for threads in ("1", "3", None, None):
+        env = dict(os.environ)
+        env.pop("OMP_NUM_THREADS", None)
+        if threads:
+            env["OMP_NUM_THREADS"] = threads
+        r = subprocess.run([sys.executable, "-c", _REPRO_SNIPPET.format(root=root)], env=env, capture_output=True,
+                           text=True, check=True)
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0]["threads"] == 1 and outs[1]["threads"] == 3
+    assert len({o["digest"] for o in outs}) == 1, outs
+    assert outs[0]["its"] > 3

@@ -340,6 +340,33 @@ def main():
             cpu = dict(value=s_cpu["num_iterations"] / tcpu, unit="LM-iterations/s", cores=int(OB.lib().bao_num_threads()),
                        kind="port", sample=f"full {S}x{N} workload, {s_cpu['num_iterations']} LM iterations "
                        f"(oracle/ba_oracle.c, OpenMP, includes the initial evaluation), {tcpu:.1f} s")
+        parity_c3 = None
+        if cpu is not None:
+            # the SAME headline problem and the same iterations the port was just timed on, now on the GPU through the
+            # public entry: the LM trajectories side by side
+            o5 = BundleAdjustmentOptions()
+            o5.solver_options.max_num_iterations = args.cpu_iters
+            o5.solver_options.function_tolerance = o5.solver_options.gradient_tolerance = -1.0
+            o5.solver_options.parameter_tolerance = -1.0
+            gp, ge, gK, gx, gs = BA.bundle_adjustment(D(pts0, dev), D(ext0_c, dev), D(K0_c, dev), D(sc.tracks, dev), D(sc.mask, dev),
+                                                      None, D(extra0_c, dev), shared, cam_type, o5)
+            oe = np.concatenate([OB.quat_to_rotmat(cq), ct[:, :, None]], -1)
+            ge, gp = ge.cpu().numpy(), gp.cpu().numpy()
+            relv = lambda a, b: float(np.max(np.linalg.norm((a - b).reshape(len(a), -1), axis=1)
+                                             / np.maximum(np.linalg.norm(b.reshape(len(b), -1), axis=1), 1e-12)))
+            its = list(zip(gs["iterations"], s_cpu["iterations"]))
+            parity_c3 = dict(workload=f"the timed workload itself ({S} x {N} {cam_type}{' shared' if shared else ''}), "
+                                      f"{args.cpu_iters} LM iterations from the same start, termination tests off",
+                             lm_iterations_gpu=int(gs["num_iterations"]), lm_iterations_port=int(s_cpu["num_iterations"]),
+                             accept_pattern_equal=bool(all(a["successful"] == b["successful"] for a, b in its)),
+                             max_rel_cost_delta_per_iteration=float(max(abs(a["cost"] - b["cost"]) / b["cost"] for a, b in its)),
+                             max_rel_radius_delta_per_iteration=float(max(abs(a["radius"] - b["radius"]) / b["radius"] for a, b in its)),
+                             max_rel_rotation_delta=relv(ge[:, :, :3], oe[:, :, :3]),
+                             max_rel_translation_delta=relv(ge[1:, :, 3], oe[1:, :, 3]),
+                             max_rel_point_delta=relv(gp, pts_c),
+                             max_rel_focal_delta=float(abs(gK[0, 0, 0].item() / intr[0, 0] - 1)) if shared else
+                             float(np.max(np.abs(gK[:, 0, 0].cpu().numpy() / intr[:, 0] - 1))),
+                             tolerance=1e-4, reference="oracle/ba_oracle.c (Ceres/COLMAP restatement; unpinned vs pycolmap)")
         parity = None
         if cpu is not None:
             # "pose delta vs ref" half of BASELINE.json's metric: the same full solve (reference BA options: 50 iterations,
@@ -391,6 +418,7 @@ def main():
             "iteration_roofline": iteration,
             "cpu_baseline": cpu,
             "pose_delta_vs_port": parity,
+            "pose_delta_vs_port_c3": parity_c3,
             "strong_scaling_c4": strong,
         }
         print(json.dumps(out))

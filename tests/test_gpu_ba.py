@@ -297,21 +297,26 @@ CASES = [
     # (the CPU port needs ~1 s per iteration here)
     (50, 20000, "SIMPLE_PINHOLE", False, "prep12"),
     (200, 10000, "SIMPLE_RADIAL", True, "prep12"),
+    # the HEADLINE configuration, BASELINE configs[2] at full size (200 frames x 100k tracks, shared
+    # SIMPLE_RADIAL, 5 M observations, n = 1202), 5 LM iterations (~2 s each for the CPU port), and the block shape of
+    # configs[3] -- per-frame SIMPLE_RADIAL, 8 x 8 camera blocks, the 128 x 128 tile variant, n = 3200 -- at 400 frames
+    (200, 100000, "SIMPLE_RADIAL", True, "prep5"),
+    (400, 5000, "SIMPLE_RADIAL", False, "prep8"),
 ]
 
 
 def _oracle_opts(kind):
-    if kind == "prep12":
+    if kind in ("prep12", "prep8", "prep5"):
         o = OB.prepare_ba_options()
-        o.max_num_iterations = 12
+        o.max_num_iterations = int(kind[4:])
         return o
     return OB.prepare_ba_options() if kind == "prep" else OB.ceres_options()
 
 
 def _gpu_opts(kind):
-    if kind == "prep12":
+    if kind in ("prep12", "prep8", "prep5"):
         o = prepare_ba_options()
-        o.solver_options.max_num_iterations = 12
+        o.solver_options.max_num_iterations = int(kind[4:])
         return o
     return prepare_ba_options() if kind == "prep" else BundleAdjustmentOptions()
 

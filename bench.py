@@ -236,11 +236,7 @@ def main():
         pairs_all = float((counts * (counts + 1) / 2).sum().item())
         pairs_diag = float((seg_count * (seg_count + 1) / 2).sum().item())       # both cameras in one 16-camera group
         pairs_off = pairs_all - pairs_diag
-        super_tiles = prob.quad_mask is not None
-        if super_tiles:               # opt-in 2 x 2 super-tiles: ONE launch computes every pair (reported under schur_tile<offdiag>)
-            pairs_off, pairs_diag = pairs_all, 0.0
-            ROCPROF_NAME["schur_tile<offdiag>"] = "super_tile_kernel"
-        elif prob.merged_tile_launch:  # small problems: off-diagonal and diagonal tiles in one launch
+        if prob.merged_tile_launch:  # small problems: off-diagonal and diagonal tiles in one launch
             pairs_off, pairs_diag = pairs_all, 0.0
             ROCPROF_NAME["schur_tile<offdiag>"] = "schur_tile_merged_kernel"
         # algorithmic work per launch (DESIGN.md "Kernels"): flops for the fp64-compute-bound kernels,

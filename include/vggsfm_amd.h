@@ -28,7 +28,12 @@ extern "C" {
 
 /* library / build identification ("gfx950"), for loud failure when the wrong object is loaded */
 const char* vgg_build_arch(void);
-int vgg_abi_version(void);
+int vgg_abi_version(void);          /* VGG_ABI_VERSION of the build: bumped whenever a struct below changes layout */
+#define VGG_ABI_VERSION 2
+/* sizeof of the by-pointer structs as the library was compiled (which: 0 vgg_ba_problem, 1 vgg_ba_options,
+ * 2 vgg_ba_iteration, 3 vgg_ba_summary; 0 for anything else): a binding checks its own layout against these and
+ * refuses to drive a library built from another revision of this header (vggsfm_amd/_lib.py does). */
+size_t vgg_abi_sizeof(int which);
 
 /* ------------------------------------------------------------------------------------------
  * project_3D_points + img_from_cam       vggsfm/utils/triangulation_helpers.py:311-395
@@ -141,10 +146,6 @@ typedef struct {
   int32_t num_segments;       /* segments: runs of one point's observations inside one camera group */
   const int32_t* obs_slot;    /* [num_obs] = segment*16 + (camera % 16): where the point-major observation's
                                  Schur factor lives in the zero-padded segment buffer */
-  const int32_t* obs_pt;      /* [num_obs] optional: the point of every point-major observation (the inverse of row_ptr).  With it
-                                 the per-observation Schur factors Y are written by a thread-per-observation kernel after the
-                                 wave-per-point reductions (fewer registers, full lanes for short tracks); NULL = the fused
-                                 wave-per-point pass of round 1. */
   int32_t num_tiles;
   const int32_t* tile_desc;   /* [num_tiles,4] = groupI, groupJ, chunk_begin, chunk_end (chunks of one tile
                                  are consecutive; their partial sums are reduced in this order) */
@@ -169,28 +170,6 @@ typedef struct {
                                  find_camera_order -- nested-dissection order of sliding-window / video visibility).  NULL =
                                  dense (then chol_split_a / b, if set, describe a two-block leading part).  The caller
                                  guarantees the structure, with several ranks for the SUM of their systems. */
-  const int32_t* block_chunk;    /* device, optional [num_chunks]: launch position -> chunk.  Workgroup b of a tile launch runs
-                                 on XCD b % 8 (private L2 each); the host side cuts the point range into 8 parts, chunks every
-                                 tile per part and places the chunks of part x at the positions = x (mod 8) of their launch
-                                 range, so that all tiles stage a given point's segments on ONE XCD (ba.py:
-                                 build_schur_tiles).  A permutation inside every [chunk_begin, first_diagonal_chunk) and
-                                 [first_diagonal_chunk, chunk_end) range of tile_batches.  NULL = identity. */
-  int32_t super_tiles;           /* 0: 16-camera tiles as described above.  1 (only for 6 x 6 camera blocks: num_intr == 1, or
-                                 refine_focal == refine_extra == 0): 2 x 2 SUPER-TILES of 32 x 32 cameras, one launch
-                                 (ba.py: build_schur_supertiles) -- then
-                                   chunk_desc  [num_chunks,8] = superI, superJ, entry_begin, entry_end, j, J, quad_begin, 0
-                                   entries     [num_entries,4] = segment_A0, segment_A1, segment_B0, segment_B1 (the two camera
-                                               groups of either side; num_segments = absent; a diagonal super-tile has B = A)
-                                   quad_mask   [num_quads,2] = presence of the 32 cameras of superI / superJ in the quad
-                                               (entries and quad_mask: padded by 32 entries / 8 quads behind the last tile)
-                                   tile_desc   [num_tiles,4] = superI, superJ, chunk_begin, chunk_end
-                                   tile_batches one row (0, 0, num_chunks, 0, num_tiles, 0); block_chunk unused */
-  const int32_t* quad_mask;
-  const int32_t* tile_sched;     /* device, optional: explicit BATCH SCHEDULE of the 16-camera tile chunks.  When set, fields 4 and 5
-                                 of a chunk_desc row are (offset into tile_sched, number of batches) instead of (j, J), and batch b
-                                 of the chunk multiplies the quad tile_sched[offset + b] of its tile (quad q = entries
-                                 tile_entry_begin + 4 q .. + 3).  Every quad of a tile must appear in exactly one of its chunks.
-                                 The host side uses it to walk the points range by range on every XCD (ba.py: xcd_range_schedule) */
   int32_t merged_tile_launch;    /* 1: the off-diagonal and the diagonal chunks of a batch run in ONE launch (the host sized them for
                                  one shared resident round) -- small problems, where the second launch costs more than the
                                  lower occupancy of the merged kernel */

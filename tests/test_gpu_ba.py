@@ -198,28 +198,6 @@ def test_ba_camera_split_matches_unsplit(monkeypatch, shared, N, density_cut):
     np.testing.assert_array_equal(a[1][0].cpu().numpy(), ext0[0])             # the gauge frame is still frame 0
 
 
-@pytest.mark.parametrize("S,N,cam", [(160, 8000, "SIMPLE_RADIAL"), (40, 1500, "SIMPLE_PINHOLE"), (9, 300, "SIMPLE_RADIAL")])
-def test_ba_super_tiles_match_tiles(monkeypatch, S, N, cam):
-    """The opt-in 2 x 2 super-tile Schur path (ba.SUPER_TILES: 32 x 32 cameras per workgroup, LDS-DMA ring, presence
-    skipping) against the default 16-camera tiles on shared-intrinsics problems: same trajectory to rounding."""
-    sc = make_scene(S, N, cam, shared_camera=True, seed=17)
-    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=17)
-    opt = BundleAdjustmentOptions()
-    opt.solver_options.max_num_iterations = 10
-
-    def solve():
-        return BA.bundle_adjustment(D(pts0), D(ext0), D(K0), D(sc.tracks), D(sc.mask), None, D(extra0), True, cam, opt)
-    monkeypatch.setattr(BA, "SUPER_TILES", False)
-    ref = solve()
-    monkeypatch.setattr(BA, "SUPER_TILES", True)
-    a = solve()
-    assert a[4]["num_iterations"] == ref[4]["num_iterations"]
-    assert abs(a[4]["final_cost"] - ref[4]["final_cost"]) <= 1e-9 * ref[4]["final_cost"]
-    for x, y in zip(a[:4], ref[:4]):
-        if x is not None:
-            np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-7, atol=1e-7)
-
-
 @pytest.mark.parametrize("S,N,cam,shared", [(60, 3000, "SIMPLE_RADIAL", True), (24, 1500, "SIMPLE_PINHOLE", False), (90, 2500, "SIMPLE_RADIAL", False)])
 def test_ba_launch_variants_agree(S, N, cam, shared):
     """Every launch variant of the observation passes (vgg_ba_tuning: 8 / 16 / 32 / 64 lanes per point, the long-track
@@ -248,29 +226,6 @@ def test_ba_launch_variants_agree(S, N, cam, shared):
         assert L.vgg_ba_tuning(5, 0, 0, 0) != 0                          # not a lane count
     finally:
         L.vgg_ba_tuning(0, -1, 0, 0)
-
-
-@pytest.mark.parametrize("shared,cam", [(True, "SIMPLE_RADIAL"), (False, "SIMPLE_PINHOLE")])
-def test_ba_xcd_schedule_matches_default(monkeypatch, shared, cam):
-    """The opt-in explicit batch schedule of the tile chunks (ba.XCD_SCHEDULE: every XCD walks its part of the points range
-    by range) against the default strided sub-chunks: same trajectory to rounding (only the order of the sums changes)."""
-    sc = make_scene(160, 8000, cam, shared_camera=shared, seed=29)
-    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=29)
-    opt = BundleAdjustmentOptions()
-    opt.solver_options.max_num_iterations = 10
-
-    def solve():
-        return BA.bundle_adjustment(D(pts0), D(ext0), D(K0), D(sc.tracks), D(sc.mask), None, D(extra0), shared, cam, opt)
-    ref = solve()
-    monkeypatch.setattr(BA, "XCD_SCHEDULE", True)
-    monkeypatch.setattr(BA, "OVERLAP_MIN_OBS", 1000)
-    monkeypatch.setattr(BA, "SUPER_TILES", False)
-    a = solve()
-    assert a[4]["num_iterations"] == ref[4]["num_iterations"]
-    assert abs(a[4]["final_cost"] - ref[4]["final_cost"]) <= 1e-9 * ref[4]["final_cost"]
-    for x, y in zip(a[:4], ref[:4]):
-        if x is not None:
-            np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-7, atol=1e-7)
 
 
 def test_cholesky_flags_indefinite():

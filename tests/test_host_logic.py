@@ -30,6 +30,19 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(L, sym), sym
     L.vgg_build_arch.restype = ctypes.c_char_p
     assert L.vgg_build_arch() == b"gfx950"
+    # the binding refuses a library with another struct layout: version and sizes are compared at load
+    assert int(re.search(r"#define VGG_ABI_VERSION (\d+)", header).group(1)) == _lib.ABI_VERSION == L.vgg_abi_version()
+    L.vgg_abi_sizeof.restype = ctypes.c_size_t
+    assert [int(L.vgg_abi_sizeof(i)) for i in range(5)] == [ctypes.sizeof(t) for t in (_lib.BAProblem, _lib.BAOptions,
+                                                                                       _lib.BAIteration, _lib.BASummary)] + [0]
+    assert _lib.lib() is not None
+
+
+def test_binding_rejects_a_library_with_another_abi(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
+    with pytest.raises(RuntimeError, match="ABI version"):
+        _lib.lib()
 
 
 def test_product_path_has_no_cpu_fallback():
@@ -135,7 +148,6 @@ def _check_views_and_work_list(prob, S, vi, row_ptr, obs_cam):
 @pytest.mark.parametrize("density_cut", [0.0, 2.0])    # in-place filtering of the grid / the observation-list construction
 @pytest.mark.parametrize("S,N", [(5, 40), (40, 300), (70, 150)])
 def test_compile_problem_matches_oracle_construction(S, N, density_cut, monkeypatch):
-    monkeypatch.setattr(BA, "SUPER_TILES", False)        # (the 2 x 2 super-tile list has its own test below)
     monkeypatch.setattr(BA, "SPARSE_GRID_DENSITY", density_cut)
     sc = make_scene(S, N, "SIMPLE_RADIAL", shared_camera=True, seed=S)
     ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=S)
@@ -164,7 +176,6 @@ def test_compile_problem_on_irregular_visibility(S, N, density, seed, density_cu
     """The same invariants on visibility patterns make_scene does not produce: Bernoulli masks (tracks with gaps), cameras
     that see nothing, points seen by exactly two cameras of different groups, frame counts around the 16-camera group
     size, per-frame intrinsics."""
-    monkeypatch.setattr(BA, "SUPER_TILES", False)
     monkeypatch.setattr(BA, "SPARSE_GRID_DENSITY", density_cut)
     rng = np.random.default_rng(seed)
     sc = make_scene(S, N, "SIMPLE_RADIAL", shared_camera=False, seed=seed)
@@ -196,125 +207,9 @@ def test_normalize_matches_oracle():
     np.testing.assert_allclose(p1.numpy(), p2, rtol=1e-13, atol=1e-13)
 
 
-@pytest.mark.parametrize("S,N,max_wgs", [(5, 40, 256), (40, 300, 256), (70, 900, 16), (130, 600, 40)])
-def test_supertile_list_covers_every_camera_pair_once(S, N, max_wgs, monkeypatch):
-    """build_schur_supertiles: every co-observing camera pair (a <= b) of every point is produced by exactly one
-    (super-tile, entry, half pair); quads carry the union of the presence of their four entries; the strided sub-chunks
-    of the workgroups partition every tile's entry list; the workgroup count respects the cap (or is one per tile)."""
-    sc = make_scene(S, N, "SIMPLE_RADIAL", shared_camera=True, seed=S)
-    m = torch.from_numpy(sc.mask)
-    m[:, 3] = False
-    m[:2, 3] = True
-    pm = torch.nonzero(m.t())
-    obs_cam = pm[:, 1].to(torch.int32)
-    row_ptr = torch.zeros(N + 1, dtype=torch.int32)
-    row_ptr[1:] = torch.cumsum(m.sum(0), 0).to(torch.int32)
-    cd, ent, qm, td, slot, nseg = (t.numpy() if torch.is_tensor(t) else t for t in BA.build_schur_supertiles(row_ptr, obs_cam, max_wgs=max_wgs))
-    oc, rp = obs_cam.numpy(), row_ptr.numpy()
-    G = BA.GROUP
-    nent = int(cd[:, 3].max())
-    assert len(ent) == nent + BA.SUB and (ent[nent:] == nseg).all() and len(qm) >= (nent + 3) // 4 + BA.SUB // 4      # padding
-    ent = ent[:nent]
-    assert len(np.unique(slot)) == len(slot) and slot.max() < nseg * G and (slot % G == oc % G).all()
-    seg_of = slot // G
-    pt_of_obs = np.repeat(np.arange(N), np.diff(rp))
-    seg_cams = {int(sg): oc[seg_of == sg] for sg in np.unique(seg_of)}
-    seg_pt = {int(sg): int(pt_of_obs[np.nonzero(seg_of == sg)[0][0]]) for sg in np.unique(seg_of)}
-    seg_cams[nseg] = np.zeros(0, np.int32)                    # the all-zero segment
-    mask32 = lambda s0, s1: (sum(1 << (int(c) % G) for c in seg_cams[s0]) | (sum(1 << (int(c) % G) for c in seg_cams[s1]) << 16))
-    covered, seen = {}, np.zeros(len(ent), int)
-    assert len(cd) <= max(max_wgs, len(td))
-    assert td[0, 2] == 0 and td[-1, 3] == len(cd) and (td[1:, 2] == td[:-1, 3]).all()
-    assert len({(int(a), int(b)) for a, b, _, _ in td}) == len(td)
-    for sI, sJ, c0, c1 in td:
-        assert (cd[c0:c1, 0] == sI).all() and (cd[c0:c1, 1] == sJ).all() and (cd[c0:c1, 5] == c1 - c0).all()
-        assert sorted(cd[c0:c1, 4].tolist()) == list(range(c1 - c0))
-    for sI, sJ, tb, te, j, J, q0, _ in cd:
-        assert sI <= sJ
-        for s0 in range(tb + j * BA.SUB, te, J * BA.SUB):
-            for k in range(s0, min(s0 + BA.SUB, te)):
-                seen[k] += 1
-                a0, a1, b0, b1 = (int(v) for v in ent[k])
-                if sI == sJ:
-                    assert (a0, a1) == (b0, b1)
-                assert a0 < nseg or a1 < nseg
-                p = seg_pt[a0 if a0 < nseg else a1]
-                for sg, grp in ((a0, 2 * sI), (a1, 2 * sI + 1), (b0, 2 * sJ), (b1, 2 * sJ + 1)):
-                    assert sg == nseg or (seg_pt[sg] == p and (seg_cams[sg] // G == grp).all())
-                q = q0 + (k - tb) // 4
-                qa = qb = 0
-                for kk in range(tb + (k - tb) // 4 * 4, min(tb + (k - tb) // 4 * 4 + 4, te)):
-                    qa |= mask32(ent[kk, 0], ent[kk, 1])
-                    qb |= mask32(ent[kk, 2], ent[kk, 3])
-                assert (int(qm[q, 0]) & 0xffffffff) == qa and (int(qm[q, 1]) & 0xffffffff) == qb
-                A = np.concatenate([seg_cams[a0], seg_cams[a1]])
-                B = np.concatenate([seg_cams[b0], seg_cams[b1]])
-                for a in A:
-                    for bb in B:
-                        if sI == sJ and a > bb:
-                            continue
-                        covered[(p, int(a), int(bb))] = covered.get((p, int(a), int(bb)), 0) + 1
-    assert (seen == 1).all()
-    expect = set()
-    for p in range(N):
-        cams = oc[rp[p]:rp[p + 1]]
-        for i, a in enumerate(cams):
-            for bb in cams[i:]:
-                expect.add((p, int(a), int(bb)))
-    assert set(covered) == expect and all(v == 1 for v in covered.values())
-    # compile_problem hands the super-tile list to shared-intrinsics problems when the path is switched on
-    monkeypatch.setattr(BA, "SUPER_TILES", True)
-    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=S)
-    prob, _, _ = BA.compile_problem(T(pts0), T(ext0), T(K0), T(sc.tracks), T(sc.mask), T(extra0), True, "SIMPLE_RADIAL")
-    assert prob.quad_mask is not None and prob.chunk_desc.shape[1] == 8 and prob.c_struct().super_tiles == 1
-    prob, _, _ = BA.compile_problem(T(pts0), T(ext0), T(K0), T(sc.tracks), T(sc.mask), T(extra0), False, "SIMPLE_RADIAL")
-    assert prob.quad_mask is None and prob.chunk_desc.shape[1] == 6 and prob.c_struct().super_tiles == 0
-
-
-def test_xcd_range_schedule_covers_every_quad_once():
-    """ba.xcd_range_schedule (opt-in batch schedule of the tile chunks): every quad of every tile appears in exactly one
-    chunk of that tile, chunks of a tile are consecutive, the launch map is a permutation inside each launch, the chunks at
-    the positions = x (mod 8) of a launch work on part x of the sweep, and inside a chunk the positions ascend."""
-    sc = make_scene(120, 6000, "SIMPLE_RADIAL", shared_camera=True, seed=3)
-    m = torch.from_numpy(sc.mask)
-    pm = torch.nonzero(m.t())
-    obs_cam = pm[:, 1].to(torch.int32)
-    row_ptr = torch.zeros(m.shape[1] + 1, dtype=torch.int32)
-    row_ptr[1:] = torch.cumsum(m.sum(0), 0).to(torch.int32)
-    cd, ent, td, slot, nseg, bd, bc = BA.build_schur_tiles(row_ptr, obs_cam, max_chunks=(96, 128))
-    res = BA.xcd_range_schedule(ent, cd, td, bd, (96, 128), range_points=64)
-    assert res is not None
-    ncd, ntd, nbd, nbc, sched = (t.numpy() for t in res)
-    e = ent.numpy()
-    c0, cm, c1 = (int(v) for v in nbd[0, :3])
-    assert c0 == 0 and c1 == len(ncd) and cm == 96 and c1 - cm == 128
-    assert sorted(nbc[:cm].tolist()) == list(range(cm)) and sorted(nbc[cm:].tolist()) == list(range(cm, c1))
-    for gI, gJ, a, b in ntd:
-        tb, te = ncd[a, 2], ncd[a, 3]
-        seen = np.zeros((te - tb + 3) // 4, int)
-        for c in range(a, b):
-            assert ncd[c, 0] == gI and ncd[c, 1] == gJ and ncd[c, 2] == tb and ncd[c, 3] == te
-            q = sched[ncd[c, 4]:ncd[c, 4] + ncd[c, 5]]
-            seen[q] += 1
-            assert (np.diff(e[tb + 4 * q, 0]) > 0).all()                 # ascending sweep positions inside a chunk
-        assert (seen == 1).all()
-    assert ntd[0, 2] == 0 and ntd[-1, 3] == len(ncd) and (ntd[1:, 2] == ntd[:-1, 3]).all()
-    # position p of the off-diagonal launch: part p % 8 -- the position ranges of different residues do not interleave
-    span = {}
-    for p in range(cm):
-        c = nbc[p]
-        q = sched[ncd[c, 4]:ncd[c, 4] + ncd[c, 5]]
-        pos = e[ncd[c, 2] + 4 * q, 0]
-        lo, hi = span.get(p % 8, (pos.min(), pos.max()))
-        span[p % 8] = (min(lo, pos.min()), max(hi, pos.max()))
-    order = sorted(span.values())
-    assert all(order[i][1] <= order[i + 1][0] + 3 for i in range(len(order) - 1))      # (quads straddle a cut by < 4 positions)
-
-
-@pytest.mark.parametrize("xcds", [1, 8])
 @pytest.mark.parametrize("num_batches", [1, 2, 3])
 @pytest.mark.parametrize("max_chunks", [1, 7, 40, 100000])
-def test_schur_chunks_adaptive_cover(max_chunks, num_batches, xcds):
+def test_schur_chunks_adaptive_cover(max_chunks, num_batches):
     """Adaptive chunk size: every entry belongs to exactly one workgroup's strided sub-chunks and the
     workgroup count respects the device capacity (or is one per tile when there are more tiles than slots).
     Batches: consecutive chunk / tile ranges, off-diagonal chunks before the diagonal ones inside each batch,
@@ -327,29 +222,15 @@ def test_schur_chunks_adaptive_cover(max_chunks, num_batches, xcds):
     obs_cam = pm[:, 1].to(torch.int32)
     row_ptr = torch.zeros(P + 1, dtype=torch.int32)
     row_ptr[1:] = torch.cumsum(m.sum(0), 0).to(torch.int32)
-    desc, ent, tiles, slot, nseg, batches, block_chunk = BA.build_schur_tiles(row_ptr, obs_cam, max_chunks=max_chunks,
-                                                                              num_batches=num_batches, later_scale=0.875, xcds=xcds)
+    desc, ent, tiles, slot, nseg, batches = BA.build_schur_tiles(row_ptr, obs_cam, max_chunks=max_chunks,
+                                                                 num_batches=num_batches, later_scale=0.875)
     seen = np.zeros(len(ent), int)
     for gI, gJ, tb, te, j, J in desc.numpy():
         for s0 in range(tb + j * BA.SUB, te, J * BA.SUB):
             seen[s0:min(s0 + BA.SUB, te)] += 1
     assert (seen == 1).all()
-    assert len(desc) <= max(2 * max_chunks * num_batches, xcds * len(tiles))
+    assert len(desc) <= max(2 * max_chunks * num_batches, len(tiles))
     td, cd, bd = tiles.numpy(), desc.numpy(), batches.numpy()
-    # XCD placement: a permutation inside every launch range; a chunk's entries belong to ONE point-range part, and the
-    # chunks at the positions = x (mod 8) of a range are those of part x as long as part x has any left
-    bc = block_chunk.numpy()
-    pts = ent.numpy()[:, 0]
-    cuts = np.unique(np.concatenate([[pts[tb:te].min(), pts[tb:te].max()] for _, _, tb, te, _, _ in cd]))
-    for c0, cm, c1 in bd[:, :3]:
-        for lo, hi in ((c0, cm), (cm, c1)):
-            assert sorted(bc[lo:hi].tolist()) == list(range(lo, hi))
-    # every point's entries live in chunks of one part: the point ranges of different parts do not overlap
-    part_range = {}
-    for ci, (_, _, tb, te, _, _) in enumerate(cd):
-        part_range.setdefault((int(pts[tb:te].min()), int(pts[tb:te].max())), []).append(ci)
-    ranges = sorted(part_range)
-    assert len(ranges) <= xcds * max(1, num_batches) * 2 * len(td)
     assert td[0, 2] == 0 and td[-1, 3] == len(desc) and (td[1:, 2] == td[:-1, 3]).all()
     assert not batches.is_cuda and bd.shape == (num_batches, 6)
     assert bd[0, 0] == 0 and bd[-1, 2] == len(cd) and bd[0, 3] == 0 and bd[-1, 4] == len(td)

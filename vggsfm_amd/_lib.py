@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VGGSFM_AMD_LIB") or os.path.join(_HERE, "libvggsfm_amd.so")
 
 VGG_OK = 0
+ABI_VERSION = 2       # VGG_ABI_VERSION of include/vggsfm_amd.h this binding was written against
 _ERRORS = {-1: "invalid argument", -2: "HIP runtime error", -3: "workspace too small / missing",
            -4: "unsupported configuration"}
 
@@ -28,10 +29,9 @@ class BAProblem(ctypes.Structure):
                 ("cobs_uv", ctypes.c_void_p), ("cam_const", ctypes.c_void_p), ("intr_const", ctypes.c_void_p),
                 ("pt_const", ctypes.c_void_p), ("num_chunks", ctypes.c_int32), ("num_tile_batches", ctypes.c_int32),
                 ("chunk_desc", ctypes.c_void_p),
-                ("entries", ctypes.c_void_p), ("num_segments", ctypes.c_int32), ("obs_slot", ctypes.c_void_p), ("obs_pt", ctypes.c_void_p),
+                ("entries", ctypes.c_void_p), ("num_segments", ctypes.c_int32), ("obs_slot", ctypes.c_void_p),
                 ("num_tiles", ctypes.c_int32), ("tile_desc", ctypes.c_void_p), ("tile_batches", ctypes.c_void_p),
-                ("chol_split_a", ctypes.c_int32), ("chol_split_b", ctypes.c_int32), ("chol_first_blk", ctypes.c_void_p), ("block_chunk", ctypes.c_void_p),
-                ("super_tiles", ctypes.c_int32), ("quad_mask", ctypes.c_void_p), ("tile_sched", ctypes.c_void_p), ("merged_tile_launch", ctypes.c_int32)]
+                ("chol_split_a", ctypes.c_int32), ("chol_split_b", ctypes.c_int32), ("chol_first_blk", ctypes.c_void_p), ("merged_tile_launch", ctypes.c_int32)]
 
 
 class BAOptions(ctypes.Structure):
@@ -58,7 +58,7 @@ class BASummary(ctypes.Structure):
 
 
 # every symbol include/vggsfm_amd.h declares (tests check the library exports all of them)
-EXPORTED = ["vgg_build_arch", "vgg_abi_version", "vgg_project_points", "vgg_filter_points_workspace_bytes",
+EXPORTED = ["vgg_build_arch", "vgg_abi_version", "vgg_abi_sizeof", "vgg_project_points", "vgg_filter_points_workspace_bytes",
             "vgg_filter_points", "vgg_cam_from_img_workspace_bytes", "vgg_cam_from_img",
             "vgg_triangulate_workspace_bytes", "vgg_triangulate_tracks", "vgg_triangulate_by_pair", "vgg_triangulate_chunks_workspace_bytes",
             "vgg_triangulate_tracks_chunks", "vgg_ba_workspace_bytes", "vgg_ba_solve",
@@ -90,6 +90,15 @@ def lib():
                  "vgg_cholesky_workspace_bytes", "vgg_p3p_ransac_workspace_bytes"):
         getattr(L, name).restype = ctypes.c_size_t
     L.vgg_ba_workspace_bytes.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    # a stale or variant build (VGGSFM_AMD_LIB) with another struct layout would be driven with shifted pointers: refuse it
+    if not hasattr(L, "vgg_abi_sizeof") or L.vgg_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH}: ABI version {L.vgg_abi_version()} but this binding speaks {ABI_VERSION}; rebuild "
+                           "the library (`make -C vggsfm_amd/csrc`)")
+    L.vgg_abi_sizeof.restype = ctypes.c_size_t
+    for which, st in enumerate((BAProblem, BAOptions, BAIteration, BASummary)):
+        if int(L.vgg_abi_sizeof(which)) != ctypes.sizeof(st):
+            raise RuntimeError(f"{LIB_PATH}: sizeof({st.__name__}) is {int(L.vgg_abi_sizeof(which))} in the library and "
+                               f"{ctypes.sizeof(st)} in the binding -- header and binding are out of step")
     _lib = L
     return L
 

@@ -18,8 +18,6 @@ import ctypes
 from dataclasses import dataclass
 from typing import Optional
 
-import os
-
 import torch
 
 from . import _lib
@@ -38,11 +36,6 @@ OVERLAP_FACTORIZATION = False
 OVERLAP_MIN_OBS, OVERLAP_MIN_FRAMES = 1_000_000, 8 * GROUP   # smaller problems keep one batch
 TILE_BATCHES = 3     # Schur tile launches per iteration when the factorisation overlaps them (large problems)
 CHOL_CUS = 32        # CUs given to the factorisation while it overlaps (options.overlap_factorization; multiple of 32)
-XCDS = 1             # point-range parts for XCD placement of the Schur tile chunks (build_schur_tiles); 8 = one part per
-#                      accelerator complex die.  MEASURED AND LEFT OFF (round 2, c3): with 8 parts FETCH_SIZE of the
-#                      off-diagonal launch only went from 3.04 to 2.79 GB and the launch from 0.64 to 0.76 ms -- a 4 MB L2
-#                      turns over every ~6 us under this stream, far less than the drift between the tiles that share a
-#                      segment, so same-XCD placement alone does not produce hits
 
 
 # ------------------------------------------------------------------ rotations (Eigen conventions)
@@ -144,10 +137,6 @@ class DeviceProblem:
     chol_split: tuple = (0, 0)        # (columns of A, columns of B): block-diagonal leading part of the reduced system
     cam_perm: Optional[torch.Tensor] = None     # (S,) long: camera s of this problem is input frame cam_perm[s] (None = identity)
     chol_first_blk: Optional[torch.Tensor] = None   # (ceil(n / 64),) int32 device: row envelope of the reduced system (None = dense)
-    block_chunk: Optional[torch.Tensor] = None      # (num_chunks,) int32 device: launch position -> chunk (XCD placement; None = identity)
-    obs_pt: Optional[torch.Tensor] = None           # (O,) int32 device: point of every point-major observation (None = fused Y pass)
-    quad_mask: Optional[torch.Tensor] = None        # (Q,2) int32 device: set <=> chunk_desc / entries / tile_desc are SUPER-TILES
-    tile_sched: Optional[torch.Tensor] = None       # (B,) int32 device: batch schedule of the tile chunks (xcd_range_schedule)
     merged_tile_launch: bool = False                # off-diagonal and diagonal tile chunks in one launch (small problems)
 
     @property
@@ -161,14 +150,11 @@ class DeviceProblem:
         P.camera_model, P.refine_focal, P.refine_extra = self.camera_model, int(self.refine_focal), int(self.refine_extra)
         P.loss, P.loss_scale = self.loss, self.loss_scale
         for name in ("cam_q", "cam_t", "intr", "pts", "row_ptr", "obs_cam", "obs_uv", "col_ptr", "cobs_pt", "cobs_uv",
-                     "cam_const", "intr_const", "pt_const", "chunk_desc", "entries", "tile_desc", "obs_slot", "obs_pt", "quad_mask", "tile_sched"):
+                     "cam_const", "intr_const", "pt_const", "chunk_desc", "entries", "tile_desc", "obs_slot"):
             t = getattr(self, name)
             setattr(P, name, None if t is None else t.data_ptr())
         P.num_chunks = self.chunk_desc.shape[0]
-        P.super_tiles = int(self.quad_mask is not None)
         P.merged_tile_launch = int(self.merged_tile_launch)
-        if self.quad_mask is not None:
-            self.batch_desc = torch.tensor([[0, 0, self.chunk_desc.shape[0], 0, self.tile_desc.shape[0], 0]], dtype=torch.int32)
         if self.batch_desc is None:                 # a hand-built problem: one batch, off-diagonal chunks first
             noff = int((self.chunk_desc[:, 0] != self.chunk_desc[:, 1]).sum().item())
             self.batch_desc = torch.tensor([[0, noff, self.chunk_desc.shape[0], 0, self.tile_desc.shape[0], 0]],
@@ -180,11 +166,10 @@ class DeviceProblem:
         P.num_segments = self.num_segments
         P.chol_split_a, P.chol_split_b = int(self.chol_split[0]), int(self.chol_split[1])
         P.chol_first_blk = None if self.chol_first_blk is None else self.chol_first_blk.data_ptr()
-        P.block_chunk = None if self.block_chunk is None else self.block_chunk.data_ptr()
         return P
 
 
-def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=None, num_batches=1, later_scale=1.0, xcds=XCDS,
+def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=None, num_batches=1, later_scale=1.0,
                       merged_slots=None):
     """Block-sparse Schur work list (device, torch ops; structure is fixed for the whole solve).
 
@@ -206,14 +191,6 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     first_camera_group).  `later_scale` shrinks the workgroup caps of the batches after the first (they run on a
     CU-masked stream beside the factorisation).
 
-    XCD placement (`xcds` > 1): a point with segments in g camera groups appears in g (g + 1) / 2 tiles, and every one of
-    them stages the point's segments again.  The eight XCDs have private L2s, and workgroup b of a launch runs on XCD
-    b % 8: so the POINT range is cut into `xcds` parts of about equal entry counts, every tile's entry list is chunked
-    per part, and the returned `block_chunk` (num_chunks,) int32 maps launch position -> chunk such that the chunks of
-    part x sit at positions = x (mod xcds).  All tiles then process a given point on the same XCD and its segments come
-    through the fabric once per iteration instead of once per tile -- in principle; see the note at XCDS (measured:
-    no pay-off, default 1 part).
-
     `merged_slots`: the off-diagonal and the diagonal chunks will run in ONE launch (vgg_ba_problem.merged_tile_launch) with
     that many resident workgroups in all; the split between the two kinds follows their entry counts."""
     dev = obs_cam.device
@@ -222,7 +199,7 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     if O == 0:
         z = torch.zeros((0, 4), dtype=torch.int32, device=dev)
         return (torch.zeros((0, 6), dtype=torch.int32, device=dev), z, z.clone(), torch.zeros(0, dtype=torch.int32, device=dev), 0,
-                torch.zeros((1, 6), dtype=torch.int32), torch.zeros(0, dtype=torch.int32, device=dev))
+                torch.zeros((1, 6), dtype=torch.int32))
     counts = (row_ptr[1:] - row_ptr[:-1]).long()
     obs_pt = torch.repeat_interleave(torch.arange(P, device=dev), counts)
     grp = (obs_cam // group).long()
@@ -267,16 +244,7 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     order = torch.argsort(key * P + epos)
     A, B, key, epos = A[order], B[order], key[order], epos[order]
     emask = seg_mask[A] | (seg_mask[B] << 16)
-    # part of an entry = the XCD its point belongs to: `xcds` contiguous ranges of sweep positions with about equal entry counts
-    xcds = max(1, int(xcds))
-    per_point = torch.bincount(epos, minlength=P).double()
-    cum_pt = torch.cumsum(per_point, 0) - per_point
-    part_of_pos = torch.clamp((cum_pt * xcds / max(float(total), 1.0)).long(), max=xcds - 1)
-    epart = part_of_pos[epos]
-    # chunking unit = (tile, part): inside a tile the entries are sorted by sweep position, hence by part
-    ukeys, kcounts = torch.unique_consecutive(key * xcds + epart, return_counts=True)
-    upart = ukeys % xcds
-    ukeys = ukeys // xcds
+    ukeys, kcounts = torch.unique_consecutive(key, return_counts=True)              # chunking unit = tile
     tile_start = torch.cumsum(kcounts, 0) - kcounts
     # presence of a quad = union over its four entries (quads are aligned to the start of the unit, like the kernel's batches)
     unit_of_entry = torch.repeat_interleave(torch.arange(kcounts.shape[0], device=dev), kcounts)
@@ -327,7 +295,6 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     local = torch.arange(ctile.shape[0], device=dev) - cfirst[ctile]
     chunk_desc = torch.stack([ukeys[ctile] // ngroups, ukeys[ctile] % ngroups, tile_start[ctile],
                               tile_start[ctile] + kcounts[ctile], local, nchunks[ctile]], 1).to(torch.int32)
-    chunk_part = upart[ctile]
     # tiles: runs of consecutive units with the same tile key (the partial tiles of ALL their chunks are summed)
     ukey_full = tbatch * (2 * nn) + is_diag.long() * nn + ukeys
     new_tile = torch.ones_like(ukey_full, dtype=torch.bool)
@@ -356,291 +323,12 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
         dg = ids[td[ids]]
         cm = int(tf[dg[0]]) if dg.numel() else c1
         batch_desc[b] = torch.tensor([c0, cm, c1, int(ids[0]), int(ids[-1]) + 1, int(tg[ids].min())])
-    # launch position -> chunk: inside every launch range (off-diagonal / diagonal chunks of a batch) the chunks of part x
-    # go to the positions = x (mod xcds); a part that runs out of chunks is filled from the fullest remaining one
-    cp = chunk_part.cpu().tolist()
-    block_chunk = list(range(len(cp)))
-    if xcds > 1:
-        for b in range(nb):
-            c0, cm, c1 = (int(v) for v in batch_desc[b, :3])
-            for lo, hi in ((c0, cm), (cm, c1)):
-                lists = [[c for c in range(lo, hi) if cp[c] == x] for x in range(xcds)]
-                heads = [0] * xcds
-                for pos in range(lo, hi):
-                    x = (pos - lo) % xcds
-                    if heads[x] >= len(lists[x]):
-                        x = max(range(xcds), key=lambda y: len(lists[y]) - heads[y])
-                    block_chunk[pos] = lists[x][heads[x]]
-                    heads[x] += 1
-    block_chunk = torch.tensor(block_chunk, dtype=torch.int32, device=dev)
     return (chunk_desc.contiguous(), entries.contiguous(), tile_desc.contiguous(), obs_slot.contiguous(), int(nseg),
-            batch_desc.contiguous(), block_chunk)
+            batch_desc.contiguous())
 
 
-XCD_SCHEDULE = os.environ.get("VGGSFM_XCD_SCHEDULE", "0") == "1"   # opt-in: xcd_range_schedule for large single-batch problems
-XCD_RANGE_POINTS = 128
 SPARSE_GRID_DENSITY = 0.05        # compile_problem: below this fill of the (frames x tracks) grid work on the observation list
 MERGED_TILE_MAX_OBS = 1_000_000   # below: off-diagonal and diagonal tiles share one launch
-
-
-def xcd_range_schedule(entries, chunk_desc, tile_desc, batch_desc, wgs, range_points=XCD_RANGE_POINTS, xcds=8):
-    """Explicit batch schedule of the 16-camera tile chunks (`vgg_ba_problem.tile_sched`): every XCD walks ITS eighth of
-    the points RANGE BY RANGE with all the tiles those points touch, so that the re-reads of a segment by the tiles that
-    need it meet in that XCD's L2 instead of coming through the fabric once per tile.
-
-    Workgroup b of a launch runs on XCD b % 8 and the workgroups of an XCD are dispatched in order.  For each launch
-    (off-diagonal tiles, diagonal tiles; `wgs` = (workgroups of the off-diagonal launch, of the diagonal launch), multiples
-    of `xcds`): the quads (four consecutive entries, aligned to the tile's begin) are cut by sweep position into `xcds`
-    parts of equal size; inside part x every tile with quads gets a workgroup and the rest go one by one to the tile with
-    the most quads per workgroup; the part's position interval is cut into ranges of `range_points` positions and the quads of
-    (tile, range) are dealt round-robin to the tile's workgroups -- every workgroup of the XCD therefore works on range r
-    at about the same time.  Returns (chunk_desc (n,6) = gI, gJ, tile_entry_begin, tile_entry_end, sched offset, batches;
-    tile_desc; batch_desc; block_chunk; sched (int32)) or None when a part touches more tiles than it has workgroups."""
-    import numpy as np
-    dev = entries.device
-    ent = entries.cpu().numpy()
-    cd = chunk_desc.cpu().numpy()
-    td = tile_desc.cpu().numpy()
-    bd = batch_desc.numpy()
-    if bd.shape[0] != 1:
-        return None
-    new_cd, new_td, sched_all, block_chunk = [], [], [], []
-    first_diag_chunk = None
-    sched_off = 0
-    for diag, W_total in ((False, wgs[0]), (True, wgs[1])):
-        tiles = [t for t in range(td.shape[0]) if (td[t, 0] == td[t, 1]) == diag]
-        if diag:
-            first_diag_chunk = len(new_cd)
-        if not tiles:
-            continue
-        W = max(1, W_total // xcds)
-        tb = np.array([cd[td[t, 2], 2] for t in tiles]); te = np.array([cd[td[t, 2], 3] for t in tiles])
-        nq = (te - tb + 3) // 4
-        qtile = np.repeat(np.arange(len(tiles)), nq)
-        qloc = np.arange(nq.sum()) - np.repeat(np.cumsum(nq) - nq, nq)
-        qpos = ent[tb[qtile] + 4 * qloc, 0].astype(np.int64)
-        # parts of equal quad counts by position
-        order = np.argsort(qpos, kind="stable")
-        cuts = qpos[order[(np.arange(1, xcds) * len(order)) // xcds]]
-        part = np.searchsorted(cuts, qpos, side="right")
-        part_lo = np.concatenate([[qpos.min()], cuts])
-        rng = (qpos - part_lo[part]) // range_points
-        # workgroups per (tile, part): largest remainder, at least one for a tile with quads in the part
-        cnt = np.zeros((len(tiles), xcds), np.int64)
-        np.add.at(cnt, (qtile, part), 1)
-        J = np.zeros_like(cnt)
-        for x in range(xcds):
-            act = np.nonzero(cnt[:, x])[0]
-            if len(act) == 0:
-                continue
-            if len(act) > W:
-                return None
-            # one workgroup each, then the rest one by one to the tile with the most quads per workgroup (minimises the
-            # largest load; a proportional rounding left single workgroups with twice the average)
-            import heapq
-            j = np.ones(len(act), np.int64)
-            heap = [(-float(cnt[a, x]), k) for k, a in enumerate(act)]
-            heapq.heapify(heap)
-            for _ in range(W - len(act)):
-                _, k = heapq.heappop(heap)
-                j[k] += 1
-                heapq.heappush(heap, (-float(cnt[act[k], x]) / j[k], k))
-            J[act, x] = j
-        # rank of a quad inside its (tile, part, range) run (quads of a tile are ascending in position)
-        key = (qtile * xcds + part) * (rng.max() + 1) + rng
-        run_start = np.concatenate([[True], key[1:] != key[:-1]])
-        rank = np.arange(len(key)) - np.maximum.accumulate(np.where(run_start, np.arange(len(key)), 0))
-        wg = (rank + rng) % J[qtile, part]
-        # chunk id: tile-major, then part, then workgroup
-        chunk_of = np.cumsum(J.reshape(-1)) - J.reshape(-1)               # first chunk of (tile, part)
-        cid = chunk_of[qtile * xcds + part] + wg
-        nchunks = int(J.sum())
-        o2 = np.argsort(cid, kind="stable")                                # positions ascending inside a chunk
-        nbat = np.bincount(cid, minlength=nchunks)
-        offs = np.cumsum(nbat) - nbat + sched_off
-        sched_all.append(qloc[o2].astype(np.int32))
-        sched_off += len(o2)
-        base = len(new_cd)
-        ct = np.repeat(np.arange(len(tiles)), J.sum(1))                     # tile of every chunk
-        for c in range(nchunks):
-            t = tiles[ct[c]]
-            new_cd.append([td[t, 0], td[t, 1], tb[ct[c]], te[ct[c]], offs[c], nbat[c]])
-        first = np.cumsum(J.sum(1)) - J.sum(1)
-        for k, t in enumerate(tiles):
-            new_td.append([td[t, 0], td[t, 1], base + first[k], base + first[k] + J[k].sum()])
-        # launch position p -> chunk: XCD p % xcds takes the workgroups of part p % xcds in tile order
-        cpart = np.concatenate([np.repeat(np.arange(xcds), J[k]) for k in range(len(tiles))])
-        lists = [list(base + np.nonzero(cpart == x)[0]) for x in range(xcds)]
-        heads = [0] * xcds
-        for pos in range(nchunks):
-            x = pos % xcds
-            if heads[x] >= len(lists[x]):
-                x = max(range(xcds), key=lambda y: len(lists[y]) - heads[y])
-            block_chunk.append(lists[x][heads[x]])
-            heads[x] += 1
-    n = len(new_cd)
-    i32 = lambda a: torch.tensor(np.asarray(a, dtype=np.int32).reshape(len(a), -1) if len(a) else np.zeros((0, 6), np.int32), dtype=torch.int32, device=dev)
-    batch = torch.tensor([[0, first_diag_chunk if first_diag_chunk is not None else n, n, 0, len(new_td), 0]], dtype=torch.int32)
-    sched = torch.from_numpy(np.concatenate(sched_all)).to(dev)
-    return (i32(new_cd).contiguous(), i32(new_td).contiguous(), batch, torch.tensor(block_chunk, dtype=torch.int32, device=dev), sched.contiguous())
-
-
-SUPER_BATCH_OVERHEAD = 12.0  # cost of a batch besides its matrix instructions, in matrix instructions of one SIMD (barrier, operand fetch)
-
-
-def _super_block_bits(group=GROUP, bd=6):
-    """(24 * bd / 16,) long: bits of the 32-camera presence mask of a super-group whose cameras have rows in each 16-row
-    block of the super-tile (`super_block_bits` in csrc/ba.hip)."""
-    per_half = group * bd // 16
-    out = []
-    for blk in range(2 * per_half):
-        half, b = divmod(blk, per_half)
-        s0, s1 = (16 * b) // bd, min(group - 1, (16 * b + 15) // bd)
-        out.append((((2 << s1) - 1) & ~((1 << s0) - 1)) << (16 * half))
-    return torch.tensor(out, dtype=torch.long)
-
-
-# Opt-in (VGGSFM_SUPER_TILES=1): 2 x 2 super-tiles of 32 x 32 cameras for shared-intrinsics problems (build_schur_supertiles,
-# super_tile_kernel).  Measured on c3: 1.62 ms against 0.62 + 0.27 ms of the 16-camera tile kernels -- see DESIGN.md section 6.
-SUPER_TILES = os.environ.get("VGGSFM_SUPER_TILES", "0") == "1"
-
-
-def build_schur_supertiles(row_ptr, obs_cam, group=GROUP, max_wgs=256):
-    """Schur work list in 2 x 2 SUPER-TILES (6 x 6 camera blocks only; `super_tile_kernel` in csrc/ba.hip).
-
-    The tile kernel of `build_schur_tiles` is bound by the staging of its operands: a 96 x 96 tile multiplies two 2304-byte
-    segments per entry, 12 flop per staged byte -- the machine balance (78.6 TFLOP/s over ~6.4 TB/s).  A workgroup of 8
-    wavefronts that owns the 192 x 192 tile of a PAIR of camera groups on either side stages 4 segments for 4 products:
-    twice the flops per byte, and with the presence skipping of the kernels the absent halves cost nothing.
-
-    A super-group = 2 consecutive camera groups (32 cameras); a super-entry pairs the (up to) two segments of a point in
-    super-group sI with those in sJ >= sI; the segment buffer and `obs_slot` are those of `build_schur_tiles`.
-    Returns (chunk_desc (n,8) int32 = sI,sJ,entry_begin,entry_end,j,J,quad_begin,0 ; entries (E,4) int32 = segA0,segA1,segB0,
-    segB1 (`num_segments` = the all-zero segment stands for an absent half; a diagonal super-tile has B = A) ; quad_mask
-    (Q,2) int32 = presence of the 32 cameras of sI / of sJ in the union of the four entries of a quad (quads are aligned to
-    the tile's begin) ; tile_desc (T,4) int32 = sI,sJ,chunk_begin,chunk_end ; obs_slot ; number of segments).  `entries` and
-    `quad_mask` carry one sub-chunk (SUB entries, SUB / 4 quads) of padding behind the last tile.
-    Entries are sorted by tile (off-diagonal tiles first) and by the sweep position of the point inside a tile; a tile with
-    Entries are sorted by tile (off-diagonal tiles first) and, inside a tile, by block pattern and sweep position; a tile
-    gets J workgroups in proportion to its cost (matrix instructions of the busiest SIMD, from the quad masks), all
-    workgroups together filling `max_wgs` (one resident round of one workgroup per CU); workgroup j takes the sub-chunks
-    j, j + J, ... of SUB entries."""
-    dev = obs_cam.device
-    O = obs_cam.shape[0]
-    P = row_ptr.shape[0] - 1
-    i32 = lambda *shape: torch.zeros(shape, dtype=torch.int32, device=dev)
-    if O == 0:
-        return i32(0, 8), i32(0, 4), i32(0, 2), i32(0, 4), i32(0), 0
-    counts = (row_ptr[1:] - row_ptr[:-1]).long()
-    obs_pt = torch.repeat_interleave(torch.arange(P, device=dev), counts)
-    grp = (obs_cam // group).long()
-    is_start = torch.ones(O, dtype=torch.bool, device=dev)
-    is_start[1:] = (obs_pt[1:] != obs_pt[:-1]) | (grp[1:] != grp[:-1])
-    seg_begin = torch.nonzero(is_start).squeeze(1)
-    nseg = seg_begin.shape[0]
-    seg_id = torch.cumsum(is_start.long(), 0) - 1
-    seg_mask = torch.zeros(nseg + 1, dtype=torch.long, device=dev).index_add_(0, seg_id, 1 << (obs_cam.long() % group))
-    seg_pt, seg_grp = obs_pt[seg_begin], grp[seg_begin]
-    obs_slot = (seg_id * group + obs_cam.long() % group).to(torch.int32)
-    # super-segments: runs of (point, group // 2) -- one or two consecutive segments
-    sgrp = seg_grp // 2
-    s_start = torch.ones(nseg, dtype=torch.bool, device=dev)
-    s_start[1:] = (seg_pt[1:] != seg_pt[:-1]) | (sgrp[1:] != sgrp[:-1])
-    ss_first = torch.nonzero(s_start).squeeze(1)
-    nss = ss_first.shape[0]
-    ss_n = torch.bincount(torch.cumsum(s_start.long(), 0) - 1, minlength=nss)
-    first_half = seg_grp[ss_first] % 2
-    zero = torch.full_like(ss_first, nseg)
-    h0 = torch.where(first_half == 0, ss_first, zero)
-    h1 = torch.where(first_half == 1, ss_first, torch.where(ss_n == 2, ss_first + 1, zero))
-    ss_mask = seg_mask[h0] | (seg_mask[h1] << 16)                  # (seg_mask[nseg] = 0: the zero segment)
-    ss_pt, ss_g = seg_pt[ss_first], sgrp[ss_first]
-    nsg = int(ss_g.max().item()) + 1
-    # pairs (sI <= sJ) of the super-segments of a point
-    pss_ptr = torch.zeros(P + 1, dtype=torch.long, device=dev)
-    pss_ptr[1:] = torch.cumsum(torch.bincount(ss_pt, minlength=P), 0)
-    idx = torch.arange(nss, device=dev)
-    npair = pss_ptr[ss_pt + 1] - idx
-    total = int(npair.sum().item())
-    A = torch.repeat_interleave(idx, npair)
-    B = A + (torch.arange(total, device=dev) - (torch.cumsum(npair, 0) - npair)[A])
-    # sweep position of a point (see build_schur_tiles)
-    ncam = int(obs_cam.max().item()) + 1
-    first_cam = obs_cam.long()[row_ptr[:-1].long().clamp(max=O - 1)]
-    last_cam = obs_cam.long()[(row_ptr[1:].long() - 1).clamp(min=0)]
-    prank = torch.empty(P, dtype=torch.long, device=dev)
-    prank[torch.argsort(first_cam * ncam + last_cam, stable=True)] = torch.arange(P, device=dev)
-    sI, sJ = ss_g[A], ss_g[B]
-    nn = nsg * nsg
-    key = (sI == sJ).long() * nn + sI * nsg + sJ
-    # inside a tile: by BLOCK PATTERN (which of the 2 x 12 sixteen-row blocks of the super-tile hold a camera of the entry),
-    # then by sweep position -- the four entries of a quad then have (nearly) the same pattern and the union the kernel
-    # skips by is (nearly) what every one of them needs
-    bits = _super_block_bits(group)
-    patA = (((ss_mask[:, None] & bits[None].to(dev)) != 0).long() * (1 << torch.arange(bits.shape[0], device=dev))[None]).sum(1)
-    pat = patA[A] * (1 << bits.shape[0]) + patA[B]
-    order = torch.argsort((key * (1 << (2 * bits.shape[0])) + pat) * P + prank[ss_pt[A]])
-    A, B, key = A[order], B[order], key[order]
-    entries = torch.stack([h0[A], h1[A], h0[B], h1[B]], 1).to(torch.int32)
-    ukeys, kcounts = torch.unique_consecutive(key, return_counts=True)
-    tile_start = torch.cumsum(kcounts, 0) - kcounts
-    is_diag = ukeys >= nn
-    ukeys = ukeys % nn
-    # quads
-    unit = torch.repeat_interleave(torch.arange(kcounts.shape[0], device=dev), kcounts)
-    upos = torch.arange(total, device=dev) - tile_start[unit]
-    nquad = (kcounts + 3) // 4
-    quad_start = torch.cumsum(nquad, 0) - nquad
-    quad = quad_start[unit] + upos // 4
-    NQ = int(nquad.sum().item())
-    qa = torch.zeros((NQ, 4), dtype=torch.long, device=dev)
-    qb = torch.zeros((NQ, 4), dtype=torch.long, device=dev)
-    qa[quad, upos % 4] = ss_mask[A]
-    qb[quad, upos % 4] = ss_mask[B]
-    quad_mask = torch.stack([qa[:, 0] | qa[:, 1] | qa[:, 2] | qa[:, 3], qb[:, 0] | qb[:, 1] | qb[:, 2] | qb[:, 3]], 1).to(torch.int32)
-    # Workgroups per tile in proportion to the tile's COST: per quad, the matrix instructions of the busiest SIMD under the
-    # kernel's sub-tile ownership (+ a constant per batch), summed over the tile.  The strided sub-chunks give every
-    # workgroup of a tile the same mix of patterns, so its cost is the tile's / J.
-    ua = ((quad_mask[:, 0:1].long() & bits[None].to(dev)) != 0)                  # (Q, 12) blocks of side A with a camera
-    ub = ((quad_mask[:, 1:2].long() & bits[None].to(dev)) != 0)
-    nblk = bits.shape[0]
-    cls = torch.arange(nblk, device=dev) % 4
-    ra4 = torch.stack([ua[:, cls == k].sum(1) for k in range(4)], 1).double()      # active rows per class r % 4
-    cb4 = torch.stack([ub[:, cls == k].sum(1) for k in range(4)], 1).double()
-    off_simd = torch.stack([sum(ra4[:, k] * cb4[:, (sd - k) % 4] for k in range(4)) for sd in range(4)], 1)   # (r + c) % 4 == sd
-    tri_r, tri_c = torch.tril_indices(nblk, nblk, device=dev)                     # row-major enumeration of the lower triangle
-    tri_on = (ua[:, tri_r] & ua[:, tri_c]).double()
-    tcls = torch.arange(tri_r.shape[0], device=dev) % 4
-    diag_simd = torch.stack([tri_on[:, tcls == k].sum(1) for k in range(4)], 1)
-    quad_diag = torch.repeat_interleave(is_diag, nquad)
-    quad_cost = 3.0 * torch.where(quad_diag, diag_simd.max(1).values, off_simd.max(1).values) + SUPER_BATCH_OVERHEAD
-    tile_cost = torch.zeros(kcounts.shape[0], dtype=torch.float64, device=dev).index_add_(
-        0, torch.repeat_interleave(torch.arange(kcounts.shape[0], device=dev), nquad), quad_cost)
-    max_j = torch.clamp((kcounts + MIN_CHUNK - 1) // MIN_CHUNK, min=1)            # at least MIN_CHUNK entries per workgroup
-    jof = lambda c: torch.minimum(torch.clamp(torch.ceil(tile_cost / c).long(), min=1), max_j)
-    lo_c, hi_c = float(tile_cost.sum().item()) / max(max_wgs, 1), float(tile_cost.max().item()) + 1.0
-    if int(jof(hi_c).sum().item()) > max_wgs:       # more tiles than workgroup slots: one workgroup per tile
-        lo_c = hi_c
-    for _ in range(40):                             # smallest cost per workgroup whose workgroup count fits
-        mid = 0.5 * (lo_c + hi_c)
-        if int(jof(mid).sum().item()) <= max_wgs:
-            hi_c = mid
-        else:
-            lo_c = mid
-    nchunks = jof(hi_c)
-    ctile = torch.repeat_interleave(torch.arange(ukeys.shape[0], device=dev), nchunks)
-    cfirst = torch.cumsum(nchunks, 0) - nchunks
-    local = torch.arange(ctile.shape[0], device=dev) - cfirst[ctile]
-    chunk_desc = torch.stack([ukeys[ctile] // nsg, ukeys[ctile] % nsg, tile_start[ctile], tile_start[ctile] + kcounts[ctile],
-                              local, nchunks[ctile], quad_start[ctile], torch.zeros_like(local)], 1).to(torch.int32)
-    tile_desc = torch.stack([ukeys // nsg, ukeys % nsg, cfirst, cfirst + nchunks], 1).to(torch.int32)
-    # the kernel fetches indices and masks a whole sub-chunk at a time: one sub-chunk of padding behind the last tile
-    entries = torch.cat([entries, torch.full((SUB, 4), nseg, dtype=torch.int32, device=dev)])
-    quad_mask = torch.cat([quad_mask, torch.zeros((SUB // 4, 2), dtype=torch.int32, device=dev)])
-    return (chunk_desc.contiguous(), entries.contiguous(), quad_mask.contiguous(), tile_desc.contiguous(), obs_slot.contiguous(),
-            int(nseg))
-
-
 CAMERA_SPLIT_MIN_STEPS = 2    # shared 64-column factorisation steps below which re-ordering the cameras is not worth it
 
 
@@ -833,7 +521,6 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
         row_ptr = torch.zeros(P + 1, dtype=torch.int32, device=dev)
         row_ptr[1:] = torch.cumsum(torch.bincount(p, minlength=P), 0).to(torch.int32)
         obs_uv = cobs_uv[o].contiguous()
-        pm = torch.stack([p[o], fs[o]], 1)                             # (point, camera) of every point-major observation
     else:
         if cam_perm is not None:                        # (frames 0 and 1 -- the default gauge -- stay first: A is a prefix)
             ext, K, masks, tracks = ext[cam_perm], K[cam_perm], masks[cam_perm], tracks[cam_perm]
@@ -887,33 +574,17 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
     # resident schur_tile workgroups per CU (occupancy of the kernel variant): off-diagonal launch 3 (BD = 6) or 2,
     # diagonal launch 4 or 2 -- one full round each
     slots = (cus * 3, cus * 4) if shared_camera else (cus * 2, cus * 2)
-    if os.environ.get("VGGSFM_TILE_SLOTS"):         # experiment (with VGG_TILE_MERGED=1: one launch, the slots shared by both kinds)
-        slots = tuple(int(v) for v in os.environ["VGGSFM_TILE_SLOTS"].split(","))
     # three batches when the factorisation can overlap the later ones (enough camera groups, enough work per batch)
     overlap = OVERLAP_FACTORIZATION if overlap is None else bool(overlap)
     nb = TILE_BATCHES if (overlap and int(obs_cam.shape[0]) >= OVERLAP_MIN_OBS and S >= OVERLAP_MIN_FRAMES) else 1
-    quad_mask = None
-    merged = False
-    if SUPER_TILES and shared_camera and nb == 1 and int(obs_cam.shape[0]) > 0:
-        # 6 x 6 camera blocks: 2 x 2 super-tiles, one workgroup of 8 wavefronts per CU, one launch
-        chunk_desc, entries, quad_mask, tile_desc, obs_slot, nseg = build_schur_supertiles(row_ptr, obs_cam, max_wgs=cus)
-        batch_desc, block_chunk = None, None
-    else:
-        # small problems: one tile launch (c2, 0.25 M observations: 0.101 -> 0.068 ms for the tiles; c3, 5 M: 0.84 -> 0.90 ms)
-        merged = nb == 1 and int(obs_cam.shape[0]) < MERGED_TILE_MAX_OBS and not os.environ.get("VGGSFM_TILE_SLOTS")
-        chunk_desc, entries, tile_desc, obs_slot, nseg, batch_desc, block_chunk = build_schur_tiles(
-            row_ptr, obs_cam, max_chunks=slots, num_batches=nb, later_scale=(cus - CHOL_CUS) / cus,
-            merged_slots=(slots[0] if merged else None))
-    tile_sched = None
-    if XCD_SCHEDULE and quad_mask is None and nb == 1 and int(obs_cam.shape[0]) >= OVERLAP_MIN_OBS:
-        res = xcd_range_schedule(entries, chunk_desc, tile_desc, batch_desc, (slots[0] // 8 * 8, slots[1] // 8 * 8))
-        if res is not None:
-            chunk_desc, tile_desc, batch_desc, block_chunk, tile_sched = res
+    # small problems: one tile launch (c2, 0.25 M observations: 0.101 -> 0.068 ms for the tiles; c3, 5 M: 0.84 -> 0.90 ms)
+    merged = nb == 1 and int(obs_cam.shape[0]) < MERGED_TILE_MAX_OBS
+    chunk_desc, entries, tile_desc, obs_slot, nseg, batch_desc = build_schur_tiles(
+        row_ptr, obs_cam, max_chunks=slots, num_batches=nb, later_scale=(cus - CHOL_CUS) / cus,
+        merged_slots=(slots[0] if merged else None))
     prob = DeviceProblem(cam_q, cam_t, intr, pts, row_ptr, obs_cam, obs_uv, col_ptr, cobs_pt, cobs_uv, chunk_desc,
                          entries, tile_desc, obs_slot, nseg, MODEL_ID[camera_type], cam_const=cam_const,
-                         batch_desc=batch_desc, chol_split=chol_split, cam_perm=cam_perm, block_chunk=block_chunk, quad_mask=quad_mask,
-                         tile_sched=tile_sched, merged_tile_launch=(quad_mask is None and tile_sched is None and merged),
-                         obs_pt=pm[:, 0].to(torch.int32).contiguous())
+                         batch_desc=batch_desc, chol_split=chol_split, cam_perm=cam_perm, merged_tile_launch=merged)
     if first_group is not None:
         kd = 2 if camera_type == "SIMPLE_RADIAL" else 1              # upper bound of the intrinsics unknowns per block
         prob.chol_first_blk = envelope_blocks(first_group, S, 6 * S + kd * n_intr).to(dev)

@@ -124,7 +124,7 @@ static Dims make_dims(const vgg_ba_problem* pb) {
   return d;
 }
 
-static Ws carve(const Dims& d, int max_iters, int num_chunks, int num_segments, void* base, int super_tiles = 0) {
+static Ws carve(const Dims& d, int max_iters, int num_chunks, int num_segments, void* base) {
   Ws w;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return (char*)base + o; };
@@ -160,7 +160,7 @@ static Ws carve(const Dims& d, int max_iters, int num_chunks, int num_segments, 
   w.chol_inv = (double*)take(cholesky_workspace_bytes(d.n_red));
   {
     const size_t bdt = d.shared ? 6 : d.BDp;
-    w.tile_part = (double*)take(8ull * (size_t)(num_chunks > 0 ? num_chunks : 1) * bdt * bdt * 256 * (super_tiles ? 4 : 1));   // R*R, R = 16*bdt (32*bdt)
+    w.tile_part = (double*)take(8ull * (size_t)(num_chunks > 0 ? num_chunks : 1) * bdt * bdt * 256);   // R*R, R = 16*bdt
   }
   w.batch_flags = (int32_t*)take(64);
   w.total_bytes = off;
@@ -170,7 +170,7 @@ static Ws carve(const Dims& d, int max_iters, int num_chunks, int num_segments, 
 struct DevProblem {  // by-value kernel argument
   Dims d;
   const double *cam_q, *cam_t, *intr, *pts;
-  const int32_t *row_ptr, *obs_cam, *col_ptr, *cobs_pt, *obs_slot, *obs_pt;
+  const int32_t *row_ptr, *obs_cam, *col_ptr, *cobs_pt, *obs_slot;
   const float2 *obs_uv, *cobs_uv;
   const uint8_t *cam_const, *intr_const, *pt_const;
 };
@@ -179,7 +179,7 @@ static DevProblem dev_problem(const vgg_ba_problem* pb, const Dims& d) {
   DevProblem p;
   p.d = d; p.cam_q = pb->cam_q; p.cam_t = pb->cam_t; p.intr = pb->intr; p.pts = pb->pts;
   p.row_ptr = pb->row_ptr; p.obs_cam = pb->obs_cam; p.col_ptr = pb->col_ptr; p.cobs_pt = pb->cobs_pt;
-  p.obs_slot = pb->obs_slot; p.obs_pt = pb->obs_pt;
+  p.obs_slot = pb->obs_slot;
   p.obs_uv = (const float2*)pb->obs_uv; p.cobs_uv = (const float2*)pb->cobs_uv;
   p.cam_const = pb->cam_const; p.intr_const = pb->intr_const; p.pt_const = pb->pt_const;
   return p;
@@ -573,8 +573,6 @@ static int lanes_per_point(int P, int O) {
 static bool long_tracks(int lpp, int P, int O) {
   return g_tuning.longt >= 0 ? g_tuning.longt != 0 : (double)O > 1.5 * lpp * (double)P;
 }
-static const bool g_tile_merged = [] { const char* e = getenv("VGG_TILE_MERGED"); return e && e[0] == '1'; }();   // experiment: one tile launch
-static const bool g_fused_point_pass = [] { const char* e = getenv("VGG_SPLIT_POINT_PASS"); return !(e && e[0] == '1'); }();
 
 // ---------------------------------------------------------------------------------------------
 // point-major pass: LPP lanes per point, 64 / LPP points per wavefront (LPP = 64: one wavefront per point; 32 / 16 for
@@ -831,44 +829,6 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
   if (threadIdx.x == 0) w.part_B[blockIdx.x] = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
 }
 
-// Per-observation Schur factors Y_i = s_c o ((F_i^T E_i) G_p), one THREAD per observation (point-major order, so the
-// lanes of a wavefront read consecutive observations, mostly of the same point and of consecutive cameras: the gathers of
-// the point's X / G and of the cameras coalesce or hit L1).  No reductions and no per-point serial work in here: ~100
-// registers, and every lane is busy whatever the track length.  Same arithmetic as the Y sweep of point_pass_kernel
-// (G is read back from w.G instead of being held in registers): bit-identical Y.
-template <int KD>
-__global__ __launch_bounds__(256, 4) void y_write_kernel(DevProblem pb, Ws w) {
-  constexpr int BD = 6 + KD;
-  if (w.ctl->done) return;
-  const Dims& d = pb.d;
-  const int bdt = d.shared ? 6 : BD, rt = kGroup * bdt;
-  const int O = d.O;
-  for (int o = blockIdx.x * 256 + threadIdx.x; o < O; o += gridDim.x * 256) {
-    const int p = pb.obs_pt[o], c = pb.obs_cam[o], slot = pb.obs_slot[o];
-    const float2 uv = pb.obs_uv[o];
-    const int a = d.shared ? 0 : c;
-    const double X[3] = {pb.pts[3 * p], pb.pts[3 * p + 1], pb.pts[3 * p + 2]};
-    const bool pt_c = pb.pt_const ? pb.pt_const[p] != 0 : false;
-    const double* Gp = w.G + 6 * (size_t)p;
-    const double G0 = Gp[0], G1 = Gp[1], G2 = Gp[2], G3 = Gp[3], G4 = Gp[4], G5 = Gp[5];
-    double r[2], F[2 * BD], E[6];
-    eval_full<KD>(d, CamR(pb.cam_q + 4 * c).R, pb.cam_t + 3 * c, pb.intr + 4 * a, X, uv, pb.cam_const ? pb.cam_const[c] : 0u,
-                  pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
-    double* y = w.Y + (size_t)(slot >> 4) * (3 * rt) + (slot & 15) * bdt;
-#pragma unroll
-    for (int i = 0; i < BD; ++i) {
-      if (i < bdt) {
-        const double sc = (i < 6) ? w.scale_c[6 * c + i] : w.scale_c[6 * d.C + KD * c + (i - 6)];
-        const double w0 = F[i] * E[0] + F[BD + i] * E[3], w1 = F[i] * E[1] + F[BD + i] * E[4],
-                     w2 = F[i] * E[2] + F[BD + i] * E[5];
-        y[i] = sc * (w0 * G0);
-        y[rt + i] = sc * (w0 * G1 + w1 * G3);
-        y[2 * rt + i] = sc * (w0 * G2 + w1 * G4 + w2 * G5);
-      }
-    }
-  }
-}
-
 // start-of-iteration checks (Ceres FinalizeIterationAndCheckIfMinimizerCanContinue)
 __device__ __forceinline__ void begin_iteration(const Ws& w, const vgg_ba_options& opt) {
   Ctl* c = w.ctl;
@@ -919,12 +879,6 @@ __global__ __launch_bounds__(256) void begin_iteration_kernel(Ws w, vgg_ba_optio
 // NH x NH accumulators in registers for the whole chunk; all MFMAs are unconditional (scalar loop bounds).
 typedef double f64x4_t __attribute__((ext_vector_type(4)));
 
-#ifndef VGG_SUPER_TRACE
-#define VGG_SUPER_TRACE 0            // debug builds: per-workgroup cycle counts of super_tile_kernel (printf)
-#endif
-#ifndef VGG_SABLATE
-#define VGG_SABLATE 0                // profiling builds of super_tile_kernel: 1 = no matrix instructions, 2 = no LDS-DMA
-#endif
 #ifndef VGG_NO_SKIP
 #define VGG_NO_SKIP 0               // profiling builds: 1 = every sub-tile of every batch runs (no presence skipping)
 #endif
@@ -940,7 +894,7 @@ __device__ __forceinline__ uint32_t block_slot_bits(int blk) {
 template <int BD, bool DIAG>
 __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __restrict__ chunk_desc,
                                                 const int32_t* __restrict__ entries, int chunk, int zero_seg,
-                                                const int32_t* __restrict__ sched, double* __restrict__ ops) {
+                                                double* __restrict__ ops) {
   constexpr int YS = BD * 3;                      // doubles per Y block
   constexpr int SEG = kGroup * YS;                // doubles per segment (16 slots)
   constexpr int R = kGroup * BD;                  // rows / cols of the tile
@@ -959,19 +913,12 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
   // workgroup j takes the sub-chunks j, j+J, j+2J, ... of kSub entries, so all workgroups of all tiles sweep
   // the point range at the same relative rate and the (up to ~G) re-reads of one point's segments by
   // different tiles fall close together in time (they hit the L2 / Infinity Cache instead of HBM).
-  // launch position -> chunk (XCD placement: the chunks of one point range share an XCD and its L2; vggsfm_amd.h)
   const int e0 = chunk_desc[6 * chunk + 2], e1 = chunk_desc[6 * chunk + 3];
   const int cj = chunk_desc[6 * chunk + 4], cJ = chunk_desc[6 * chunk + 5];
   constexpr int BPS = kSub / 4;                   // batches of 4 entries per sub-chunk
   const int nsub = (e1 - e0 + kSub - 1) / kSub;
-  // With a batch schedule (vgg_ba_problem.tile_sched) fields 4, 5 of the chunk are (offset into sched, number of batches)
-  // and batch b of the workgroup is the quad sched[offset + b] of its tile -- any order the host wants; batches past the
-  // end point behind the tile's list (zero segments).
-  const int nb = sched ? cJ : ((nsub - cj + cJ - 1) / cJ) * BPS;             // batches of this workgroup
-  auto ebase = [&](int b) -> int {
-    if (sched) return (b < nb) ? e0 + 4 * sched[cj + b] : e1;
-    return e0 + ((b / BPS) * cJ + cj) * kSub + (b % BPS) * 4;
-  };
+  const int nb = ((nsub - cj + cJ - 1) / cJ) * BPS;                          // batches of this workgroup
+  auto ebase = [&](int b) -> int { return e0 + ((b / BPS) * cJ + cj) * kSub + (b % BPS) * 4; };
   f64x4_t acc[NH][NH];
 #pragma unroll
   for (int i = 0; i < NH; ++i)
@@ -1140,26 +1087,22 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
 // the two launches of a tile batch (off-diagonal tiles, diagonal tiles) ...
 template <int BD, bool DIAG>
 __global__ __launch_bounds__(256, (BD == 6 ? (DIAG ? 4 : VGG_OFFDIAG_OCC) : 2)) void schur_tile_kernel(Ws w, const int32_t* __restrict__ chunk_desc,
-                                                         const int32_t* __restrict__ entries, int chunk0, int zero_seg,
-                                                         const int32_t* __restrict__ block_chunk,
-                                                         const int32_t* __restrict__ sched) {
+                                                         const int32_t* __restrict__ entries, int chunk0, int zero_seg) {
   __shared__ __attribute__((aligned(16))) double ops[2 * (DIAG ? 1 : 2) * 4 * kGroup * BD * 3];
   if (w.ctl->done) return;
-  const int chunk = block_chunk ? block_chunk[chunk0 + blockIdx.x] : chunk0 + blockIdx.x;
-  schur_tile_body<BD, DIAG>(w, chunk_desc, entries, chunk, zero_seg, sched, ops);
+  const int chunk = chunk0 + blockIdx.x;
+  schur_tile_body<BD, DIAG>(w, chunk_desc, entries, chunk, zero_seg, ops);
 }
 // ... or ONE launch for both (vgg_ba_tuning / VGG_TILE_MERGED): the diagonal tiles then sweep the points together with the
 // off-diagonal ones and find the segments those have just brought into the Infinity Cache
 template <int BD>
 __global__ __launch_bounds__(256, (BD == 6 ? VGG_OFFDIAG_OCC : 2)) void schur_tile_merged_kernel(Ws w, const int32_t* __restrict__ chunk_desc,
-                                                         const int32_t* __restrict__ entries, int chunk0, int zero_seg,
-                                                         const int32_t* __restrict__ block_chunk,
-                                                         const int32_t* __restrict__ sched) {
+                                                         const int32_t* __restrict__ entries, int chunk0, int zero_seg) {
   __shared__ __attribute__((aligned(16))) double ops[2 * 2 * 4 * kGroup * BD * 3];
   if (w.ctl->done) return;
-  const int chunk = block_chunk ? block_chunk[chunk0 + blockIdx.x] : chunk0 + blockIdx.x;
-  if (chunk_desc[6 * chunk] == chunk_desc[6 * chunk + 1]) schur_tile_body<BD, true>(w, chunk_desc, entries, chunk, zero_seg, sched, ops);
-  else schur_tile_body<BD, false>(w, chunk_desc, entries, chunk, zero_seg, sched, ops);
+  const int chunk = chunk0 + blockIdx.x;
+  if (chunk_desc[6 * chunk] == chunk_desc[6 * chunk + 1]) schur_tile_body<BD, true>(w, chunk_desc, entries, chunk, zero_seg, ops);
+  else schur_tile_body<BD, false>(w, chunk_desc, entries, chunk, zero_seg, ops);
 }
 
 // S[(cI,a,i),(cJ,b,j)] = - sum over the chunks of tile (gI,gJ) of the partial tiles (plain stores: every
@@ -1199,341 +1142,6 @@ __global__ __launch_bounds__(256) void tile_reduce_kernel(Ws w, int n_red, int C
   if (ch < c1) s0 += src[(size_t)ch * R * R];
   const int hi = ri > cj ? ri : cj, lo = ri > cj ? cj : ri;
   dst[(size_t)hi * n + lo] = -(s0 + s1);
-}
-
-// ---------------------------------------------------------------------------------------------
-// 2 x 2 SUPER-TILES (6 x 6 camera blocks: shared intrinsics or constant intrinsics).
-// schur_tile_kernel stages 2 x 2304 bytes per entry for a 96 x 96 product: 12 flop per byte, the machine balance, so it
-// runs at the rate its operands come through the fabric (measured: skipping 28 % of its MFMAs bought 3 %).  Here a
-// workgroup of EIGHT wavefronts owns the 192 x 192 tile of a PAIR of camera groups on either side (144 sub-tiles, 18 per
-// wavefront = 144 accumulator registers, one workgroup per CU) and stages 4 segments for 4 products -- twice the
-// arithmetic per staged byte; the halves a point does not reach are the all-zero segment (an L2 hit) and their
-// sub-tiles are skipped with the quad mask.  Same segment buffer, same component-major LDS image with the odd entries
-// XOR-swizzled, same one-batch-ahead register staging as schur_tile_kernel; off-diagonal and diagonal super-tiles
-// share one launch (chunk sizes weighted by bytes per entry on the host, ba.build_schur_supertiles).
-constexpr int kSBD = 6;                           // rows per camera
-constexpr int kSSeg = kGroup * kSBD * 3;          // doubles per segment
-constexpr int kSR = kGroup * kSBD;                // rows of one half (one camera group)
-constexpr int kSR2 = 2 * kSR;                     // rows / cols of a super-tile
-constexpr int kSNT = kSR2 / 16;                   // 12 sub-tiles per side
-constexpr int kSRing = 4;                         // LDS ring: the batch being multiplied + three in flight
-constexpr int kSOpsBytes = kSRing * 4 * 4 * kSSeg * 8;  // operand ring: [ring slot][entry][segment][SEG] = 147456 bytes
-constexpr int kSIdxSlot = kSub * 16 + (kSub / 4) * 8;  // index ring slot: the entries (4 int32 each) and quad masks of one sub-chunk
-constexpr int kSIdxRing = 4;
-constexpr int kSuperLds = kSOpsBytes + kSIdxRing * kSIdxSlot;   // 149760 of the 160 KiB
-
-// presence bits (of the 32-camera mask of a super-group) of the cameras with rows in 16-row block `blk` (0..11)
-__device__ __forceinline__ uint32_t super_block_bits(int blk) {
-  if (blk >= kSNT) return 0u;
-  const int half = blk / (kSNT / 2);
-  return block_slot_bits<kSBD>(blk - half * (kSNT / 2)) << (16 * half);
-}
-
-#if VGG_SUPER_TRACE
-__device__ long long g_super_trace[1024 * 8 * 8];   // [chunk][wave][sI, sJ, batches, cycles, load wait, barrier wait, pre-MFMA, MFMA phase]
-#endif
-// LDS-DMA: 16 bytes per active lane from `src` (per lane) to LDS byte address lds_dst + 16 * lane (wave-uniform base in
-// M0).  Not counted by the compiler: completion is awaited with explicit s_waitcnt vmcnt(N) (one count per statement).
-__device__ __forceinline__ void glds16(const void* src, uint32_t lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
-}
-
-// One workgroup with one resident batch in flight (register staging, as schur_tile_kernel does with 3-4 workgroups per CU)
-// ran at 1.6 TB/s: 37 KB per ~5.9 us per CU, a load latency per batch.  So the operands go straight to LDS (no staging
-// registers, no ds_write pass) into a ring of four batch images: while batch b is multiplied the loads of b+1, b+2, b+3
-// are in flight (110 KB per CU), one barrier per batch.  Every wavefront stages whole segments (two, diagonal tile: one;
-// 3 LDS-DMA statements of 1024 + 1024 + 256 bytes each), so its segment indices are wave-uniform scalar loads and the
-// loop holds no compiler-counted vector load: `s_waitcnt vmcnt(2 K)` at the top of iteration b (K statements per batch)
-// means exactly "my pieces of batch b have landed", the barrier makes it everybody's, and the ring slot that batch b-1
-// used is refilled right behind it.
-template <bool DIAG>
-__device__ __forceinline__ void super_tile_body(const Ws& w, double* __restrict__ ops, const int32_t* __restrict__ cd,
-                                                const int32_t* __restrict__ entries, const uint32_t* __restrict__ quad_mask,
-                                                int zero_seg, int chunk) {
-  constexpr int SEG = kSSeg, R = kSR, NS = DIAG ? 2 : 4;
-  constexpr int SPW = 4 * NS / 8;                 // segments staged by one wavefront per batch: 2 (1)
-  constexpr int K = 3 * SPW;                      // LDS-DMA statements per wavefront per batch
-  constexpr int BUF = 4 * NS * SEG;               // doubles per ring slot
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int e0 = cd[2], e1 = cd[3], cj = cd[4], cJ = cd[5], q0 = cd[6];
-  constexpr int BPS = kSub / 4;
-  const int nsub = (e1 - e0 + kSub - 1) / kSub;
-  const int nb = ((nsub - cj + cJ - 1) / cJ) * BPS;
-  auto ebase = [&](int b) -> int { return e0 + ((b / BPS) * cJ + cj) * kSub + (b % BPS) * 4; };
-  // staging: slots wave * SPW + h of the batch image = (entry my_e, segments my_w + h)
-  const int my_e = (wave * SPW) / NS, my_w = (wave * SPW) % NS;
-  // Segment indices and quad masks come from an INDEX RING in LDS, filled by LDS-DMA two sub-chunks (16 batches) ahead
-  // by wavefront 0: scalar loads in the loop cost a scalar-cache miss per batch with nothing to hide it behind (their
-  // counter is shared with the LDS reads, and out of order), ~1000 cycles of every batch.  Slot s & 3 holds sub-chunk s of
-  // this workgroup: kSub entries, then kSub / 4 quad masks.  (The host pads both arrays by one sub-chunk.)
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)ops;
-  const char* idx_ring = reinterpret_cast<const char*>(ops) + kSOpsBytes;
-  auto issue_index = [&](int sc) __attribute__((always_inline)) {      // sub-chunk sc of this workgroup (wavefront 0 only)
-    const size_t first = (size_t)e0 + (size_t)(sc * cJ + cj) * kSub;   // entry; quad = q0 + (first - e0) / 4
-    const uint32_t dst = lds0 + (uint32_t)(kSOpsBytes + (sc & (kSIdxRing - 1)) * kSIdxSlot);
-    if (lane < kSub) glds16(reinterpret_cast<const char*>(entries) + (first + lane) * 16, dst);
-    if (lane < kSub / 8) glds16(reinterpret_cast<const char*>(quad_mask) + ((size_t)q0 + (first - e0) / 4) * 8 + lane * 16, dst + kSub * 16);
-  };
-  // (vector registers; made scalar with readfirstlane by the consumer one iteration later)
-  auto fetch_seg = [&](int b, int h) -> int {
-    const int* sl = reinterpret_cast<const int*>(idx_ring + ((b / BPS) & (kSIdxRing - 1)) * kSIdxSlot);
-    return sl[4 * ((b % BPS) * 4 + my_e) + my_w + h];
-  };
-  auto seg_valid = [&](int b) -> bool { return b < nb && ebase(b) + my_e < e1; };
-  auto fetch_mask = [&](int b, int side) -> uint32_t {
-    const uint32_t* sl = reinterpret_cast<const uint32_t*>(idx_ring + ((b / BPS) & (kSIdxRing - 1)) * kSIdxSlot + kSub * 16);
-    return sl[2 * (b % BPS) + side];
-  };
-  // the LDS image of a segment is linear except that the odd entries are XOR-swizzled by 8 double2 (see schur_tile_kernel);
-  // the DMA writes lane-linear, so the swizzle goes on the SOURCE
-  const int sx = (my_e & 1) * 8;
-  const uint32_t so0 = (uint32_t)((lane ^ sx) * 16), so1 = (uint32_t)(((64 + lane) ^ sx) * 16),
-                 so2 = (uint32_t)(((128 + (lane & 15)) ^ sx) * 16);
-  const char* ybase = reinterpret_cast<const char*>(w.Y);
-  // piece p (0 .. K-1) of a batch: part p % 3 (1024 + 1024 + 256 bytes) of this wavefront's segment p / 3
-  auto issue_piece = [&](int slot, const int (&sg)[SPW], int p) __attribute__((always_inline)) {
-#if VGG_SABLATE == 2
-    return;
-#endif
-    const int h = p / 3, part = p % 3;
-    const char* src = ybase + (size_t)sg[h] * (SEG * 8);
-    const uint32_t dst = lds0 + (uint32_t)(slot * BUF + (wave * SPW + h) * SEG) * 8u;
-    if (part == 0) glds16(src + so0, dst);
-    else if (part == 1) glds16(src + so1, dst + 1024u);
-    else if (lane < 16) glds16(src + so2, dst + 2048u);
-  };
-  auto issue = [&](int slot, const int (&sg)[SPW]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int p = 0; p < K; ++p) issue_piece(slot, sg, p);
-  };
-  const int li = lane & 15, lk = lane >> 4;
-  const int swz = (lk & 1) * 16;
-  // operand address of 16-row block blk (0..11) of side s for this lane (component ks adds ks * R)
-  auto block_off = [&](int s, int blk) -> int {
-    const int b = min(blk, kSNT - 1), half = b / (kSNT / 2);
-    return (lk * NS + (DIAG ? 0 : 2 * s) + half) * SEG + ((16 * (b - half * (kSNT / 2)) + li) ^ swz);
-  };
-  double* part = w.tile_part + (size_t)chunk * kSR2 * kSR2;
-  auto store_subtile = [&](int rb, int cb, const f64x4_t& v) {
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) part[(size_t)(16 * rb + lk + 4 * reg) * kSR2 + 16 * cb + li] = v[reg];
-  };
-
-#if VGG_SUPER_TRACE
-  long long t_load = 0, t_bar = 0, t_pre = 0, t_mfma = 0;
-  const long long t_begin = __builtin_readcyclecounter(), t_wall0 = (long long)wall_clock64();
-#endif
-  // prologue: index slots of sub-chunks 0 and 1, then the operand images of batches 0, 1, 2
-  if (wave == 0) { issue_index(0); issue_index(1); }
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-  int sg_next[SPW];
-#pragma unroll
-  for (int pb = 0; pb < kSRing - 1; ++pb) {
-#pragma unroll
-    for (int h = 0; h < SPW; ++h) sg_next[h] = seg_valid(pb) ? __builtin_amdgcn_readfirstlane(fetch_seg(pb, h)) : zero_seg;
-    issue(pb, sg_next);
-  }
-  int sgv[SPW];                                   // raw fetches for the batch staged NEXT iteration
-#pragma unroll
-  for (int h = 0; h < SPW; ++h) sgv[h] = fetch_seg(kSRing - 1, h);
-  uint32_t qav = fetch_mask(0, 0), qbv = fetch_mask(0, 1);
-  auto sweep = [&](auto&& mfma_batch) __attribute__((always_inline)) {
-    for (int b = 0; b < nb; ++b) {
-#if VGG_SUPER_TRACE
-      const long long tw0 = __builtin_readcyclecounter();
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * K) : "memory");
-      const long long tw1 = __builtin_readcyclecounter();
-      asm volatile("s_barrier" ::: "memory");
-      const long long tw2 = __builtin_readcyclecounter();
-      t_load += tw1 - tw0; t_bar += tw2 - tw1;
-#else
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * K) : "memory");
-#endif
-      // batch b + 3 goes into the slot batch b - 1 has just left -- piece by piece between the MFMAs (the workgroup is alone
-      // on its CU and in lockstep: a burst of K LDS-DMA statements per wavefront up front would idle the matrix pipes)
-      const int refill = (b + kSRing - 1) & (kSRing - 1);
-#pragma unroll
-      for (int h = 0; h < SPW; ++h) sg_next[h] = seg_valid(b + kSRing - 1) ? __builtin_amdgcn_readfirstlane(sgv[h]) : zero_seg;
-      const uint32_t qa = (uint32_t)__builtin_amdgcn_readfirstlane((int)qav), qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qbv);
-      // (index slot of sub-chunk b / 8 + 2: its predecessor in that slot, sub-chunk b / 8 - 2, was last read 5 batches ago)
-      if (wave == 0 && (b % BPS) == 0 && b / BPS + 2 < nb / BPS) issue_index(b / BPS + 2);
-      // next iteration's indices and masks: read now, consumed (readfirstlane) after the matrix instructions below
-#pragma unroll
-      for (int h = 0; h < SPW; ++h) sgv[h] = fetch_seg(b + kSRing, h);
-      qav = fetch_mask(b + 1, 0); qbv = fetch_mask(b + 1, 1);
-#if VGG_SUPER_TRACE
-      const long long tw3 = __builtin_readcyclecounter();
-#endif
-      mfma_batch(ops + (size_t)(b & (kSRing - 1)) * BUF, qa, qb, [&](int p) __attribute__((always_inline)) { issue_piece(refill, sg_next, p); });
-#if VGG_SUPER_TRACE
-      const long long tw4 = __builtin_readcyclecounter();
-      t_pre += tw3 - tw2; t_mfma += tw4 - tw3;
-#endif
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // nothing may land in LDS after this workgroup has gone
-#if VGG_SUPER_TRACE
-    if (lane == 0 && chunk < 1024) {
-      long long* tr = g_super_trace + ((size_t)chunk * 8 + wave) * 8;
-      tr[0] = cd[0]; tr[1] = cd[1]; tr[2] = nb; tr[3] = (long long)__builtin_readcyclecounter() - t_begin; tr[4] = t_load; tr[5] = t_bar;
-      tr[6] = t_pre; tr[7] = t_mfma;
-    }
-#endif
-  };
-  if constexpr (!DIAG) {
-    // Sub-tile (r, c) belongs to SIMD (r + c) % 4 -- diagonal stripes: whatever rectangle of blocks a quad has cameras in,
-    // the four matrix pipes get a quarter of it (+-1); a column-strided grid left the pipe of the fullest column class
-    // with ceil(L / 4) of L columns.  The two wavefronts of a SIMD split its stripes by row parity: wave = 4 rpar + simd
-    // owns rows r = rpar + 2 i (i < 6) and, in row i, the columns c = cc[i & 1] + 4 j (j < 3), cc = {cA, cA ^ 2},
-    // cA = (simd - rpar) & 3.
-    constexpr int NI = kSNT / 2, NJ = kSNT / 4;
-    const int simd = wave & 3, rpar = wave >> 2;
-    const int cc[2] = {(simd - rpar) & 3, ((simd - rpar) & 3) ^ 2};
-    int offA[NI], offB[2][NJ];
-    uint32_t bitsA[NI], bitsB[2][NJ];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) { offA[i] = block_off(0, rpar + 2 * i); bitsA[i] = super_block_bits(rpar + 2 * i); }
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) { offB[q][j] = block_off(1, cc[q] + 4 * j); bitsB[q][j] = super_block_bits(cc[q] + 4 * j); }
-    f64x4_t acc[NI][NJ];
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) acc[i][j] = (f64x4_t){0.0, 0.0, 0.0, 0.0};
-    sweep([&](const double* Os, uint32_t ma, uint32_t mb, auto&& piece) __attribute__((always_inline)) {
-      // one scalar bit per sub-tile of this wavefront (bit 3 i + j): every skip test below is a bit test + branch (with
-      // the conditions kept as booleans the compiler built each one from 64-bit lane masks, ~6 dependent scalar
-      // instructions per test, 54 tests per batch -- more time than the matrix instructions they guarded)
-      uint32_t colm[2] = {0u, 0u}, on = 0u;
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) colm[q] |= ((mb & bitsB[q][j]) != 0 ? 1u : 0u) << j;
-#pragma unroll
-      for (int i = 0; i < NI; ++i) on |= ((ma & bitsA[i]) != 0 ? colm[i & 1] : 0u) << (NJ * i);
-      on = (uint32_t)__builtin_amdgcn_readfirstlane((int)on);
-#if VGG_SABLATE == 1
-      on = 0u;
-#endif
-      // sub-tile-major: one test per sub-tile and batch, its three K steps back to back (the other wavefront of the SIMD
-      // fills the gaps of the dependent chain); column operands of the batch up front, row operands one row ahead
-      double bq[3][2][NJ], a[2][3];
-#pragma unroll
-      for (int ks = 0; ks < 3; ++ks)
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) bq[ks][q][j] = Os[offB[q][j] + ks * R];
-#pragma unroll
-      for (int ks = 0; ks < 3; ++ks) a[0][ks] = Os[offA[0] + ks * R];
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        if (i + 1 < NI) {
-#pragma unroll
-          for (int ks = 0; ks < 3; ++ks) a[(i + 1) & 1][ks] = Os[offA[i + 1] + ks * R];
-        }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          if (VGG_NO_SKIP || ((on >> (NJ * i + j)) & 1u)) {
-#pragma unroll
-            for (int ks = 0; ks < 3; ++ks)
-              acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i & 1][ks], bq[ks][i & 1][j], acc[i][j], 0, 0, 0);
-          }
-        if (i < K) piece(i);
-      }
-    });
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) store_subtile(rpar + 2 * i, cc[i & 1] + 4 * j, acc[i][j]);
-  } else {
-    // lower triangle of the 12 x 12 sub-tiles (78), dealt round-robin to the 8 wavefronts (consecutive sub-tiles of a row
-    // on different SIMDs)
-    constexpr int NL = kSNT * (kSNT + 1) / 2, PER = (NL + 7) / 8;
-    const int nmine = __builtin_amdgcn_readfirstlane((NL - wave + 7) / 8);
-    int rbs[PER], cbs[PER], offA[PER], offB[PER];
-    uint32_t bitsR[PER], bitsC[PER];
-    {
-      int rb = 0, cb = 0;
-      for (int t = 0; t < wave; ++t) { if (cb == rb) { ++rb; cb = 0; } else ++cb; }
-#pragma unroll
-      for (int t = 0; t < PER; ++t) {
-        rbs[t] = min(rb, kSNT - 1); cbs[t] = min(cb, kSNT - 1);
-        offA[t] = block_off(0, rbs[t]); offB[t] = block_off(0, cbs[t]);
-        bitsR[t] = (t < nmine) ? super_block_bits(rbs[t]) : 0u;
-        bitsC[t] = (t < nmine) ? super_block_bits(cbs[t]) : 0u;
-        for (int u = 0; u < 8; ++u) { if (cb == rb) { ++rb; cb = 0; } else ++cb; }
-      }
-    }
-    f64x4_t acc[PER];
-#pragma unroll
-    for (int t = 0; t < PER; ++t) acc[t] = (f64x4_t){0.0, 0.0, 0.0, 0.0};
-    sweep([&](const double* Os, uint32_t ma, uint32_t, auto&& piece) __attribute__((always_inline)) {
-      uint32_t on = 0u;
-#pragma unroll
-      for (int t = 0; t < PER; ++t) on |= (((ma & bitsR[t]) != 0 && (ma & bitsC[t]) != 0) ? 1u : 0u) << t;
-      on = (uint32_t)__builtin_amdgcn_readfirstlane((int)on);
-#if VGG_SABLATE == 1
-      on = 0u;
-#endif
-      double a[2][3], bq[2][3];                   // operands of sub-tile t in set t & 1, fetched one sub-tile ahead
-#pragma unroll
-      for (int ks = 0; ks < 3; ++ks) { a[0][ks] = Os[offA[0] + ks * R]; bq[0][ks] = Os[offB[0] + ks * R]; }
-#pragma unroll
-      for (int t = 0; t < PER; ++t) {
-        if (t + 1 < PER) {
-#pragma unroll
-          for (int ks = 0; ks < 3; ++ks) { a[(t + 1) & 1][ks] = Os[offA[t + 1] + ks * R]; bq[(t + 1) & 1][ks] = Os[offB[t + 1] + ks * R]; }
-        }
-        if (VGG_NO_SKIP ? (t < nmine) : ((on >> t) & 1u)) {
-#pragma unroll
-          for (int ks = 0; ks < 3; ++ks) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t & 1][ks], bq[t & 1][ks], acc[t], 0, 0, 0);
-        }
-        if (t % 3 == 1 && t / 3 < K) piece(t / 3);
-      }
-    });
-#pragma unroll
-    for (int t = 0; t < PER; ++t)
-      if (t < nmine) store_subtile(rbs[t], cbs[t], acc[t]);
-  }
-}
-
-__global__ __launch_bounds__(512, 1) void super_tile_kernel(Ws w, const int32_t* __restrict__ chunk_desc, const int32_t* __restrict__ entries,
-                                                            const uint32_t* __restrict__ quad_mask, int zero_seg) {
-  extern __shared__ __attribute__((aligned(16))) double super_ops[];
-  if (w.ctl->done) return;
-  const int chunk = blockIdx.x;
-  const int32_t* cd = chunk_desc + 8 * (size_t)chunk;
-  if (cd[0] == cd[1]) super_tile_body<true>(w, super_ops, cd, entries, quad_mask, zero_seg, chunk);
-  else super_tile_body<false>(w, super_ops, cd, entries, quad_mask, zero_seg, chunk);
-}
-
-// S blocks of the super-tiles: like tile_reduce_kernel with 32 cameras per side.  grid = (192 * 192 / 256, num_tiles)
-__global__ __launch_bounds__(256) void super_reduce_kernel(Ws w, int n_red, int C, const int32_t* __restrict__ tile_desc,
-                                                           double* __restrict__ dst) {
-  constexpr int R2 = kSR2, BD = kSBD;
-  if (w.ctl->done) return;
-  const int tile = blockIdx.y;
-  const int sI = tile_desc[4 * tile], sJ = tile_desc[4 * tile + 1];
-  const int c0 = tile_desc[4 * tile + 2], c1 = tile_desc[4 * tile + 3];
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= R2 * R2) return;
-  const int row = e / R2, col = e - row * R2;
-  const int a = row / BD, i = row - a * BD, b = col / BD, j = col - b * BD;
-  const int ca = sI * 2 * kGroup + a, cb = sJ * 2 * kGroup + b;
-  if (ca >= C || cb >= C) return;
-  if (sI == sJ && col > row) return;
-  const int ri = 6 * ca + i, cj = 6 * cb + j;
-  double s0 = 0.0, s1 = 0.0;
-  int ch = c0;
-  for (; ch + 1 < c1; ch += 2) { s0 += w.tile_part[(size_t)ch * R2 * R2 + e]; s1 += w.tile_part[(size_t)(ch + 1) * R2 * R2 + e]; }
-  if (ch < c1) s0 += w.tile_part[(size_t)ch * R2 * R2 + e];
-  const int hi = ri > cj ? ri : cj, lo = ri > cj ? cj : ri;
-  dst[(size_t)hi * n_red + lo] = -(s0 + s1);
 }
 
 // diagonal blocks, camera/intrinsics coupling, damping, right-hand side.  One workgroup (64) per camera,
@@ -1907,10 +1515,7 @@ struct Launch {
   Dims d; DevProblem dp; Ws w; vgg_ba_options opt; hipStream_t st; int wgB;
   int lpp;                                      // lanes per point of the point passes: 16, 32 or 64 (lanes_per_point)
   const int32_t* chunk_desc; const int32_t* entries; int num_chunks, num_segments;
-  const int32_t* block_chunk;                   // launch position -> chunk (XCD placement) or NULL
-  const int32_t* tile_sched;                    // batch schedule of the tile chunks (vgg_ba_problem.tile_sched) or NULL
   int merged_tile_launch;
-  int super_tiles; const int32_t* quad_mask;    // 2 x 2 super-tiles (vgg_ba_problem.super_tiles)
   const int32_t* tile_desc; int num_tiles;
   const int32_t* batches; int num_batches;      // HOST table [num_batches][6], see vgg_ba_problem.tile_batches
   int chol_split_a, chol_split_b;               // block-diagonal leading part of the reduced system (0 = none)
@@ -1955,31 +1560,16 @@ template <int BD>
 static void launch_schur_batch(const Launch& L, int batch, hipStream_t st, double* dst) {
   const int32_t* B = L.batches + 6 * batch;
   const int c0 = B[0], cm = B[1], c1 = B[2], t0 = B[3], t1 = B[4];
-  if (L.super_tiles) {
-    if constexpr (BD == kSBD) {
-      static bool attr_set = false;
-      if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(super_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kSuperLds);
-        attr_set = true;
-      }
-      if (c1 > c0) {
-        ProfScope ps(kProfSchurTile, st);
-        super_tile_kernel<<<c1 - c0, 512, kSuperLds, st>>>(L.w, L.chunk_desc, L.entries, reinterpret_cast<const uint32_t*>(L.quad_mask), L.num_segments);
-      }
-      if (t1 > t0) super_reduce_kernel<<<dim3(div_up(kSR2 * kSR2, 256), t1 - t0), 256, 0, st>>>(L.w, L.d.n_red, L.d.C, L.tile_desc, dst);
-    }
-    return;
-  }
-  if ((g_tile_merged || L.merged_tile_launch) && c1 > c0) {
+  if (L.merged_tile_launch && c1 > c0) {
     ProfScope ps(kProfSchurTile, st);
-    schur_tile_merged_kernel<BD><<<c1 - c0, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, c0, L.num_segments, L.block_chunk, L.tile_sched);
+    schur_tile_merged_kernel<BD><<<c1 - c0, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, c0, L.num_segments);
   } else if (cm > c0) {
     ProfScope ps(kProfSchurTile, st);
-    schur_tile_kernel<BD, false><<<cm - c0, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, c0, L.num_segments, L.block_chunk, L.tile_sched);
+    schur_tile_kernel<BD, false><<<cm - c0, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, c0, L.num_segments);
   }
-  if (!(g_tile_merged || L.merged_tile_launch) && c1 > cm) {
+  if (!L.merged_tile_launch && c1 > cm) {
     ProfScope ps(kProfSchurTileDiag, st);
-    schur_tile_kernel<BD, true><<<c1 - cm, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, cm, L.num_segments, L.block_chunk, L.tile_sched);
+    schur_tile_kernel<BD, true><<<c1 - cm, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, cm, L.num_segments);
   }
   if (t1 > t0)
     tile_reduce_kernel<BD><<<dim3(div_up(kGroup * BD * kGroup * BD, 256), t1 - t0), 256, 0, st>>>(L.w, L.d.n_red, L.d.C, L.d.kd,
@@ -2041,11 +1631,7 @@ static void phase_schur(const Launch& L) {
     ProfScope ps(kProfPointPass, L.st);
     // cameras (q, t, pose scales, constant flags: 14 doubles each) cached in LDS when they fit beside 2 workgroups/CU
     const size_t cam_lds = sizeof(double) * 19 * (size_t)d.C;
-    if (L.dp.obs_pt && !g_fused_point_pass && L.lpp == 64) {
-      if (cam_lds <= 64 * 1024) point_pass_kernel<KD, true, false, 64><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w, L.opt);
-      else point_pass_kernel<KD, false, false, 64><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w, L.opt);
-      y_write_kernel<KD><<<min(div_up(L.d.O, 256), 256 * 16), 256, 0, L.st>>>(L.dp, L.w);
-    } else {
+    {
       auto launch = [&](auto lpp) {
         constexpr int LPP = decltype(lpp)::value;
         const bool longt = long_tracks(LPP, L.d.P, L.d.O);
@@ -2153,18 +1739,14 @@ static int make_launch(const vgg_ba_problem* pb, const vgg_ba_options* opt, void
   if (pb->camera_model != kPinhole && pb->camera_model != kSimpleRadial) return VGG_ERR_UNSUPPORTED;
   L->d = make_dims(pb);
   L->dp = dev_problem(pb, L->d);
-  L->w = carve(L->d, opt->max_num_iterations, pb->num_chunks, pb->num_segments, workspace, pb->super_tiles);
+  L->w = carve(L->d, opt->max_num_iterations, pb->num_chunks, pb->num_segments, workspace);
   L->opt = *opt;
   L->st = st;
   L->lpp = lanes_per_point(L->d.P, L->d.O);
   // (c3: 512 or 1024 workgroups 2.18 ms per iteration, 2048: 2.21 -- every workgroup fills its LDS camera cache first)
   L->wgB = min(max(div_up(L->d.P, 4 * (64 / L->lpp)), 1), g_tuning.point_wgs > 0 ? min(g_tuning.point_wgs, kMaxWG) : 1024);
   L->chunk_desc = pb->chunk_desc; L->entries = pb->entries; L->num_chunks = pb->num_chunks;
-  L->block_chunk = pb->block_chunk;
-  L->tile_sched = pb->tile_sched;
   L->merged_tile_launch = pb->merged_tile_launch;
-  L->super_tiles = pb->super_tiles; L->quad_mask = pb->quad_mask;
-  if (pb->super_tiles && (!pb->quad_mask || pb->num_tile_batches != 1 || !(L->d.shared || L->d.kd == 0))) return VGG_ERR_INVALID_ARGUMENT;
   L->num_segments = pb->num_segments;
   L->batches = pb->tile_batches; L->num_batches = pb->num_tile_batches;
   L->chol_split_a = pb->chol_split_a; L->chol_split_b = pb->chol_split_b;
@@ -2278,12 +1860,21 @@ int vgg_ba_profile_read(int kernel_id, double* total_ms, int* launches, int rese
 }
 
 const char* vgg_build_arch(void) { return "gfx950"; }
-int vgg_abi_version(void) { return 1; }
+int vgg_abi_version(void) { return VGG_ABI_VERSION; }
+size_t vgg_abi_sizeof(int which) {
+  switch (which) {
+    case 0: return sizeof(vgg_ba_problem);
+    case 1: return sizeof(vgg_ba_options);
+    case 2: return sizeof(vgg_ba_iteration);
+    case 3: return sizeof(vgg_ba_summary);
+    default: return 0;
+  }
+}
 
 size_t vgg_ba_workspace_bytes(const vgg_ba_problem* problem, const vgg_ba_options* options) {
   if (!problem || !options) return 0;
   const Dims d = make_dims(problem);
-  return carve(d, options->max_num_iterations, problem->num_chunks, problem->num_segments, nullptr, problem->super_tiles).total_bytes + 256;
+  return carve(d, options->max_num_iterations, problem->num_chunks, problem->num_segments, nullptr).total_bytes + 256;
 }
 
 int vgg_ba_begin(const vgg_ba_problem* problem, const vgg_ba_options* options, void* workspace, size_t workspace_bytes,
@@ -2312,7 +1903,7 @@ int vgg_ba_reduce_buffer(const vgg_ba_problem* problem, const vgg_ba_options* op
                          double** device_ptr, size_t* count) {
   if (!problem || !options || !workspace || !device_ptr || !count) return VGG_ERR_INVALID_ARGUMENT;
   const Dims d = make_dims(problem);
-  Ws w = carve(d, options->max_num_iterations, problem->num_chunks, problem->num_segments, workspace, problem->super_tiles);
+  Ws w = carve(d, options->max_num_iterations, problem->num_chunks, problem->num_segments, workspace);
   switch (which) {
     case 0: *device_ptr = w.lin; *count = w.lin_count; break;
     case 1: *device_ptr = w.sys; *count = w.sys_count; break;
@@ -2374,9 +1965,3 @@ int vgg_ba_solve(const vgg_ba_problem* problem, const vgg_ba_options* options, v
 }
 
 }  // extern "C"
-
-#if VGG_SUPER_TRACE
-extern "C" int vgg_debug_read_super_trace(long long* host, size_t count) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vgg::g_super_trace), sizeof(long long) * count);
-}
-#endif

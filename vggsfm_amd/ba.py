@@ -327,6 +327,7 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
             batch_desc.contiguous())
 
 
+TILE_WGS_PER_CU = (3, 4)           # resident schur_tile workgroups per CU with 6 x 6 blocks: (off-diagonal, diagonal) launch
 SPARSE_GRID_DENSITY = 0.05        # compile_problem: below this fill of the (frames x tracks) grid work on the observation list
 MERGED_TILE_MAX_OBS = 1_000_000   # below: off-diagonal and diagonal tiles share one launch
 CAMERA_SPLIT_MIN_STEPS = 2    # shared 64-column factorisation steps below which re-ordering the cameras is not worth it
@@ -573,7 +574,7 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
     cus = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == "cuda" else 256
     # resident schur_tile workgroups per CU (occupancy of the kernel variant): off-diagonal launch 3 (BD = 6) or 2,
     # diagonal launch 4 or 2 -- one full round each
-    slots = (cus * 3, cus * 4) if shared_camera else (cus * 2, cus * 2)
+    slots = (cus * TILE_WGS_PER_CU[0], cus * TILE_WGS_PER_CU[1]) if shared_camera else (cus * 2, cus * 2)
     # three batches when the factorisation can overlap the later ones (enough camera groups, enough work per batch)
     overlap = OVERLAP_FACTORIZATION if overlap is None else bool(overlap)
     nb = TILE_BATCHES if (overlap and int(obs_cam.shape[0]) >= OVERLAP_MIN_OBS and S >= OVERLAP_MIN_FRAMES) else 1

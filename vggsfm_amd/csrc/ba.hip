@@ -79,6 +79,16 @@ struct Dims {
   double loss_scale;
 };
 
+// Doubles per slot (one observation) of the segment buffer Y.
+// 6 x 6 camera blocks (shared or constant intrinsics): COMPRESSED -- the 6 x 3 Schur factor of an observation is
+//   Y_i = s_c o (F_i^T E_i G_p) = s_c o [ [2 a]x ; I ] N_i,   N_i = Jw^T (E_i G_p) (3 x 3),  a = R_c X_p,
+// because the pose Jacobian factors as F = Jw [ -2 [a]x | I ] (J_delta = -2 J_Y [R X]x, J_t = J_Y; the
+// loss corrector multiplies from the left).  The slot holds N (row-major, 9) and 2 a (3): 96 bytes instead of 144; the tile
+// kernel rebuilds the six rows while it stages the segment, the Jacobi scales s_c and the constant-parameter masks are
+// applied to the finished tile sums (tile_reduce_kernel).  Larger blocks (per-camera intrinsics) keep the full factor.
+constexpr int kYc = 12;
+static inline size_t y_slot_doubles(const Dims& d) { return (d.shared || d.kd == 0) ? (size_t)kYc : (size_t)d.BDp * 3; }
+
 struct Ws {  // device workspace carve-up (pointers into the caller's buffer)
   Ctl* ctl;
   vgg_ba_iteration* log;
@@ -109,6 +119,7 @@ struct Ws {  // device workspace carve-up (pointers into the caller's buffer)
 };
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
 
 static Dims make_dims(const vgg_ba_problem* pb) {
   Dims d;
@@ -155,7 +166,7 @@ static Ws carve(const Dims& d, int max_iters, int num_chunks, int num_segments, 
   w.cam_part = (double*)take(8ull * (d.C + 1) * 2);
   w.cam_split = (double*)take(8ull * (size_t)d.C * kCamSplitMax * kCamNV);
   // + one all-zero segment behind the last real one (target of the tile kernel's loads past the end of a list)
-  w.y_bytes = 8ull * ((size_t)(num_segments > 0 ? num_segments : 0) + 1) * kGroup * (d.shared ? 6 : d.BDp) * 3;
+  w.y_bytes = 8ull * ((size_t)(num_segments > 0 ? num_segments : 0) + 1) * kGroup * y_slot_doubles(d);
   w.Y = (double*)take(w.y_bytes);
   w.chol_inv = (double*)take(cholesky_workspace_bytes(d.n_red));
   {
@@ -229,7 +240,7 @@ struct CamR {                                    // rotation matrix of a quatern
 template <int KD>
 __device__ __forceinline__ double eval_full(const Dims& d, const double* Rm, const double* t, const double* in4,
                                             const double* X, float2 uv, unsigned camflag, bool intr_c, bool pt_c,
-                                            double* r, double* F, double* E) {
+                                            double* r, double* F, double* E, double* Jw = nullptr) {
   constexpr int BD = 6 + KD;
   double Jp[12], Ji[4];
   obs_eval_R(d.model, Rm, t, in4, X, (double)uv.x, (double)uv.y, r, Jp, Ji, E);
@@ -248,6 +259,11 @@ __device__ __forceinline__ double eval_full(const Dims& d, const double* Rm, con
     c.jac<BD>(r, F);
     c.jac<3>(r, E);
     r[0] *= c.residual_scaling; r[1] *= c.residual_scaling;
+  }
+  // Jw = corrected d r / d (R X + t) (2 x 3) BEFORE the constant-parameter masks: the translation columns of F
+  if (Jw) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { Jw[k] = F[3 + k]; Jw[3 + k] = F[BD + 3 + k]; }
   }
   if (camflag) {
 #pragma unroll
@@ -580,10 +596,10 @@ static bool long_tracks(int lpp, int P, int O) {
 // instructions of a point at 50 observations) is shared by 2 / 4 points, and a 12-observation track fills 12 of 16 lanes
 // instead of 12 of 64).  The lanes of a point reduce among themselves (xor offsets < LPP); observations beyond the first
 // LPP of a track are re-evaluated in the Y sweep.
-// WRITE_Y = false: the per-observation Schur factors are left to y_write_kernel (thread per observation); this kernel
-// then needs neither the cached Jacobians nor the slot prefetch and fits three wavefronts per SIMD.
-template <int KD, bool LDSCAM, bool WRITE_Y, int LPP, bool LONGT = false>
-__global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void point_pass_kernel(DevProblem pb, Ws w, vgg_ba_options opt) {
+// CY: the tile blocks are 6 x 6 (shared or constant intrinsics) and the segment buffer holds the COMPRESSED factors
+// (kYc doubles per observation: N and 2 a, see y_slot_doubles); otherwise the full BD x 3 factor.
+template <int KD, bool LDSCAM, bool CY, int LPP, bool LONGT = false>
+__global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem pb, Ws w, vgg_ba_options opt) {
   constexpr int BD = 6 + KD;
   __shared__ double wmax[4];
   extern __shared__ double cam_cache[];          // LDSCAM: R[9C] t[3C] pose scales[6C] flags[C] (as doubles)
@@ -636,7 +652,7 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
     n_o0 = pb.row_ptr[p]; n_o1 = pb.row_ptr[p + 1];
     n_X0 = pb.pts[3 * p]; n_X1 = pb.pts[3 * p + 1]; n_X2 = pb.pts[3 * p + 2];
     n_ptc = pb.pt_const ? pb.pt_const[p] != 0 : false;
-    n_pf.template load<WRITE_Y>(pb.obs_cam, pb.obs_uv, pb.obs_slot, n_o0, n_o1, LPP, sl);
+    n_pf.template load<true>(pb.obs_cam, pb.obs_uv, pb.obs_slot, n_o0, n_o1, LPP, sl);
     if (p + nw < d.P) {
       const int pm = p + nw;
       m_o0 = pb.row_ptr[pm]; m_o1 = pb.row_ptr[pm + 1];
@@ -652,7 +668,7 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
     {
       // stage 1 -> current of the next iteration: observations of point p + nw (its bounds arrived an iteration ago)
       n_o0 = m_o0; n_o1 = m_o1; n_X0 = m_X0; n_X1 = m_X1; n_X2 = m_X2; n_ptc = m_ptc;
-      if (p + nw < d.P) n_pf.template load<WRITE_Y>(pb.obs_cam, pb.obs_uv, pb.obs_slot, n_o0, n_o1, LPP, sl);
+      if (p + nw < d.P) n_pf.template load<true>(pb.obs_cam, pb.obs_uv, pb.obs_slot, n_o0, n_o1, LPP, sl);
       // stage 2: bounds / coordinates of point p + 2 nw
       const int pm = p + 2 * nw;
       if (pm < d.P) {
@@ -664,22 +680,25 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
     double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0}, Wa[3 * (KD ? KD : 1)];
 #pragma unroll
     for (int i = 0; i < 3 * (KD ? KD : 1); ++i) Wa[i] = 0;
-    double cF[2 * BD], cE[6];          // Jacobians of this lane's first observation (tracks > LPP recompute)
+    // Jacobians of this lane's first observation for the Y sweep (tracks > LPP recompute): F and E, or -- compressed
+    // factors -- the 2 x 3 d r / d (R X + t) instead of F
+    double cF[CY ? 6 : 2 * BD], cE[6];
     for (int o = o0 + sl; o < o1; o += LPP) {
       const int pass = (o - o0) / LPP; const bool head = pass == 0;
       const int c = f_pf.cam(pass, pb.obs_cam, o);
       const float2 uv = f_pf.uv(pass, pb.obs_uv, o);
       const int a = d.shared ? 0 : c;
-      double r[2], F[2 * BD], E[6];
+      double r[2], F[2 * BD], E[6], Jw[6];
       if (LDSCAM)
         eval_full<KD>(d, lq + 9 * c, lt + 3 * c, pb.intr + 4 * a, X, uv, (unsigned)lfl[c],
-                      pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
+                      pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E, CY ? Jw : nullptr);
       else
         eval_full<KD>(d, CamR(pb.cam_q + 4 * c).R, pb.cam_t + 3 * c, pb.intr + 4 * a, X, uv,
-                      pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
-      if (WRITE_Y && CACHEJ && head) {
+                      pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E,
+                      CY ? Jw : nullptr);
+      if (CACHEJ && head) {
 #pragma unroll
-        for (int i = 0; i < 2 * BD; ++i) cF[i] = F[i];
+        for (int i = 0; i < (CY ? 6 : 2 * BD); ++i) cF[i] = CY ? Jw[i] : F[i];
 #pragma unroll
         for (int i = 0; i < 6; ++i) cE[i] = E[i];
       }
@@ -757,34 +776,62 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
     }
     // per-observation Schur factors Y_i = s_c o ((F_i^T E_i) G) -> slot obs_slot[o] of the zero-padded
     // segment buffer consumed by schur_tile_kernel
-    if (WRITE_Y && VGG_PP_ABLATE != 2) {
+    if (VGG_PP_ABLATE != 2) {
       const int bdt = d.shared ? 6 : BD;          // rows of the tile block (intrinsics only when per camera)
       for (int o = o0 + sl; o < o1; o += LPP) {
         const int pass = (o - o0) / LPP; const bool head = pass == 0;
         const int c = f_pf.cam(pass, pb.obs_cam, o);
-        double F[2 * BD], E[6];
+        double F[CY ? 6 : 2 * BD], E[6];          // (CY: F holds the 2 x 3 Jw)
         if (CACHEJ && head) {                     // cached Jacobians of the first slice
 #pragma unroll
-          for (int i = 0; i < 2 * BD; ++i) F[i] = cF[i];
+          for (int i = 0; i < (CY ? 6 : 2 * BD); ++i) F[i] = cF[i];
 #pragma unroll
           for (int i = 0; i < 6; ++i) E[i] = cE[i];
         } else {
           const int a = d.shared ? 0 : c;
-          double r[2];
+          double r[2], Ff[2 * BD];
           const float2 uv = f_pf.uv(pass, pb.obs_uv, o);
           if (LDSCAM)
             eval_full<KD>(d, lq + 9 * c, lt + 3 * c, pb.intr + 4 * a, X, uv, (unsigned)lfl[c],
-                          pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
+                          pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, CY ? Ff : F, E, CY ? F : nullptr);
           else
             eval_full<KD>(d, CamR(pb.cam_q + 4 * c).R, pb.cam_t + 3 * c, pb.intr + 4 * a, X, uv,
-                          pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
+                          pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r,
+                          CY ? Ff : F, E, CY ? F : nullptr);
         }
+        const int slot = f_pf.slot(pass, pb.obs_slot, o);
+        if constexpr (CY) {
+          // compressed factor: N = Jw^T (E G) (3 x 3, row-major) and 2 a = 2 R X -- one run of 96 bytes per observation
+          double M[6];
+          M[0] = E[0] * Gm[0]; M[1] = E[0] * Gm[1] + E[1] * Gm[3]; M[2] = E[0] * Gm[2] + E[1] * Gm[4] + E[2] * Gm[5];
+          M[3] = E[3] * Gm[0]; M[4] = E[3] * Gm[1] + E[4] * Gm[3]; M[5] = E[3] * Gm[2] + E[4] * Gm[4] + E[5] * Gm[5];
+          double rec[kYc];
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) rec[3 * i + m] = F[i] * M[m] + F[3 + i] * M[3 + m];
+          double Rl[9];
+          const double* Rc = Rl;
+          if (LDSCAM) Rc = lq + 9 * c; else quat_to_R(pb.cam_q + 4 * c, Rl);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const double ai = Rc[3 * i] * X[0] + Rc[3 * i + 1] * X[1] + Rc[3 * i + 2] * X[2];
+            rec[9 + i] = ai + ai;
+          }
+#if VGG_PP_ABLATE == 1                            // profiling build: the Y arithmetic without its stores
+          if (Gm[0] == 12345.678)
+#endif
+          {
+            double2* y = reinterpret_cast<double2*>(w.Y + (size_t)slot * kYc);
+#pragma unroll
+            for (int i = 0; i < kYc / 2; ++i) y[i] = make_double2(rec[2 * i], rec[2 * i + 1]);
+          }
+        } else {
         // segment layout: [component 0..2][slot 0..15][row 0..bdt-1]  (three rows of the K dimension)
-        const int slot = f_pf.slot(pass, pb.obs_slot, o), rt = kGroup * bdt;
+        const int rt = kGroup * bdt;
         double* y = w.Y + (size_t)(slot >> 4) * (3 * rt) + (slot & 15) * bdt;
         // the lane's three runs of bdt doubles go out 16 bytes at a time when bdt is even (the runs are then 16-byte
-        // aligned): half the store instructions and half the partial-line transactions of 8-byte stores.  Measured at 16
-        // lanes per point: the 720 MB of Y cost 0.13 of the 0.31 ms of this kernel, not overlapped with its arithmetic.
+        // aligned): half the store instructions and half the partial-line transactions of 8-byte stores.
         const bool pairs = (bdt & 1) == 0;
         double prev[3] = {0, 0, 0};
 #pragma unroll
@@ -808,6 +855,7 @@ __global__ __launch_bounds__(256, WRITE_Y ? VGG_PP_OCC : VGG_PP_OCC_SPLIT) void 
             }
 #endif
           }
+        }
         }
       }
     }
@@ -879,6 +927,20 @@ __global__ __launch_bounds__(256) void begin_iteration_kernel(Ws w, vgg_ba_optio
 // NH x NH accumulators in registers for the whole chunk; all MFMAs are unconditional (scalar loop bounds).
 typedef double f64x4_t __attribute__((ext_vector_type(4)));
 
+// value of the lane with the lowest bit of its index flipped (DPP quad_perm [1,0,3,2]: no LDS, no index register)
+__device__ __forceinline__ double dpp_swap_xor1(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+#ifndef VGG_TILE_TRACE
+#define VGG_TILE_TRACE 0             // debug builds: per-wavefront phase cycle sums of the off-diagonal schur_tile launch
+#endif
+#if VGG_TILE_TRACE
+__device__ long long g_tile_trace[2048 * 4 * 8];   // [workgroup][wave][batches, fetch+issue, matrix phase, LDS write phase, barrier wait, total]
+#endif
 #ifndef VGG_NO_SKIP
 #define VGG_NO_SKIP 0               // profiling builds: 1 = every sub-tile of every batch runs (no presence skipping)
 #endif
@@ -907,6 +969,11 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
   // two halves of the LDS banks (conflict-free ds_read_b64).
   constexpr int SWZ = ((SEG * 8) % 256 == 0) ? 16 : 0;
   constexpr int SIDES = DIAG ? 1 : 2;             // LDS image: ops[buffer][side][entry of the batch][SEG]
+  // BD = 6: the global segments are COMPRESSED (kYc = 12 doubles per slot: N row-major, 2 a; y_slot_doubles) and the six
+  // rows of a slot -- [2 a]x N on top of N -- are rebuilt on the way into LDS.  The LDS image and everything behind it are
+  // those of the full factors (without the Jacobi scales: tile_reduce_kernel applies them).
+  constexpr bool CY = (BD == 6);
+  constexpr int CSEG = kGroup * kYc;              // doubles per compressed segment
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: MFMAs only behind scalar control flow
   // chunk = the j-th of the J workgroups of tile (gI,gJ).  The tile's entry list [e0,e1) is sorted by point;
@@ -929,11 +996,15 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
   // no wavefront ever waits on a dependent global load: the segment index of batch n+2 is loaded while
   // the segment data of batch n+1 is in flight, and that data is written to LDS only after the MFMAs of
   // batch n (async-stage split).
-  constexpr int V = SEG / 2;                      // double2 per segment
-  constexpr int TPS = DIAG ? 64 : 32;             // threads per segment
-  constexpr int NV = (V + TPS - 1) / TPS;         // double2 per thread per batch
+  // Compressed: a PAIR of lanes per slot, three double2 each (the even lane rows 0, 1 of N, the odd lane row 2 and 2 a);
+  // the halves are exchanged with one DPP quad permute per register, the even lane then writes the rows 3..5 of the slot
+  // (N itself), the odd lane the rows 0..2 (the cross products).  A diagonal tile stages 4 segments: waves 2, 3 idle here.
+  constexpr int V = SEG / 2;                      // double2 per segment (full factors)
+  constexpr int TPS = CY ? 32 : (DIAG ? 64 : 32); // threads per segment
+  constexpr int NV = CY ? 3 : (V + TPS - 1) / TPS; // double2 per thread per batch
   const int sseg = tid / TPS, l32 = tid % TPS;
-  const int se = DIAG ? sseg : (sseg >> 1), sside = DIAG ? 0 : (sseg & 1);
+  const bool stager = !(CY && DIAG) || sseg < 4;  // (wave-uniform)
+  const int se = DIAG ? (sseg & 3) : (sseg >> 1), sside = DIAG ? 0 : (sseg & 1);
   // The segment index of a batch is loaded unconditionally (clamped entry) and only CONSUMED one iteration later;
   // entries past the end of the list are redirected to the all-zero segment behind the last real one.  Nothing in
   // the current iteration depends on the loaded value, so no s_waitcnt sits between the prefetch and the MFMAs.
@@ -942,18 +1013,56 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
   auto seg_valid = [&](int eb) -> bool { return eb + se < e1; };
   // two staging register sets: the loads of batch b + 2 are issued while batch b is multiplied and batch b + 1 (loaded an
   // iteration earlier) is written to LDS -- twice the bytes in flight per workgroup for NV more double2 registers
-  double2 sv0[NV], sv1[NV];
+  constexpr int DEPTH = (CY && !DIAG) ? 3 : 2;   // staging register sets = batches in flight ahead of the one being multiplied
+  double2 sv[DEPTH][NV];
+  // compressed staging: the lane's two LDS targets inside a staged segment (see write_lds)
+  const bool cy_top = (l32 & 1) != 0;
+  const int cy_sw = (se & 1) * SWZ, cy_r0 = 6 * (l32 >> 1);
+  const int cy_row16 = (cy_top ? cy_r0 : cy_r0 + 4) ^ cy_sw, cy_row8 = (cy_top ? cy_r0 + 2 : cy_r0 + 3) ^ cy_sw;
   auto issue_loads = [&](double2 (&sv)[NV], int seg_index, bool valid) __attribute__((always_inline)) {
-    const double2* src = reinterpret_cast<const double2*>(w.Y) + (size_t)(valid ? seg_index : zero_seg) * V;
+    if constexpr (CY) {
+      if (stager) {
+        const double2* src = reinterpret_cast<const double2*>(w.Y) + (size_t)(valid ? seg_index : zero_seg) * (CSEG / 2) + 3 * l32;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) { const int off = l32 + TPS * i; sv[i] = (off < V) ? src[off] : make_double2(0.0, 0.0); }
+        for (int i = 0; i < NV; ++i) sv[i] = src[i];
+      }
+    } else {
+      const double2* src = reinterpret_cast<const double2*>(w.Y) + (size_t)(valid ? seg_index : zero_seg) * V;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) { const int off = l32 + TPS * i; sv[i] = (off < V) ? src[off] : make_double2(0.0, 0.0); }
+    }
   };
   auto write_lds = [&](const double2 (&sv)[NV], int buf) __attribute__((always_inline)) {
-    double2* dst = reinterpret_cast<double2*>(ops + (size_t)((buf * SIDES + sside) * 4 + se) * SEG);
+    if constexpr (CY) {
+      if (stager) {
+        // odd lane:  mine = (N20 N21 N22, 2a0 2a1 2a2), other = (N00 N01 N02, N10 N11 N12) -> rows 0..2 = (2 a) x N[:, k]:
+        //            16 bytes at row 0, 8 at row 2
+        // even lane: mine = (N00 N01 N02, N10 N11 N12), other = (N20 N21 N22, ...)         -> rows 3..5 = N[:, k]:
+        //            8 bytes at row 3, 16 at row 4
+        // (the odd entries' tile rows are XOR-swizzled by 16; k R is a multiple of 32, so the swizzle acts on the row alone
+        //  and the component enters the LDS address as an immediate offset)
+        double* dst = ops + (size_t)((buf * SIDES + sside) * 4 + se) * SEG;
+        const double m[6] = {sv[0].x, sv[0].y, sv[1].x, sv[1].y, sv[2].x, sv[2].y};
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int off = l32 + TPS * i;
-      if (off < V) dst[off ^ ((se & 1) * (SWZ / 2))] = sv[i];
+        for (int k = 0; k < 3; ++k) {
+#if VGG_ABLATE == 4                               // (profiling build: the staging without its exchange / arithmetic)
+          *reinterpret_cast<double2*>(dst + k * R + cy_row16) = make_double2(m[3 + k], m[k]);
+          dst[k * R + cy_row8] = m[k];
+#else
+          const double ok = dpp_swap_xor1(m[k]), o3k = dpp_swap_xor1(m[3 + k]);   // the other half, one component at a time
+          const double t0 = m[4] * m[k] - m[5] * o3k, t1 = m[5] * ok - m[3] * m[k], t2 = m[3] * o3k - m[4] * ok;
+          *reinterpret_cast<double2*>(dst + k * R + cy_row16) = cy_top ? make_double2(t0, t1) : make_double2(m[3 + k], ok);
+          dst[k * R + cy_row8] = cy_top ? t2 : m[k];
+#endif
+        }
+      }
+    } else {
+      double2* dst = reinterpret_cast<double2*>(ops + (size_t)((buf * SIDES + sside) * 4 + se) * SEG);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int off = l32 + TPS * i;
+        if (off < V) dst[off ^ ((se & 1) * (SWZ / 2))] = sv[i];
+      }
     }
   };
   // operand addressing: entry e = lane >> 4 of the batch, component c = ks, tile row rr = 16 rb + (lane & 15)
@@ -963,37 +1072,71 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
 
   // presence of a batch (quad): field 3 of its first entry, wave-uniform (scalar load), fetched one batch ahead
   auto load_quad_mask = [&](int eb) -> uint32_t { return (uint32_t)entries[4 * (size_t)min(eb, e1 - 1) + 3]; };
-  issue_loads(sv0, load_seg_index(ebase(0)), seg_valid(ebase(0)));
-  issue_loads(sv1, load_seg_index(ebase(1)), seg_valid(ebase(1)));
-  int seg_next = load_seg_index(ebase(2));
-  bool valid_next = seg_valid(ebase(2));
+  // DEPTH staging register sets (batch n lives in set n % DEPTH): the loads of batch b + DEPTH are issued while batch b is
+  // multiplied and batch b + 1, requested DEPTH - 1 steps earlier, is written to LDS (round 3, off-diagonal launch with
+  // compressed segments: with two sets the LDS write phase spent most of its ~1000 cycles per batch waiting for loads
+  // issued one step -- ~2 us -- before; the other variants have no registers to spare for a third set)
+#pragma unroll
+  for (int u = 0; u < DEPTH; ++u) issue_loads(sv[u], load_seg_index(ebase(u)), seg_valid(ebase(u)));
+  int seg_next = load_seg_index(ebase(DEPTH));
+  bool valid_next = seg_valid(ebase(DEPTH));
   uint32_t qmask = load_quad_mask(ebase(0)), qmask_next = load_quad_mask(ebase(1));
-  write_lds(sv0, 0);
+  write_lds(sv[0], 0);
   __syncthreads();
-  // software pipeline shared by the two sub-tile assignments below (two batches per trip: the register sets alternate)
+  // software pipeline shared by the two sub-tile assignments below
   auto sweep = [&](auto&& mfma_batch) __attribute__((always_inline)) {
-    auto step = [&](int b, int buf, double2 (&sv_load)[NV], const double2 (&sv_write)[NV]) __attribute__((always_inline)) {
-#if VGG_ABLATE != 2                               // (profiling builds only: 1 = no MFMA, 2 = no global loads)
-      issue_loads(sv_load, seg_next, valid_next); // batch b+2 (the zero segment past the end of the tile's list)
-      seg_next = load_seg_index(ebase(b + 3));
-      valid_next = seg_valid(ebase(b + 3));
+#if VGG_TILE_TRACE
+    long long tr_issue = 0, tr_mfma = 0, tr_write = 0, tr_bar = 0;
+    const long long tr_begin = __builtin_amdgcn_s_memtime(), tr_wall = (long long)wall_clock64();
+#define VGG_TT(var) { const long long now_ = __builtin_amdgcn_s_memtime(); var += now_ - tr_last; tr_last = now_; }
+#else
+#define VGG_TT(var)
 #endif
+    auto step = [&](int b, int buf, double2 (&sv_load)[NV], const double2 (&sv_write)[NV]) __attribute__((always_inline)) {
+#if VGG_TILE_TRACE
+      long long tr_last = __builtin_amdgcn_s_memtime();
+#endif
+#if VGG_ABLATE != 2                               // (profiling builds only: 1 = no MFMA, 2 = no global loads)
+      // (the index of batch b+DEPTH+1 is requested BEFORE the data of batch b+DEPTH: waiting for it next time round then
+      //  leaves the younger data loads in flight -- vmcnt(3), not vmcnt(0))
+      const int seg_after = load_seg_index(ebase(b + DEPTH + 1));
+      issue_loads(sv_load, seg_next, valid_next); // batch b+DEPTH (the zero segment past the end of the tile's list)
+      seg_next = seg_after;
+      valid_next = seg_valid(ebase(b + DEPTH + 1));
+#endif
+      VGG_TT(tr_issue)
 #if VGG_ABLATE != 1
       mfma_batch(buf, qmask);
 #endif
+      VGG_TT(tr_mfma)
       qmask = qmask_next;
       qmask_next = load_quad_mask(ebase(b + 2));
-      write_lds(sv_write, buf ^ 1);               // batch b+1, in flight since the previous step
+#if VGG_ABLATE != 5                               // (profiling build: 5 = no LDS writes)
+      write_lds(sv_write, buf ^ 1);               // batch b+1, in flight for two steps
+#endif
+      VGG_TT(tr_write)
 #if VGG_ABLATE != 3
       __syncthreads();
 #endif
+      VGG_TT(tr_bar)
     };
+    // (2 DEPTH steps per trip: the LDS buffers alternate, the register sets rotate)
+    constexpr int TRIP = 2 * DEPTH;
     int b = 0;
-    for (; b + 1 < nb; b += 2) {
-      step(b, 0, sv0, sv1);
-      step(b + 1, 1, sv1, sv0);
+    for (; b + TRIP - 1 < nb; b += TRIP) {
+#pragma unroll
+      for (int u = 0; u < TRIP; ++u) step(b + u, u & 1, sv[u % DEPTH], sv[(u + 1) % DEPTH]);
     }
-    if (b < nb) step(b, 0, sv0, sv1);
+#pragma unroll
+    for (int u = 0; u < TRIP - 1; ++u)
+      if (b + u < nb) step(b + u, u & 1, sv[u % DEPTH], sv[(u + 1) % DEPTH]);
+#if VGG_TILE_TRACE
+    if (!DIAG && lane == 0 && blockIdx.x < 2048) {
+      long long* t = g_tile_trace + ((size_t)blockIdx.x * 4 + wave) * 8;
+      t[0] = nb; t[1] = tr_issue; t[2] = tr_mfma; t[3] = tr_write; t[4] = tr_bar; t[5] = __builtin_amdgcn_s_memtime() - tr_begin;
+      t[6] = (long long)wall_clock64() - tr_wall;
+    }
+#endif
   };
   // partial tile of this chunk, row-major R x R (f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 reg);
   // tile_reduce_kernel sums the chunks of a tile in a fixed order (deterministic, no atomics)
@@ -1020,20 +1163,52 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
     sweep([&](int buf, uint32_t qm) {
       const double* As = ops + (size_t)(buf * SIDES) * 4 * SEG;
       const double* Bs = ops + (size_t)(buf * SIDES + 1) * 4 * SEG;
-      bool ra[NH], cb[NH];
+      // one scalar bit per sub-tile of this wavefront (bit NH i + j), built once per batch: every skip test below is a bit
+      // test + branch.  (With the conditions kept as booleans the compiler built each of the 27 tests of a batch from 64-bit
+      // lane masks -- six dependent scalar instructions and two branches per matrix instruction.)
+      uint32_t colm = 0u, on = 0u;
 #pragma unroll
-      for (int i = 0; i < NH; ++i) { ra[i] = (qm & bitsA[i]) != 0; cb[i] = (qm & bitsB[i]) != 0; }
+      for (int j = 0; j < NH; ++j) colm |= ((qm & bitsB[j]) != 0 ? 1u : 0u) << j;
 #pragma unroll
-      for (int ks = 0; ks < 3; ++ks) {
-        double a[NH], bq[NH];
+      for (int i = 0; i < NH; ++i) on |= ((qm & bitsA[i]) != 0 ? colm : 0u) << (NH * i);
+      on = VGG_NO_SKIP ? 0xFFFFFFFFu : (uint32_t)__builtin_amdgcn_readfirstlane((int)on);
+      // operands of K step ks + 1 are requested before the matrix instructions of step ks; `pin` keeps the compiler from
+      // sinking the LDS reads to their first use (it then waited for each one right in front of its matrix instruction),
+      // `opaque` from turning the bit tests into lane-mask booleans shared by the three K steps
+      double a[2][NH], bq[2][NH];
+      auto fetch = [&](int set, int ks) __attribute__((always_inline)) {
+#if VGG_ABLATE == 6                               // (profiling build: no LDS operand reads)
 #pragma unroll
-        for (int i = 0; i < NH; ++i) { a[i] = As[rowoffA[i] + ks * R]; bq[i] = Bs[rowoffB[i] + ks * R]; }
+        for (int i = 0; i < NH; ++i) { a[set][i] = 1.0 + ks; bq[set][i] = 2.0 + i; }
+#else
+#pragma unroll
+        for (int i = 0; i < NH; ++i) { a[set][i] = As[rowoffA[i] + ks * R]; bq[set][i] = Bs[rowoffB[i] + ks * R]; }
+#endif
+      };
+      auto pin = [&](int set) __attribute__((always_inline)) {
+        static_assert(NH == 3 || NH == 4, "operand sets");
+        if constexpr (NH == 3)
+          asm volatile("" : "+v"(a[set][0]), "+v"(a[set][1]), "+v"(a[set][2]), "+v"(bq[set][0]), "+v"(bq[set][1]), "+v"(bq[set][2]));
+        else
+          asm volatile("" : "+v"(a[set][0]), "+v"(a[set][1]), "+v"(a[set][2]), "+v"(a[set][3]), "+v"(bq[set][0]), "+v"(bq[set][1]),
+                       "+v"(bq[set][2]), "+v"(bq[set][3]));
+      };
+      auto group = [&](int set) __attribute__((always_inline)) {
+        uint32_t m = on;
+        asm volatile("" : "+s"(m));
 #pragma unroll
         for (int i = 0; i < NH; ++i)
 #pragma unroll
           for (int j = 0; j < NH; ++j)
-            if (VGG_NO_SKIP || (ra[i] && cb[j])) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bq[j], acc[i][j], 0, 0, 0);
-      }
+            if (m & (1u << (NH * i + j))) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[set][i], bq[set][j], acc[i][j], 0, 0, 0);
+      };
+      fetch(0, 0);
+      fetch(1, 1); pin(0);
+      group(0);
+      fetch(0, 2); pin(1);
+      group(1);
+      pin(0);
+      group(0);
     });
 #pragma unroll
     for (int i = 0; i < NH; ++i)
@@ -1064,17 +1239,22 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
     }
     sweep([&](int buf, uint32_t qm) {
       const double* As = ops + (size_t)(buf * SIDES) * 4 * SEG;
-      bool on[PER];
+      uint32_t on = 0u;                             // bit t: sub-tile t of this wavefront has a camera in its rows and in its columns
 #pragma unroll
-      for (int t = 0; t < PER; ++t) on[t] = (qm & bitsR[t]) != 0 && (qm & bitsC[t]) != 0;
+      for (int t = 0; t < PER; ++t) on |= (((qm & bitsR[t]) != 0 && (qm & bitsC[t]) != 0) ? 1u : 0u) << t;
+      on = VGG_NO_SKIP ? ((1u << nmine) - 1u) : (uint32_t)__builtin_amdgcn_readfirstlane((int)on);
+      // (a sub-tile's row and column operands are fetched per K step, right in front of its matrix instruction: the diagonal
+      //  launch runs at four workgroups per CU and has no registers for a second operand set)
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
+        uint32_t m = on;
+        asm volatile("" : "+s"(m));                 // (keeps the tests scalar bit tests; see the off-diagonal variant)
         double a[PER], bq[PER];
 #pragma unroll
         for (int t = 0; t < PER; ++t) { a[t] = As[offA[t] + ks * R]; bq[t] = As[offB[t] + ks * R]; }
 #pragma unroll
         for (int t = 0; t < PER; ++t)
-          if (VGG_NO_SKIP ? (t < nmine) : on[t])
+          if (m & (1u << t))
             acc[t / NH][t % NH] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], bq[t], acc[t / NH][t % NH], 0, 0, 0);
       }
     });
@@ -1141,7 +1321,14 @@ __global__ __launch_bounds__(256) void tile_reduce_kernel(Ws w, int n_red, int C
   for (; ch + 1 < c1; ch += 2) { s0 += src[(size_t)ch * R * R]; s1 += src[(size_t)(ch + 1) * R * R]; }
   if (ch < c1) s0 += src[(size_t)ch * R * R];
   const int hi = ri > cj ? ri : cj, lo = ri > cj ? cj : ri;
-  dst[(size_t)hi * n + lo] = -(s0 + s1);
+  double v = -(s0 + s1);
+  if constexpr (BD == 6) {
+    // compressed factors carry neither the Jacobi scales nor the constant-parameter masks (y_slot_doubles): both act on
+    // whole rows / columns of the sum
+    const double mi = w.active[ri] ? w.scale_c[ri] : 0.0, mj = w.active[cj] ? w.scale_c[cj] : 0.0;
+    v *= mi * mj;
+  }
+  dst[(size_t)hi * n + lo] = v;
 }
 
 // diagonal blocks, camera/intrinsics coupling, damping, right-hand side.  One workgroup (64) per camera,
@@ -1632,14 +1819,21 @@ static void phase_schur(const Launch& L) {
     // cameras (q, t, pose scales, constant flags: 14 doubles each) cached in LDS when they fit beside 2 workgroups/CU
     const size_t cam_lds = sizeof(double) * 19 * (size_t)d.C;
     {
-      auto launch = [&](auto lpp) {
+      auto launch_cy = [&](auto lpp, auto cy) {
         constexpr int LPP = decltype(lpp)::value;
+        constexpr bool CY = decltype(cy)::value;
         const bool longt = long_tracks(LPP, L.d.P, L.d.O);
         if (longt && LPP <= 32) {
-          if (cam_lds <= 64 * 1024) point_pass_kernel<KD, true, true, LPP, (LPP <= 32)><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w, L.opt);
-          else point_pass_kernel<KD, false, true, LPP, (LPP <= 32)><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w, L.opt);
-        } else if (cam_lds <= 64 * 1024) point_pass_kernel<KD, true, true, LPP><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w, L.opt);
-        else point_pass_kernel<KD, false, true, LPP><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w, L.opt);
+          if (cam_lds <= 64 * 1024) point_pass_kernel<KD, true, CY, LPP, (LPP <= 32)><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w, L.opt);
+          else point_pass_kernel<KD, false, CY, LPP, (LPP <= 32)><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w, L.opt);
+        } else if (cam_lds <= 64 * 1024) point_pass_kernel<KD, true, CY, LPP><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w, L.opt);
+        else point_pass_kernel<KD, false, CY, LPP><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w, L.opt);
+      };
+      // compressed Schur factors with 6 x 6 tile blocks (shared or constant intrinsics), full factors otherwise
+      auto launch = [&](auto lpp) {
+        if constexpr (KD == 0) launch_cy(lpp, std::true_type{});
+        else if (d.shared) launch_cy(lpp, std::true_type{});
+        else launch_cy(lpp, std::false_type{});
       };
       if (L.lpp == 8) launch(std::integral_constant<int, 8>{});
       else if (L.lpp == 16) launch(std::integral_constant<int, 16>{});
@@ -1965,3 +2159,9 @@ int vgg_ba_solve(const vgg_ba_problem* problem, const vgg_ba_options* options, v
 }
 
 }  // extern "C"
+
+#if VGG_TILE_TRACE
+extern "C" int vgg_debug_read_tile_trace(long long* host, size_t count) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vgg::g_tile_trace), sizeof(long long) * count);
+}
+#endif

@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-triangulation", action="store_true", help="skip the triangulation leg (tracks/s of the same scene)")
     ap.add_argument("--no-strong-leg", action="store_true",
                     help="skip the short strong-scaling leg on BASELINE configs[3] (400 x 300k split over the ranks)")
     ap.add_argument("--strong-steps", type=int, default=10)
@@ -231,6 +232,7 @@ def main():
         P = int(prob.pts.shape[0])
         n_red = int(fin["n_reduced"])
         bd = 6 if shared else 6 + (2 if cam_type == "SIMPLE_RADIAL" else 1)     # Schur block width
+        y_slot = 12 if bd == 6 else 3 * bd                                         # doubles per observation in the segment buffer
         # camera-pair blocks (a <= b) of the Schur complement, split by the launch that computes them
         seg_count = torch.bincount(prob.obs_slot.long() // BA.GROUP, minlength=prob.num_segments).double()   # cameras per segment
         pairs_all = float((counts * (counts + 1) / 2).sum().item())
@@ -245,7 +247,9 @@ def main():
             "schur_tile<offdiag>": ("mfma", 2.0 * 3 * bd * bd * pairs_off),
             "schur_tile<diag>": ("mfma", 2.0 * 3 * bd * bd * pairs_diag),
             "cholesky": ("mfma", n_red ** 3 / 3.0 + 2.0 * n_red ** 2),
-            "point_pass": ("hbm", 12.0 * n_obs + P * (24 + 4 + 8 * (6 + 3 + 6))),
+            # (with the segment buffer it writes: 96 B per observation compressed, 24 BD B otherwise -- an artefact of the
+            #  formulation, priced because it is what bounds the kernel)
+            "point_pass": ("hbm", (12.0 + 8.0 * y_slot) * n_obs + P * (24 + 4 + 8 * (6 + 3 + 6))),
             "point_step": ("hbm", 12.0 * n_obs + P * (24 + 4 + 8 * (6 + 3) + 24)),
             "cam_pass<linearize>": ("hbm", 12.0 * n_obs + 24.0 * n_obs),
             "cam_pass<rhs>": ("hbm", 12.0 * n_obs + (24.0 + 24 + 48) * n_obs),
@@ -336,6 +340,40 @@ def main():
             cpu = dict(value=s_cpu["num_iterations"] / tcpu, unit="LM-iterations/s", cores=int(OB.lib().bao_num_threads()),
                        kind="port", sample=f"full {S}x{N} workload, {s_cpu['num_iterations']} LM iterations "
                        f"(oracle/ba_oracle.c, OpenMP, includes the initial evaluation), {tcpu:.1f} s")
+        # ---- the other half of north_star's first sentence: LO-RANSAC triangulation of the same scene
+        tri = None
+        if world == 1 and sc is not None and not args.no_triangulation:
+            from vggsfm_amd.utils import triangulation as TR
+            from vggsfm_amd.utils import triangulation_helpers as TH
+            g_ext, g_K, g_xp = D(sc.extrinsics, dev), D(sc.intrinsics, dev), D(sc.extra_params, dev)
+            g_tracks, g_vis, g_score = D(sc.tracks, dev), D(sc.vis, dev), D(sc.score, dev)
+            tn = TH.cam_from_img(g_tracks, g_K, g_xp)
+            torch.manual_seed(0)
+            TR.triangulate_tracks(g_ext, tn, track_vis=g_vis, track_score=g_score)        # warm-up (same draws discarded)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 3
+            torch.cuda.synchronize()
+            th0 = time.perf_counter()
+            ev0.record()
+            for _ in range(reps):
+                p3, num_inl, _ = TR.triangulate_tracks(g_ext, tn, track_vis=g_vis, track_score=g_score)
+            ev1.record()
+            torch.cuda.synchronize()
+            t_host = (time.perf_counter() - th0) / reps
+            t_dev = ev0.elapsed_time(ev1) * 1e-3 / reps
+            hyp = min(256, S * (S - 1) // 2)
+            # SURVEY 8(d) per-track flops of the REFERENCE formulation (its all-pairs angle term included)
+            f_ref = N * (hyp * (2.5e3 + 70 * S) + 60 * (150 * S + 2e3 + 70 * S) + 60 * 40 * S * S)
+            # what the kernel evaluates: (H + 2 x 60) view passes of ~70 flop + (H + 60) x 3k flop of DLT / Jacobi per track
+            f_exec = N * ((hyp + 120) * S * 70.0 + (hyp + 60) * 3e3)
+            tri = dict(workload=f"triangulate_tracks on the timed scene ({S} x {N}), {hyp} hypotheses + 2 local-optimisation rounds, "
+                                "all reference chunks in one launch", ms=1e3 * t_dev, ms_host_inclusive=1e3 * t_host,
+                       tracks_per_s=N / t_dev, valid_frac=float((num_inl >= 3).float().mean()),
+                       bound="fp64 valu", executed_flops=f_exec, frac_of_fp64_peak=f_exec / t_dev / (FP64_PEAK_TFLOPS * 1e12),
+                       reference_formulation_flops=f_ref, reference_formulation_tflops=f_ref / t_dev / 1e12,
+                       kernel="triangulate_kernel (profiles/: rocprofv3 stats of scripts/prof/bench_geometry.py)")
+            del g_tracks, g_vis, g_score, tn, p3
+            torch.cuda.empty_cache()
         parity_c3 = None
         if cpu is not None:
             # the SAME headline problem and the same iterations the port was just timed on, now on the GPU through the
@@ -416,6 +454,7 @@ def main():
             "pose_delta_vs_port": parity,
             "pose_delta_vs_port_c3": parity_c3,
             "strong_scaling_c4": strong,
+            "triangulation": tri,
         }
         print(json.dumps(out))
     if dist:

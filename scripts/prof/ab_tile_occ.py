@@ -11,7 +11,7 @@ for name, lib, wgs in (("occ3", None, "3,4"), ("occ4", "vggsfm_amd/_variants/lib
     env = dict(os.environ, VGGSFM_TILE_WGS=wgs)
     if lib:
         env["VGGSFM_AMD_LIB"] = os.path.join(ROOT, lib)
-    code = ("import os, sys, runpy; sys.argv = ['bench.py', '--steps', '20', '--warmup', '5', '--no-cpu-baseline', '--no-strong-leg'];"
+    code = ("import os, sys, runpy; sys.argv = ['bench.py', '--steps', '20', '--warmup', '5', '--no-cpu-baseline', '--no-strong-leg', '--no-triangulation'];"
             "import vggsfm_amd.ba as BA; BA.TILE_WGS_PER_CU = tuple(int(v) for v in os.environ['VGGSFM_TILE_WGS'].split(','));"
             "runpy.run_path('bench.py', run_name='__main__')")
     out = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True).stdout

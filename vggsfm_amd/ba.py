@@ -169,8 +169,37 @@ class DeviceProblem:
         return P
 
 
+TILE_FIXED_COST = 18.0   # cost of a tile batch besides its matrix instructions, in matrix instructions of one wavefront
+#                          (staging, LDS write phase, barrier: ~2400 of ~5000 cycles per batch in the round-3 phase trace)
+
+
+def _entry_cost(qmask, diag, bd, group=GROUP):
+    """Cost model of one tile entry for the workgroup counts (what schur_tile_kernel spends on the QUAD the entry belongs
+    to): TILE_FIXED_COST + 3 x the matrix instructions of the busiest of the four wavefronts, from the quad's presence masks
+    exactly as the kernel skips -- 16-row block b of a side runs when one of the cameras with rows in it (slots 16 b // bd
+    .. (16 b + 15) // bd) is present.  Off-diagonal tile: wavefront (wr, wc) owns the sub-tiles (wr + 2 i, wc + 2 j); diagonal
+    tile: the lower-triangle sub-tiles row by row, dealt round-robin.  qmask (E,) long: maskA | maskB << 16; diag (E,) bool."""
+    dev = qmask.device
+    nt = bd                                                   # 16 bd rows / 16
+    bits = []
+    for b in range(nt):
+        s0, s1 = (16 * b) // bd, min(group - 1, (16 * b + 15) // bd)
+        bits.append(((2 << s1) - 1) & ~((1 << s0) - 1))
+    bits = torch.tensor(bits, dtype=torch.long, device=dev)
+    ra = ((qmask[:, None] & 0xFFFF) & bits[None]) != 0        # (E, nt) row blocks with a camera
+    rb = ((qmask[:, None] >> 16) & bits[None]) != 0
+    off = torch.maximum(ra[:, 0::2].sum(1), ra[:, 1::2].sum(1)) * torch.maximum(rb[:, 0::2].sum(1), rb[:, 1::2].sum(1))
+    per_wave = torch.zeros((qmask.shape[0], 4), dtype=torch.long, device=dev)
+    t = 0
+    for r in range(nt):
+        for c in range(r + 1):
+            per_wave[:, t % 4] += (ra[:, r] & ra[:, c]).long()
+            t += 1
+    return TILE_FIXED_COST + 3.0 * torch.where(diag, per_wave.max(1).values, off).double()
+
+
 def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=None, num_batches=1, later_scale=1.0,
-                      merged_slots=None):
+                      merged_slots=None, block_rows=6):
     """Block-sparse Schur work list (device, torch ops; structure is fixed for the whole solve).
 
     A *segment* is the run of one point's observations that falls into one group of `group`
@@ -190,6 +219,11 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     being computed.  batch_desc row = (chunk_begin, first_diagonal_chunk, chunk_end, tile_begin, tile_end,
     first_camera_group).  `later_scale` shrinks the workgroup caps of the batches after the first (they run on a
     CU-masked stream beside the factorisation).
+
+    Workgroups per tile: proportional to the tile's COST (_entry_cost: staging + the matrix instructions its presence masks
+    leave), not to its entry count -- tiles whose points see few of the 2 x 16 cameras skip most of their sub-tiles and ran
+    15 % ahead of the dense ones, the launch waiting for the slowest (round 3 phase trace); `block_rows` = rows per camera
+    of the tile blocks (6, or 6 + refined intrinsics when they are per camera).
 
     `merged_slots`: the off-diagonal and the diagonal chunks will run in ONE launch (vgg_ba_problem.merged_tile_launch) with
     that many resident workgroups in all; the split between the two kinds follows their entry counts."""
@@ -258,6 +292,15 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     tbatch = ukeys // (2 * nn)
     is_diag = (ukeys % (2 * nn)) >= nn
     ukeys = ukeys % nn
+    # cost-weighted entry count of every tile (relative to the mean entry of its launch kind)
+    ecost = _entry_cost(qm[quad], is_diag[unit_of_entry], block_rows, group)
+    tcost = torch.zeros(kcounts.shape[0], dtype=torch.float64, device=dev).index_add_(0, unit_of_entry, ecost)
+    kweight = torch.ones_like(tcost)
+    for sel in (is_diag, ~is_diag):
+        if bool(sel.any()):
+            kweight[sel] = (tcost[sel] / kcounts[sel].double()) / (tcost[sel].sum() / kcounts[sel].sum().double())
+    kw = kcounts.double() * kweight
+    nsub_t = (kcounts + SUB - 1) // SUB                      # a workgroup needs at least one sub-chunk
     csize = torch.full_like(kcounts, chunk)
     if max_chunks is not None:
         # one resident round per launch: the smallest chunk size (multiple of SUB, >= MIN_CHUNK) whose workgroup
@@ -272,16 +315,16 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
             n_off = min(max(n_off, 1 if e_off else 0), merged_slots - (1 if e_diag else 0))
             caps = (max(n_off, 1), max(merged_slots - n_off, 1))
         # (the search runs on host copies of the per-tile counts: one synchronisation instead of one per probe)
-        kc_h, diag_h, tb_h = kcounts.cpu(), is_diag.cpu(), tbatch.cpu()
+        kc_h, diag_h, tb_h, kw_h, ns_h = kcounts.cpu(), is_diag.cpu(), tbatch.cpu(), kw.cpu(), nsub_t.cpu()
         csize_h = torch.full_like(kc_h, chunk)
         for b in range(nb):
             scale = 1.0 if b == 0 else later_scale
             for sel, cap in ((~diag_h & (tb_h == b), int(caps[0] * scale)), (diag_h & (tb_h == b), int(caps[1] * scale))):
                 if not bool(sel.any()):
                     continue
-                kc = kc_h[sel]
-                lo, hi = MIN_CHUNK // SUB, max(MIN_CHUNK // SUB, int(-(-int(kc.max()) // SUB)))
-                fits = lambda c: int(((kc + c * SUB - 1) // (c * SUB)).sum()) <= cap
+                kc, kwv, nsv = kc_h[sel], kw_h[sel], ns_h[sel]
+                lo, hi = MIN_CHUNK // SUB, max(MIN_CHUNK // SUB, int(-(-int(max(float(kwv.max()), float(kc.max()))) // SUB)))
+                fits = lambda c: int(torch.minimum(torch.clamp(torch.ceil(kwv / (c * SUB)), min=1).long(), nsv).sum()) <= cap
                 if not fits(hi):
                     lo = hi                         # more tiles than slots: one workgroup per tile
                 while lo < hi:
@@ -289,7 +332,7 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
                     lo, hi = (lo, mid) if fits(mid) else (mid + 1, hi)
                 csize_h[sel] = lo * SUB
         csize = csize_h.to(dev)
-    nchunks = (kcounts + csize - 1) // csize
+    nchunks = torch.minimum(torch.clamp(torch.ceil(kw / csize.double()), min=1).long(), nsub_t)
     ctile = torch.repeat_interleave(torch.arange(ukeys.shape[0], device=dev), nchunks)          # unit of every chunk
     cfirst = torch.cumsum(nchunks, 0) - nchunks
     local = torch.arange(ctile.shape[0], device=dev) - cfirst[ctile]
@@ -582,7 +625,8 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
     merged = nb == 1 and int(obs_cam.shape[0]) < MERGED_TILE_MAX_OBS
     chunk_desc, entries, tile_desc, obs_slot, nseg, batch_desc = build_schur_tiles(
         row_ptr, obs_cam, max_chunks=slots, num_batches=nb, later_scale=(cus - CHOL_CUS) / cus,
-        merged_slots=(slots[0] if merged else None))
+        merged_slots=(slots[0] if merged else None),
+        block_rows=6 if shared_camera else 6 + (2 if camera_type == "SIMPLE_RADIAL" else 1))
     prob = DeviceProblem(cam_q, cam_t, intr, pts, row_ptr, obs_cam, obs_uv, col_ptr, cobs_pt, cobs_uv, chunk_desc,
                          entries, tile_desc, obs_slot, nseg, MODEL_ID[camera_type], cam_const=cam_const,
                          batch_desc=batch_desc, chol_split=chol_split, cam_perm=cam_perm, merged_tile_launch=merged)

@@ -8,13 +8,14 @@ A *step* is ONE LM iteration (linearise -> block-sparse Schur complement -> dens
 reduced camera system -> back-substitution -> candidate cost -> trust-region decision) over the whole
 synthetic scene.  Workload at N=1 = BASELINE.json configs[2], the configuration the north-star target is
 quoted on: 200 frames x 100k tracks, SIMPLE_RADIAL, shared camera (SURVEY.md section 8d generator).
-N>1 (default workload): WEAK scaling -- the tracks are sharded by 3D point, every rank holds its own 100k-track shard
-(the global problem is 200 frames x N*100k tracks), cameras replicated, per-camera blocks / reduced system all-reduced
-over RCCL once per iteration; `value` is the whole-job aggregate in SHARD-iterations per second (N x K / t: K LM
-iterations of the N-times-larger problem, counted once per 100k-track shard), `lm_iterations_per_s_global` is K / t.
-`--workload c4` is STRONG scaling on BASELINE configs[3]: 400 frames x 300k tracks with per-frame intrinsics, the
-300k tracks split over the N ranks; `value` = LM iterations per second of that whole problem.  Unless
-`--no-strong-leg` is given, a default run also times a short c4 leg and reports it as `strong_scaling_c4`.
+N>1 (default workload): STRONG scaling on BASELINE configs[3] -- ONE fixed problem, 400 frames x 300k tracks with per-frame
+intrinsics, its tracks sharded by 3D point over the N ranks, cameras replicated, per-camera blocks all-reduced and the
+reduced system reduce-scattered + all-gathered over RCCL once per iteration; `value` = true LM iterations per second of
+that whole problem.  Rank 0 first times the SAME problem alone (`n1_same_problem`, the other ranks wait), so the line
+carries its own speed-up; a short weak-scaling leg on configs[2] shards (every rank its own 100k tracks) is reported
+as `weak_scaling_c3` in shard-iterations per second.  At N=1 a default run also times a short c4 leg
+(`strong_scaling_c4`: the N = 1 point of the strong-scaling curve) unless `--no-strong-leg` is given.
+`--workload c3 --gpus N` selects the weak-scaling problem as the main one (value = N x K / t shard-iterations/s).
 Inputs are resident in HBM before the timed region; termination tests are disabled so that exactly K
 iterations run (a solve is restarted from the initial state every EPISODE iterations, like the
 reference's 50/100-iteration BA calls).
@@ -92,7 +93,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: c3 (BASELINE configs[2]) at N = 1, c4 (configs[3], strong scaling) at N > 1")
+    ap.add_argument("--no-n1-leg", action="store_true", help="N > 1, strong scaling: skip rank 0's solo run of the whole problem")
+    ap.add_argument("--no-weak-leg", action="store_true", help="N > 1: skip the weak-scaling leg on configs[2] shards")
+    ap.add_argument("--weak-steps", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-triangulation", action="store_true", help="skip the triangulation leg (tracks/s of the same scene)")
     ap.add_argument("--no-strong-leg", action="store_true",
@@ -110,6 +115,8 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if args.workload is None:
+        args.workload = "c3" if world == 1 else "c4"
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
@@ -136,13 +143,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def build(workload):
-        """-> (problem, numpy scene or None, initial cameras / points on the host or None)"""
+    def build(workload, solo=False):
+        """-> (problem, numpy scene or None, initial cameras / points on the host or None).  solo: the whole problem on
+        this rank alone (no collective at set-up)."""
         S, N, cam_type, shared = WORKLOADS[workload]
-        reduce_adj = (lambda t: dist.all_reduce(t, op=dist.ReduceOp.MAX)) if dist else None
+        reduce_adj = (lambda t: dist.all_reduce(t, op=dist.ReduceOp.MAX)) if (dist and not solo) else None
         if workload in STRONG or S >= 400:
             # 400-frame configurations: scene drawn on the device (make_scene costs ~25 s of numpy per 100k tracks there)
-            n_local = N // world if workload in STRONG else N
+            n_local = N // world if (workload in STRONG and not solo) else N
             sc = make_scene_device(S, n_local, cam_type, shared_camera=shared, seed=0, track_seed=1000 + rank, device=dev)
             ext0_c, K0_c, extra0_c, _ = perturb_for_ba(sc_cameras_only(sc), seed=0)
             prob, _, _ = BA.compile_problem(sc.points3D_init, D(ext0_c, dev), D(K0_c, dev), sc.tracks, sc.mask, D(extra0_c, dev),
@@ -157,15 +165,23 @@ def main():
                                         camera_split=not args.no_camera_split, adjacency_reduce=reduce_adj)
         return prob, sc, (pts0, ext0_c, K0_c, extra0_c)
 
-    def timed(prob, steps, warmup, profile):
+    def timed(prob, steps, warmup, profile, solo=False):
         """K LM iterations between barriers (termination tests off, solves restarted every EPISODE iterations).
-        -> (seconds = max over ranks, summary of the last episode, per-kernel HIP-event profile or None)"""
+        -> (seconds = max over ranks, summary of the last episode, per-kernel HIP-event profile or None).
+        solo: this rank alone (no collectives, no barriers with the others)."""
+        nonlocal_dist = None if solo else dist
+
+        def barrier():
+            torch.cuda.synchronize()
+            if nonlocal_dist:
+                nonlocal_dist.barrier()
+            torch.cuda.synchronize()
         init = [t.clone() for t in (prob.cam_q, prob.cam_t, prob.intr, prob.pts)]
         opts = BundleAdjustmentOptions()
         so = opts.solver_options
         so.max_num_iterations = EPISODE
         so.function_tolerance = so.gradient_tolerance = so.parameter_tolerance = -1.0   # run exactly K iterations
-        solver = ShardedBA(prob, opts, rank, world)     # phases + RCCL all-reduces on the current stream
+        solver = ShardedBA(prob, opts, 0, 1) if solo else ShardedBA(prob, opts, rank, world)   # phases + RCCL collectives on the current stream
         counter = [0]
 
         def run(n):
@@ -187,9 +203,9 @@ def main():
         run(steps)
         barrier()
         dt = time.perf_counter() - t0
-        if dist:
+        if nonlocal_dist:
             tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            nonlocal_dist.all_reduce(tmax, op=nonlocal_dist.ReduceOp.MAX)
             dt = float(tmax.item())
         # the last episode must have run all its iterations (no early termination => no skipped work)
         fin = solver.finish()
@@ -210,8 +226,31 @@ def main():
 
     S, N, cam_type, shared = WORKLOADS[args.workload]
     strong_main = args.workload in STRONG
+    # ---- N > 1, strong scaling: the SAME whole problem on rank 0 alone first (the N = 1 point of the curve, measured on
+    # this box in this run); the other ranks wait at the barrier
+    n1 = None
+    if world > 1 and strong_main and not args.no_n1_leg:
+        if rank == 0:
+            p1, _, _ = build(args.workload, solo=True)
+            d1, f1, _ = timed(p1, args.strong_steps, 2, False, solo=True)
+            n1 = dict(workload=f"the same {S} x {N} problem on rank 0 alone", steps=args.strong_steps, observations=int(p1.num_obs),
+                      ms_per_iteration=1e3 * d1 / args.strong_steps, lm_iterations_per_s=args.strong_steps / d1)
+            del p1
+            torch.cuda.empty_cache()
+        barrier()
     prob, sc, host_init = build(args.workload)
     dt, fin, prof = timed(prob, args.steps, args.warmup, True)
+    # ---- N > 1: weak-scaling leg on configs[2] shards (every rank its own 200 x 100k shard)
+    weak = None
+    if world > 1 and strong_main and not args.no_weak_leg:
+        wprob, _, _ = build("c3")
+        wdt, wfin, _ = timed(wprob, args.weak_steps, 2, False)
+        weak = dict(workload=f"200 frames x {world} x 100000 tracks SIMPLE_RADIAL shared_camera: one 100000-track shard per rank",
+                    steps=args.weak_steps, ms_per_iteration=1e3 * wdt / args.weak_steps,
+                    lm_iterations_per_s_global=args.weak_steps / wdt, shard_iterations_per_s=args.weak_steps * world / wdt,
+                    scaling="weak")
+        del wprob
+        torch.cuda.empty_cache()
 
     # ---- strong-scaling leg: BASELINE configs[3] (400 x 300k, per-frame intrinsics) split over the ranks
     strong = None
@@ -426,7 +465,8 @@ def main():
             "metric": "BA LM-iterations/sec",
             "value": args.steps / dt if strong_main else args.steps * world / dt,
             "unit": "LM-iterations/s",
-            "value_definition": ("LM iterations per second of the whole 400 x 300000 problem (its tracks split over the ranks)"
+            "value_definition": ("true LM iterations per second of ONE fixed problem, the whole 400 x 300000 configs[3] (its tracks "
+                                 "split over the ranks); n1_same_problem is the same problem on one GPU of this box"
                                  if strong_main else
                                  "whole-job aggregate, weak scaling: K LM iterations of the 200-frame x (N x 100000)-track problem "
                                  "counted once per 100000-track shard = N x K / t ('shard-iterations per second'); at N = 1 it is "
@@ -442,7 +482,8 @@ def main():
                                     f"{' shared_camera' if shared else ''}, full LM (BASELINE configs[2] at N=1)"),
                        "frames": S, "tracks_per_gpu": (N // world if strong_main else N), "observations_per_gpu": n_obs,
                        "reduced_system": n_red,
-                       "parallelism": f"points sharded x{world}, cameras replicated, RCCL all-reduce of the reduced system",
+                       "parallelism": f"points sharded x{world}, cameras replicated, RCCL all-reduce of the camera blocks, "
+                                      "reduce-scatter + all-gather of the packed reduced system",
                        "episode_iterations": EPISODE,
                        "camera_split_columns": list(prob.chol_split),   # block-diagonal leading part factorised side by side
                        "successful_steps_last_episode": int(fin["num_successful_steps"]),
@@ -454,6 +495,9 @@ def main():
             "pose_delta_vs_port": parity,
             "pose_delta_vs_port_c3": parity_c3,
             "strong_scaling_c4": strong,
+            "n1_same_problem": n1,
+            "speedup_vs_n1": (args.steps / dt) / n1["lm_iterations_per_s"] if (n1 and strong_main) else None,
+            "weak_scaling_c3": weak,
             "triangulation": tri,
         }
         print(json.dumps(out))

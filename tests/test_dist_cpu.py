@@ -144,3 +144,55 @@ def test_gloo_world2_camera_split_is_agreed_between_ranks():
     (_, alone0, split0, red0, rsplit0), (_, alone1, split1, red1, rsplit1) = res
     assert alone0 is not None and split0[0] % 64 == 0 and alone1 is None
     assert red0 == red1 and rsplit0 == rsplit1 == (0, 0) and red0 is None
+
+
+def _collectives_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vggsfm_amd.dist import Collectives
+    res = {}
+    for M in (1, 7, 1000, 4097):                     # payloads that do and do not divide by the world size
+        g = torch.Generator().manual_seed(100 * M + rank)
+        local = torch.randn(M, dtype=torch.float64, generator=g)
+        for plain in (False, True):
+            co = Collectives(world, plain_all_reduce=plain)
+            packed, mx = local.clone(), torch.tensor([float(rank + 1) * 0.5 + M], dtype=torch.float64)
+            co.system_(packed, mx)
+            co.system_(packed.clone(), mx.clone())    # (buffers are reused across calls)
+            res[(M, plain)] = (packed.numpy().copy(), float(mx))
+        four = torch.full((4,), float(rank + 1), dtype=torch.float64)
+        Collectives(world).sum_(four)
+        res[(M, "sum")] = four.numpy().copy()
+    out.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world3_reduce_scatter_all_gather_equals_all_reduce():
+    """dist.Collectives.system_: reduce-scatter + all-gather of the padded payload with the local maxima riding in the
+    gather = SUM all-reduce + MAX all-reduce, on every rank, for payload sizes that are not multiples of the world size --
+    the collective of the GPU path (RCCL), run here over gloo with three processes."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_collectives_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(out.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for M in (1, 7, 1000, 4097):
+        expect = sum(torch.randn(M, dtype=torch.float64, generator=torch.Generator().manual_seed(100 * M + r)).numpy()
+                     for r in range(world))
+        for r in range(world):
+            for plain in (False, True):
+                packed, mx = res[r][(M, plain)]
+                np.testing.assert_allclose(packed, expect, rtol=1e-13, atol=1e-13)
+                assert mx == world * 0.5 + M
+            assert np.array_equal(res[r][(M, "sum")], np.full(4, 6.0))
+        # every rank holds the same bits (the sum is formed once per slice and distributed)
+        for r in range(1, world):
+            assert np.array_equal(res[r][(M, False)][0], res[0][(M, False)][0])

@@ -22,7 +22,7 @@ def _load(golden_dir, name):
     return dict(np.load(os.path.join(golden_dir, name), allow_pickle=False))
 
 
-@pytest.mark.parametrize("name", ["pinhole", "radial"])
+@pytest.mark.parametrize("name", ["pinhole", "radial", "radial2", "opencv4"])
 def test_project_and_cam_from_img_golden(golden_dir, name):
     g = _load(golden_dir, f"geom_{name}.npz")
     extra = g.get("extra_params")
@@ -39,7 +39,7 @@ def test_project_and_cam_from_img_golden(golden_dir, name):
     np.testing.assert_allclose(tn, g["tracks_normalized"], rtol=1e-9, atol=1e-12)
 
 
-@pytest.mark.parametrize("name", ["pinhole", "radial"])
+@pytest.mark.parametrize("name", ["pinhole", "radial", "radial2", "opencv4"])
 @pytest.mark.parametrize("chk", [0, 1])
 @pytest.mark.parametrize("thr", [4, 1])
 def test_filter_golden_bit_exact(golden_dir, name, chk, thr):

@@ -7,15 +7,19 @@ independent.  Every residual touches exactly one point, so V_p, g_p, the Schur c
 back-substitution of a point are rank-local; what couples the ranks is only the camera side:
 
   phase 0 LINEARIZE  local U_c = sum F^T F, g_c = sum F^T r, cost        -> all-reduce SUM  (C*(BD^2+BD+1) doubles)
-  phase 1 SCHUR      local reduced system S, rhs of the rank's points     -> all-reduce SUM  (packed lower triangle
-                                                                              + rhs: n(n+1)/2 + n doubles)
-                     local max |g_p|                                       -> all-reduce MAX  (1 double)
+  phase 1 SCHUR      local reduced system S, rhs of the rank's points     -> REDUCE-SCATTER + ALL-GATHER of the packed lower
+                     local max |g_p|                                          triangle + rhs (n(n+1)/2 + n doubles: every rank
+                                                                              sums 1/N of it, then the slices go round; on the
+                                                                              point-to-point xGMI mesh that keeps all 7 links of
+                                                                              a GPU busy); the local maxima ride in
+                                                                              the gather (one slot per rank) -- no MAX collective
   phase 2 STEP       every rank factors S redundantly, back-substitutes its points,
                      local candidate cost / model change / step norm       -> all-reduce SUM  (4 doubles)
   phase 3 UPDATE     identical trust-region decision on every rank
 
-One process per GPU, ``torch.distributed`` backend "nccl" (= RCCL over xGMI on ROCm).  The collectives run
-on the same stream as the kernels, so the host never synchronises inside the loop.
+Three collectives per LM iteration (round 2: four, the big one a plain all-reduce).  One process per GPU,
+``torch.distributed`` backend "nccl" (= RCCL over xGMI on ROCm).  The collectives run on the same stream as the
+kernels, so the host never synchronises inside the loop.
 """
 import ctypes
 
@@ -49,10 +53,64 @@ def shard_slice(tracks, masks, points3d, rank, world_size):
     return tracks[:, lo:hi], masks[:, lo:hi], points3d[lo:hi], (lo, hi)
 
 
+class Collectives:
+    """The three exchanges of one LM iteration over ``torch.distributed``.
+
+    `system_(packed, local_max)`: SUM of the packed reduced system over the ranks, in place, and MAX of the one-element
+    `local_max`, in place: the payload is padded to N equal slices, reduce-scattered, and all-gathered with each rank's
+    local maximum appended to its slice (RCCL on the GPU box; gloo implements both calls too, which is how the CPU tests
+    run this very code).  `plain_all_reduce=True` keeps the round-2 form -- two all-reduces -- for A/B measurements."""
+
+    def __init__(self, world_size, group=None, plain_all_reduce=False):
+        import torch.distributed as dist
+        self.dist, self.world, self.group = dist, world_size, group
+        self.scatter = not plain_all_reduce
+        self._bufs = {}
+
+    def sum_(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def system_(self, packed, local_max):
+        dist, W = self.dist, self.world
+        if not self.scatter:
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(local_max, op=dist.ReduceOp.MAX, group=self.group)
+            return
+        M = packed.numel()
+        chunk = -(-M // W)
+        key = (M, packed.device)
+        if key not in self._bufs:
+            self._bufs[key] = (torch.zeros(W * chunk, dtype=packed.dtype, device=packed.device),
+                               torch.empty(chunk + 1, dtype=packed.dtype, device=packed.device),
+                               torch.empty(W * (chunk + 1), dtype=packed.dtype, device=packed.device))
+        padded, mine, gathered = self._bufs[key]
+        padded[:M].copy_(packed)                                  # (the tail stays zero)
+        dist.reduce_scatter_tensor(mine[:chunk], padded, op=dist.ReduceOp.SUM, group=self.group)
+        mine[chunk:].copy_(local_max[:1])
+        dist.all_gather_into_tensor(gathered, mine, group=self.group)
+        g = gathered.view(W, chunk + 1)
+        packed.copy_(g[:, :chunk].reshape(-1)[:M])
+        local_max[:1].copy_(g[:, chunk].max().reshape(1))
+
+
+class _FunctionCollectives:
+    """Adapter for a caller-supplied ``all_reduce(tensor, "sum" | "max")`` (tests, lock-step emulation)."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def sum_(self, t):
+        self.fn(t, "sum")
+
+    def system_(self, packed, local_max):
+        self.fn(packed, "sum")
+        self.fn(local_max, "max")
+
+
 class ShardedBA:
     """LM loop of one rank's DeviceProblem with the collectives interleaved (also used with world_size 1)."""
 
-    def __init__(self, problem, options=None, rank=0, world_size=1, all_reduce=None):
+    def __init__(self, problem, options=None, rank=0, world_size=1, all_reduce=None, collectives=None):
         self.L = _lib.lib()
         self.problem = problem
         self.options = options or BundleAdjustmentOptions()
@@ -74,12 +132,9 @@ class ShardedBA:
                                                    ctypes.byref(p), ctypes.byref(cnt)), "vgg_ba_reduce_buffer")
             off = ctypes.addressof(p.contents) - self.ws.data_ptr()
             self.bufs.append(self.ws[off:off + 8 * cnt.value].view(torch.float64))
-        if all_reduce is None and world_size > 1:
-            import torch.distributed as dist
-
-            def all_reduce(t, op):
-                dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
-        self._all_reduce = all_reduce
+        if collectives is None and world_size > 1:
+            collectives = _FunctionCollectives(all_reduce) if all_reduce is not None else Collectives(world_size)
+        self.coll = collectives
 
     def begin(self):
         _lib.check(self.L.vgg_ba_begin(ctypes.byref(self.cp), ctypes.byref(self.co), _lib.ptr(self.ws),
@@ -90,19 +145,18 @@ class ShardedBA:
                                        _lib.stream_ptr()), "vgg_ba_phase")
 
     def iteration(self):
-        ar = self._all_reduce if self.world > 1 else None
+        co = self.coll if self.world > 1 else None
         self._phase(0)
-        if ar:
-            ar(self.bufs[0], "sum")
+        if co:
+            co.sum_(self.bufs[0])
         self._phase(1)
-        if ar:
+        if co:
             self._phase(4)                      # lower triangle + rhs -> packed buffer (half the payload)
-            ar(self.bufs[4], "sum")
+            co.system_(self.bufs[4], self.bufs[2])
             self._phase(5)
-            ar(self.bufs[2], "max")
         self._phase(2)
-        if ar:
-            ar(self.bufs[3], "sum")
+        if co:
+            co.sum_(self.bufs[3])
         self._phase(3)
 
     def finish(self, log_cap=0):

@@ -143,18 +143,17 @@ def build_reconstruction(points3D, extrinsics, intrinsics, extra_params, pred_tr
 
 
 def find_best_initial_pair(inlier_geo_vis, cheirality_mask_pair, triangle_value_pair, init_tri_angle_thres):
-    """Reference: triangulator.py:442-476: halve the angle threshold (at most 5 times) until some pair has
-    >= 100 inliers and >= 25 % of the tracks."""
-    trial_count = 0
-    N = inlier_geo_vis.shape[-1]
-    while trial_count < 5:
-        triangle_mask = triangle_value_pair >= init_tri_angle_thres
-        inlier_total = torch.logical_and(torch.logical_and(inlier_geo_vis, cheirality_mask_pair), triangle_mask)
-        max_num_inlier = inlier_total.sum(dim=-1).max()
-        if (max_num_inlier >= 100) and (max_num_inlier / N >= 0.25):
+    """Same contract as the reference's triangulator.py:442-476: relax the triangulation-angle threshold by integer
+    halving until the best frame pair keeps >= 100 inliers that are >= a quarter of all tracks -- at most five halvings,
+    and none once the threshold is below 2.  Returns the pair-inlier mask of the LAST threshold that was evaluated and the
+    threshold after the last halving (after five unsuccessful rounds those differ by one halving, as in the reference)."""
+    n_tracks = inlier_geo_vis.shape[-1]
+    eligible = inlier_geo_vis & cheirality_mask_pair
+    thres = init_tri_angle_thres
+    for _ in range(5):
+        candidates = eligible & (triangle_value_pair >= thres)
+        best = int(candidates.sum(dim=-1).max())
+        if (best >= 100 and 4 * best >= n_tracks) or thres < 2:
             break
-        if init_tri_angle_thres < 2:
-            break
-        init_tri_angle_thres = init_tri_angle_thres // 2
-        trial_count += 1
-    return inlier_total, init_tri_angle_thres
+        thres = thres // 2
+    return candidates, thres

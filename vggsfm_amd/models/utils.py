@@ -6,23 +6,19 @@ from ..utils.triangulation_helpers import create_intri_matrix
 
 
 def get_EFP(pred_cameras, image_size, B, S, default_focal=False):
-    """PerspectiveCameras (any object with .R (S,3,3), .T (S,3), .focal_length (S,2) in NDC) ->
-    extrinsics (B,S,3,4), intrinsics (B,S,3,3); one-dof focal, principal point at the image centre.
-    Reference: vggsfm/models/utils.py:38-72."""
-    scale = image_size.min()
-    focal_length = pred_cameras.focal_length
-    principal_point = torch.zeros_like(focal_length)
-    focal_length = focal_length * scale / 2
-    principal_point = (image_size[None] - principal_point * scale) / 2
-    extrinsics = torch.cat([pred_cameras.R.clone(), pred_cameras.T.clone()[..., None]], dim=-1).reshape(B, S, 3, 4)
-    focal_length = focal_length.reshape(B, S, 2)
-    principal_point = principal_point.reshape(B, S, 2)
+    """Same contract as the reference's vggsfm/models/utils.py:38-72.  `pred_cameras`: anything with .R (B S,3,3),
+    .T (B S,3), .focal_length (B S,2) in NDC units of the short image side -> extrinsics (B,S,3,4) and intrinsics
+    (B,S,3,3) in pixels with ONE focal length per frame (the mean of fx, fy, kept inside [0.2, 5] x short side; exactly
+    the short side with `default_focal`) and the principal point at the image centre."""
+    short = image_size.min()
+    pose = torch.cat([pred_cameras.R, pred_cameras.T.unsqueeze(-1)], dim=-1).reshape(B, S, 3, 4).clone()
     if default_focal:
-        focal_length = torch.full_like(focal_length, float(scale))
+        one_f = torch.full((B, S, 1), float(short), dtype=pred_cameras.focal_length.dtype, device=pred_cameras.focal_length.device)
     else:
-        focal_length = focal_length.mean(dim=-1, keepdim=True).expand(-1, -1, 2)
-        focal_length = focal_length.clamp(0.2 * scale, 5 * scale)
-    return extrinsics, create_intri_matrix(focal_length, principal_point)
+        f_px = pred_cameras.focal_length.reshape(B, S, 2) * (short / 2)
+        one_f = f_px.mean(dim=-1, keepdim=True).clamp(0.2 * short, 5 * short)
+    centre = (image_size / 2).to(one_f.dtype).expand(B, S, 2)
+    return pose, create_intri_matrix(one_f.expand(B, S, 2), centre)
 
 
 def sample_features4d(input, coords):

@@ -26,34 +26,36 @@ from .utils.triangulation_helpers import cam_from_img, filter_all_points3D
 
 
 def align_camera_extrinsics(cameras_src, cameras_tgt, estimate_scale=True, eps=1e-9):
-    """utils/align.py:145-205.  (B,3,4) x (B,3,4) -> (align_R (1,3,3), align_T (1,3), align_s): the similarity
-    that maps the source cameras onto the target ones (OpenCV convention, x_cam = R X + t).  B is a window
-    (<= 33 frames): plain torch ops, no kernel."""
-    R_src, R_tgt = cameras_src[:, :, :3], cameras_tgt[:, :, :3]
-    RRcov = torch.bmm(R_tgt.transpose(2, 1), R_src).mean(0)
-    U, _, Vh = torch.linalg.svd(RRcov)
-    align_R = Vh.transpose(0, 1) @ U.t()
-    T_src, T_tgt = cameras_src[:, :, 3], cameras_tgt[:, :, 3]
-    A = torch.bmm(T_src[:, None], R_src)[:, 0]
-    B = torch.bmm(T_tgt[:, None], R_src)[:, 0]
-    Amu, Bmu = A.mean(0, keepdim=True), B.mean(0, keepdim=True)
-    if estimate_scale and A.shape[0] > 1:
-        Ac, Bc = A - Amu, B - Bmu
-        align_s = (Ac * Bc).mean() / (Ac ** 2).mean().clamp(eps)
-    else:
-        align_s = 1.0
-    align_T = Bmu - align_s * Amu
-    return align_R[None], align_T, align_s
+    """Same contract as the reference's utils/align.py:145-205: (B,3,4) source and target cameras (x_cam = R X + t) ->
+    (align_R (1,3,3), align_T (1,3), align_s) such that `apply_transformation` carries the source set onto the target.
+
+    Derivation used here.  Rotation: the orthogonal Q maximising sum_i tr(Q^T R_tgt,i^T R_src,i) is the polar factor of
+    M = mean_i R_tgt,i^T R_src,i; with M = U S V^T that is Q = V U^T.  Translation / scale: a camera's pose in ITS OWN
+    source frame, p_i = R_src,i^T t_src,i (minus its centre), and the target translation seen from the same frame,
+    q_i = R_src,i^T t_tgt,i, are related by q_i ~ s p_i + T; s is the one-dimensional least-squares slope over all 3 B
+    coordinates of the centred sets, T the offset of the means.  B is a window (<= 33 frames): torch ops, no kernel."""
+    rot_s, rot_t = cameras_src[..., :3], cameras_tgt[..., :3]
+    m = torch.einsum("bji,bjk->ik", rot_t, rot_s) / rot_s.shape[0]
+    u, _, vh = torch.linalg.svd(m)
+    q = vh.t() @ u.t()
+    p_own = torch.einsum("bji,bj->bi", rot_s, cameras_src[..., 3])
+    q_own = torch.einsum("bji,bj->bi", rot_s, cameras_tgt[..., 3])
+    p_mean, q_mean = p_own.mean(0, keepdim=True), q_own.mean(0, keepdim=True)
+    slope = 1.0
+    if estimate_scale and p_own.shape[0] > 1:
+        dp, dq = p_own - p_mean, q_own - q_mean
+        slope = (dp * dq).mean() / dp.square().mean().clamp(eps)
+    return q[None], q_mean - slope * p_mean, slope
 
 
 def apply_transformation(cameras_src, align_R, align_T, align_s, return_extri=True):
-    """utils/align.py:208-252."""
-    R_src, T_src = cameras_src[:, :, :3], cameras_src[:, :, 3]
-    aligned_R = torch.bmm(R_src, align_R.expand(R_src.shape[0], 3, 3))
-    aligned_T = torch.bmm(R_src, align_T[..., None].repeat(R_src.shape[0], 1, 1))[..., 0] + T_src * align_s
+    """utils/align.py:208-252: R_i <- R_i Q, t_i <- R_i T + s t_i for the (Q, T, s) of `align_camera_extrinsics`."""
+    rot = cameras_src[..., :3]
+    new_rot = rot @ align_R.reshape(3, 3)
+    new_t = torch.einsum("bij,j->bi", rot, align_T.reshape(3)) + align_s * cameras_src[..., 3]
     if return_extri:
-        return torch.cat([aligned_R, aligned_T.unsqueeze(-1)], dim=-1)
-    return aligned_R, aligned_T
+        return torch.cat([new_rot, new_t[..., None]], dim=-1)
+    return new_rot, new_t
 
 
 def filter_points_and_compute_masks(points, tracks, extrinsics, intrinsics, extra_params=None, min_valid_track_length=3,

@@ -38,3 +38,14 @@ for name, k in (("issue", 1), ("matrix", 2), ("lds write", 3), ("barrier", 4), (
 for w in range(4):
     print("wave", w, {name: round(float((t[:, w, k] / np.maximum(nb[:, w], 1)).mean())) for name, k in
                       (("issue", 1), ("matrix", 2), ("write", 3), ("barrier", 4))})
+# where does the spread between workgroups come from?  by XCD (launch position mod 8) and by launch position
+tot = t[:, :, 6].mean(1) / 100e6 * 1e3                               # wall ms per workgroup
+print("wall ms per workgroup: min %.3f p10 %.3f median %.3f p90 %.3f max %.3f" % (
+    tot.min(), np.percentile(tot, 10), np.median(tot), np.percentile(tot, 90), tot.max()))
+print("by XCD (position mod 8):", [round(float(tot[x::8].mean()), 3) for x in range(8)])
+print("by position octile:", [round(float(tot[i * 96:(i + 1) * 96].mean()), 3) for i in range(8)])
+print("batches by position octile:", [round(float(nb[i * 96:(i + 1) * 96].mean()), 1) for i in range(8)])
+per_batch = t[:, :, 5].mean(1) / np.maximum(nb.mean(1), 1)
+print("cycles per batch by position octile:", [round(float(per_batch[i * 96:(i + 1) * 96].mean())) for i in range(8)])
+mat = t[:, :, 2].mean(1) / np.maximum(nb.mean(1), 1)
+print("matrix-phase cycles per batch by position octile:", [round(float(mat[i * 96:(i + 1) * 96].mean())) for i in range(8)])

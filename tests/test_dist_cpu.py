@@ -196,3 +196,15 @@ def test_gloo_world3_reduce_scatter_all_gather_equals_all_reduce():
         # every rank holds the same bits (the sum is formed once per slice and distributed)
         for r in range(1, world):
             assert np.array_equal(res[r][(M, False)][0], res[0][(M, False)][0])
+
+
+def test_chunk_ranges_cover_every_chunk_once():
+    from vggsfm_amd.dist import chunk_ranges
+    from vggsfm_amd.utils.triangulation import reference_chunks
+    assert reference_chunks(200, 100000) == (4000, 25) and reference_chunks(8, 6000) == (6000, 1)
+    assert reference_chunks(400, 300000)[1] == 147                       # serial chunks at configs[3]
+    for nc in (1, 7, 25, 147):
+        for w in (1, 2, 8, 16):
+            b = chunk_ranges(nc, w)
+            assert b[0] == 0 and b[-1] == nc and all(x <= y for x, y in zip(b, b[1:])) and len(b) == w + 1
+            assert max(y - x for x, y in zip(b, b[1:])) - min(y - x for x, y in zip(b, b[1:])) <= 1

@@ -109,3 +109,42 @@ def test_sharded_solve_stops_enqueuing_after_termination():
     assert out["final_cost"] == ref["final_cost"]
     assert calls[0] <= ref["num_iterations"] + 1 + ShardedBA.POLL
     assert torch.equal(prob.pts, prob2.pts) and torch.equal(prob.cam_t, prob2.cam_t)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_triangulation_and_filter_equal_single_rank(world):
+    """dist.triangulate_tracks_sharded / filter_all_points3D_sharded: the ranks share the work by whole reference chunks
+    (every rank consumes the RNG draws of all chunks) resp. by point ranges; concatenated in rank order the results are the
+    single-rank results BIT FOR BIT (inlier counts, masks, points).  The ranks run one after the other in this process
+    (gather=False: no communicator needed)."""
+    from vggsfm_amd import dist as DI
+    from vggsfm_amd.utils import triangulation as T
+    from vggsfm_amd.utils import triangulation_helpers as H
+    sc = make_scene(30, 700, "SIMPLE_RADIAL", shared_camera=True, seed=41, outlier_frac=0.1)
+    ext, K, xp = D(sc.extrinsics), D(sc.intrinsics), D(sc.extra_params)
+    tracks, vis, score = D(sc.tracks), D(sc.vis), D(sc.score)
+    tn = H.cam_from_img(tracks, K, xp)
+    kw = dict(max_tri_points_num=30 * 100)                           # 7 reference chunks of 100 tracks
+    torch.manual_seed(5)
+    p_ref, n_ref, m_ref = T.triangulate_tracks(ext, tn, track_vis=vis, track_score=score, **kw)
+    parts = []
+    for r in range(world):
+        torch.manual_seed(5)                                          # every rank is seeded alike
+        p, n, m, (lo, hi) = DI.triangulate_tracks_sharded(ext, tn, r, world, track_vis=vis, track_score=score, gather=False, **kw)
+        assert p.shape[0] == hi - lo
+        parts.append((p, n, m, lo, hi))
+    assert parts[0][3] == 0 and parts[-1][4] == 700 and all(a[4] == b[3] for a, b in zip(parts, parts[1:]))
+    assert torch.equal(torch.cat([a[1] for a in parts]), n_ref) and torch.equal(torch.cat([a[2] for a in parts]), m_ref)
+    assert torch.equal(torch.cat([a[0] for a in parts]), p_ref)
+    # more ranks than chunks: the surplus ranks get an empty range
+    torch.manual_seed(5)
+    p, n, m, rng = DI.triangulate_tracks_sharded(ext, tn, 0, 16, track_vis=vis, track_score=score, gather=False, **kw)
+    assert p.shape[0] == rng[1] - rng[0] == 0
+    # filter
+    fm, fd = H.filter_all_points3D(p_ref, tracks, ext, K, xp, max_reproj_error=4, return_detail=True)
+    masks, dets = [], []
+    for r in range(world):
+        (mk, dt), _ = DI.filter_all_points3D_sharded(p_ref, tracks, ext, K, r, world, extra_params=xp, gather=False,
+                                                     max_reproj_error=4, return_detail=True)
+        masks.append(mk), dets.append(dt)
+    assert torch.equal(torch.cat(masks), fm) and torch.equal(torch.cat(dets, 1), fd)

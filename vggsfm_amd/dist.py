@@ -53,6 +53,63 @@ def shard_slice(tracks, masks, points3d, rank, world_size):
     return tracks[:, lo:hi], masks[:, lo:hi], points3d[lo:hi], (lo, hi)
 
 
+def chunk_ranges(num_chunks, world_size):
+    """Contiguous, near-equal ranges of the reference's track chunks for the ranks: (world_size + 1,) boundaries."""
+    return [(num_chunks * r) // world_size for r in range(world_size + 1)]
+
+
+def _gather_rows(local, counts, group=None):
+    """all-gather of per-rank row blocks of different lengths (counts known on every rank) -> concatenation in rank order."""
+    import torch.distributed as dist
+    cap = max(counts) if counts else 0
+    if cap == 0:
+        return local
+    pad = torch.zeros((cap,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in counts]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[:c] for p, c in zip(parts, counts)])
+
+
+def triangulate_tracks_sharded(extrinsics, tracks_normalized, rank, world_size, track_vis=None, track_score=None, gather=True,
+                               group=None, **kw):
+    """`triangulate_tracks` with the track axis shared by the ranks ("shard with no collective").  The unit is
+    the reference's own chunk (triangulation.py:712-758: one randperm draw and one chunk-global indicator threshold per
+    chunk), so every rank -- seeded alike -- draws the pairs of all chunks and triangulates a contiguous range of them: the
+    concatenation over the ranks is bit for bit the single-rank result.  configs[2] has 25 chunks, configs[3] 147.
+    gather=True: all-gather of points / inlier counts / masks (the only communication); False: the rank's own slice and
+    its track range."""
+    from .utils.triangulation import reference_chunks, triangulate_tracks
+    S, N = tracks_normalized.shape[0], tracks_normalized.shape[1]
+    chunk_size, num_chunks = reference_chunks(S, N, kw.get("max_tri_points_num", 819200))
+    b = chunk_ranges(num_chunks, world_size)
+    pts, num, msk = triangulate_tracks(extrinsics, tracks_normalized, track_vis=track_vis, track_score=track_score,
+                                       chunk_range=(b[rank], b[rank + 1]), **kw)
+    if not gather or world_size == 1:
+        return pts, num, msk, (min(N, b[rank] * chunk_size), min(N, b[rank + 1] * chunk_size))
+    counts = [min(N, b[r + 1] * chunk_size) - min(N, b[r] * chunk_size) for r in range(world_size)]
+    return (_gather_rows(pts, counts, group), _gather_rows(num, counts, group),
+            _gather_rows(msk.to(torch.uint8), counts, group).bool(), (0, N))
+
+
+def filter_all_points3D_sharded(points3D, points2D, extrinsics, intrinsics, rank, world_size, extra_params=None, gather=True,
+                                group=None, **kw):
+    """`filter_all_points3D` on the rank's contiguous slice of the points (per-point work, any split gives the same
+    masks); gather=True: all-gather of the masks."""
+    from .utils.triangulation_helpers import filter_all_points3D
+    P = points3D.shape[0]
+    b = [(P * r) // world_size for r in range(world_size + 1)]
+    lo, hi = b[rank], b[rank + 1]
+    mask, det = filter_all_points3D(points3D[lo:hi], points2D[:, lo:hi], extrinsics, intrinsics, extra_params=extra_params, **kw)
+    if not gather or world_size == 1:
+        return (mask, det), (lo, hi)
+    counts = [b[r + 1] - b[r] for r in range(world_size)]
+    mask = _gather_rows(mask.to(torch.uint8), counts, group).bool()
+    if det is not None:
+        det = _gather_rows(det.t().contiguous().to(torch.uint8), counts, group).t().bool()
+    return (mask, det), (0, P)
+
+
 class Collectives:
     """The three exchanges of one LM iteration over ``torch.distributed``.
 

@@ -65,8 +65,17 @@ def _draw_pairs(S, max_ransac_iters, lo_num):
     return ransac_idx, lo_num
 
 
+def reference_chunks(S, N, max_tri_points_num=819200):
+    """(chunk_size, num_chunks) of the reference's torch.chunk split of the track axis (triangulation.py:712-723)."""
+    num_splits = 1
+    if S * N > max_tri_points_num:
+        num_splits = (S * N + max_tri_points_num - 1) // max_tri_points_num
+    chunk_size = -(-N // num_splits) if N > 0 else 1                  # torch.chunk: ceil(N / chunks) per chunk
+    return chunk_size, max(1, -(-N // chunk_size))
+
+
 def triangulate_tracks(extrinsics, tracks_normalized, max_ransac_iters=256, lo_num=50, max_angular_error=2,
-                       min_tri_angle=1.5, track_vis=None, track_score=None, max_tri_points_num=819200):
+                       min_tri_angle=1.5, track_vis=None, track_score=None, max_tri_points_num=819200, chunk_range=None):
     """Reference: triangulation.py:677-773.  extrinsics (S,3,4), tracks_normalized (S,N,2), vis/score (S,N)
     -> points (N,3) f64, inlier_num (N) int64, inlier_mask (N,S) bool.
     The reference splits the track axis into ceil(S*N/max_tri_points_num) chunks (torch.chunk), each with its own
@@ -74,7 +83,11 @@ def triangulate_tracks(extrinsics, tracks_normalized, max_ransac_iters=256, lo_n
     front, in chunk order, from the same global CPU RNG -- but all chunks run in ONE launch
     (`vgg_triangulate_tracks_chunks`): the kernel has no memory reason to chunk.
     Kernel limits (include/vggsfm_amd.h): max_ransac_iters <= 256 hypotheses per track, lo_num <= 64 (the reference's
-    call sites use 256 / 128 and 50)."""
+    call sites use 256 / 128 and 50).
+    chunk_range = (c0, c1): only the reference chunks c0 .. c1-1 are triangulated and the results cover just their tracks
+    [c0 chunk_size, min(N, c1 chunk_size)) -- the RNG draws of ALL chunks are still consumed, in order, so that ranks which
+    share the work by whole chunks (vggsfm_amd.dist.triangulate_tracks_sharded) reproduce the single-rank result bit for
+    bit."""
     if max_ransac_iters > 256 or lo_num > 64 or max_ransac_iters < 1 or lo_num < 1:
         raise ValueError(f"triangulate_tracks: max_ransac_iters={max_ransac_iters} (1..256) / lo_num={lo_num} (1..64) are outside "
                          "what vgg_triangulate_tracks_chunks supports (the reference calls it with 256 or 128, and 50)")
@@ -82,14 +95,20 @@ def triangulate_tracks(extrinsics, tracks_normalized, max_ransac_iters=256, lo_n
     L = _lib.lib()
     S, N = tracks_normalized.shape[0], tracks_normalized.shape[1]
     dev = tracks_normalized.device
-    all_tri_points_num = S * N
-    num_splits = 1
-    if all_tri_points_num > max_tri_points_num:
-        num_splits = (all_tri_points_num + max_tri_points_num - 1) // max_tri_points_num
-    chunk_size = -(-N // num_splits) if N > 0 else 1                  # torch.chunk: ceil(N / chunks) per chunk
-    num_chunks = max(1, -(-N // chunk_size))
+    chunk_size, num_chunks = reference_chunks(S, N, max_tri_points_num)
     draws = [_draw_pairs(S, max_ransac_iters, lo_num) for _ in range(num_chunks)]     # RNG consumed in chunk order
     lo = draws[0][1]
+    if chunk_range is not None:
+        c0, c1 = max(0, int(chunk_range[0])), min(num_chunks, int(chunk_range[1]))
+        t0, t1 = min(N, c0 * chunk_size), min(N, c1 * chunk_size)
+        draws = draws[c0:c1]
+        tracks_normalized = tracks_normalized[:, t0:t1]
+        track_vis = None if track_vis is None else track_vis[:, t0:t1]
+        track_score = None if track_score is None else track_score[:, t0:t1]
+        N, num_chunks = t1 - t0, max(1, c1 - c0)
+        if not draws:                                 # a rank without a chunk
+            return (torch.empty((0, 3), dtype=torch.float64, device=dev), torch.empty(0, dtype=torch.int64, device=dev),
+                    torch.empty((0, S), dtype=torch.bool, device=dev))
     pairs = torch.stack([d[0] for d in draws]).to(device=dev, dtype=torch.int32).contiguous()      # (C,H,2)
     H = pairs.shape[1]
     if track_score is not None:

@@ -421,7 +421,9 @@ class Point3D:
 
     @property
     def xyz(self):
-        return self._rec._xyz[self._pid - 1]
+        # a COPY, as pycolmap returns (`p = rec.points3D[i].xyz; p *= s` must not edit the model; a view would also be
+        # orphaned by the next _reserve()); writes go through the setter
+        return self._rec._xyz[self._pid - 1].copy()
 
     @xyz.setter
     def xyz(self, v):
@@ -429,7 +431,7 @@ class Point3D:
 
     @property
     def color(self):
-        return self._rec._rgb[self._pid - 1]
+        return self._rec._rgb[self._pid - 1].copy()
 
     @color.setter
     def color(self, v):
@@ -1019,6 +1021,8 @@ class BundleAdjuster:
         self.reconstruction, self.problem = None, None
 
     def set_up_problem(self, reconstruction, loss_function=None):
+        if self.config.constant_cam_positions:           # (loud at set-up, not only when the solve runs)
+            raise NotImplementedError("BundleAdjustmentConfig.set_constant_cam_positions is not used by the reference")
         self.reconstruction = reconstruction
         if loss_function is not None and isinstance(loss_function, tuple):
             self.options.loss_function_type, self.options.loss_function_scale = loss_function
@@ -1034,8 +1038,18 @@ class BundleAdjuster:
         cfg = self.config
         if cfg.constant_cam_positions:
             raise NotImplementedError("BundleAdjustmentConfig.set_constant_cam_positions is not used by the reference")
-        return _solve(self.reconstruction, opts, cfg.image_ids, cfg.constant_point3D_ids, sorted(cfg.constant_cam_poses),
-                      default_gauge=False)
+        # COLMAP BundleAdjuster::SetUp: a point whose track has observations in images OUTSIDE the config is held constant
+        # (its track length exceeds its observations inside the problem) unless it was named with add_variable_point.  The
+        # reference's call sites put every registered image into the config (video_runner.py:817-829), where this selects
+        # nothing.  (Deviation for configs that do leave images out: COLMAP also adds a variable point's observations in those
+        # images, with their poses constant; here they are not part of the problem.)
+        rec = self.reconstruction
+        ptr, timg, _ = rec._track_csr()
+        inside = np.isin(timg, np.asarray(cfg.image_ids, np.int64))
+        pid_of_obs = np.repeat(np.arange(1, len(ptr)), np.diff(ptr))
+        partly_outside = np.unique(pid_of_obs[~inside])
+        constant = set(cfg.constant_point3D_ids) | ({int(p) for p in partly_outside} - set(cfg.variable_point3D_ids))
+        return _solve(rec, opts, cfg.image_ids, constant, sorted(cfg.constant_cam_poses), default_gauge=False)
 
     def solve(self, reconstruction):
         self.set_up_problem(reconstruction)

@@ -136,7 +136,7 @@ class GeometryRunner:
         predictions = {}
         if image_paths is None:
             image_paths = [f"image_{s}" for s in range(S)]
-        _, preliminary_dict = estimate_preliminary_cameras(pred_track, pred_vis, W, H, tracks_score=pred_score,
+        _, preliminary_dict = estimate_preliminary_cameras(pred_track, pred_vis, W, H, tracks_score=pred_score, decompose=False,
                                                            max_error=cfg.fmat_thres, loopresidual=True,
                                                            max_ransac_iters=cfg.max_ransac_iters, lo_num=cfg.lo_num)
         (extrinsics_opencv, intrinsics_opencv, extra_params, points3D, points3D_rgb, reconstruction, valid_frame_mask,

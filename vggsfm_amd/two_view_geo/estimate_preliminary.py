@@ -118,8 +118,11 @@ def _pytorch3d_cameras(R_opencv, t_opencv):
 
 def estimate_preliminary_cameras(tracks, tracks_vis, width, height, tracks_score=None, max_error=0.5, lo_num=300,
                                  max_ransac_iters=4096, predict_essential=False, predict_homo=False, loopresidual=False,
-                                 samples=None):
-    """tracks (B,S,N,2), tracks_vis (B,S,N) [, tracks_score (B,S,N)] -> (pred_cameras, preliminary_dict)."""
+                                 samples=None, decompose=True):
+    """tracks (B,S,N,2), tracks_vis (B,S,N) [, tracks_score (B,S,N)] -> (pred_cameras, preliminary_dict).
+    decompose=False: only the fundamental-matrix part of the dictionary (`fmat*`) and pred_cameras = None -- the runners
+    discard the cameras (runner.py:487-499 keeps `fmat_inlier_mask` alone), and the essential-matrix SVD, the four
+    cheirality triangulations and their host synchronisation are then not paid for."""
     B, S, N, _ = tracks.shape
     query = tracks[:, 0:1].expand(-1, S - 1, -1, -1).reshape(B * (S - 1), N, 2)
     ref = tracks[:, 1:].reshape(B * (S - 1), N, 2)
@@ -129,6 +132,10 @@ def estimate_preliminary_cameras(tracks, tracks_vis, width, height, tracks_score
     fmat, num, mask, res = estimate_fundamental(query, ref, max_ransac_iters=max_ransac_iters, max_error=max_error,
                                                 lo_num=lo_num, valid_mask=valid, loopresidual=loopresidual,
                                                 return_residuals=True, samples=samples)
+    out = {"fmat": fmat.reshape(B, S - 1, 3, 3), "fmat_inlier_mask": mask.reshape(B, S - 1, N),
+           "fmat_inlier_num": num.reshape(B, S - 1), "fmat_residuals": res.reshape(B, S - 1, N)}
+    if not decompose:
+        return None, out
     kmat1, kmat2, fl, pp = build_default_kmat(width, height, B, S, N, device=tracks.device, dtype=torch.float64)
     emat = essential_from_fundamental(fmat.to(torch.float64), kmat1, kmat2)
     Rs, Ts = decompose_essential_matrix(emat)
@@ -137,7 +144,5 @@ def estimate_preliminary_cameras(tracks, tracks_vis, width, height, tracks_score
     R_opencv = torch.cat([eye, R_sel.reshape(B, S - 1, 3, 3)], dim=1)
     t_opencv = torch.cat([torch.zeros((B, 1, 3), dtype=torch.float64, device=tracks.device), t_sel.reshape(B, S - 1, 3)], dim=1)
     pred_cameras = _pytorch3d_cameras(R_opencv.reshape(B * S, 3, 3), t_opencv.reshape(B * S, 3))
-    return pred_cameras, {"fmat": fmat.reshape(B, S - 1, 3, 3), "fmat_inlier_mask": mask.reshape(B, S - 1, N),
-                          "fmat_inlier_num": num.reshape(B, S - 1), "fmat_residuals": res.reshape(B, S - 1, N),
-                          "R_opencv": R_opencv, "t_opencv": t_opencv, "default_intri": kmat1.reshape(B, S - 1, 3, 3),
-                          "emat_fromf": emat}
+    out.update({"R_opencv": R_opencv, "t_opencv": t_opencv, "default_intri": kmat1.reshape(B, S - 1, 3, 3), "emat_fromf": emat})
+    return pred_cameras, out

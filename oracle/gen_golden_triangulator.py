@@ -42,7 +42,12 @@ CASES = {
     # the camera model of BASELINE configs[3] (per-frame SIMPLE_RADIAL: 8 x 8 camera blocks, 128 x 128 Schur tiles) at 120
     # frames x 2000 tracks (compact)
     "radial_s120": (120, 2000, "SIMPLE_RADIAL", False, 37, dict(BA_iters=1, robust_refine=1)),
+    # the `force_estimate` branch of refine_pose (triangulation.py:406-432): frames 6 and 8 see fewer than 100 tracks, so the
+    # last robust-refine round re-estimates them with absolute_pose_estimation -- the shim's deterministic restatement of the
+    # device pipeline (oracle/pycolmap_shim.py ESTIMATION), its uniform draws recorded per frame for the GPU test to replay
+    "pinhole_s10_estimate": (10, 600, "SIMPLE_PINHOLE", False, 38, dict(BA_iters=1, robust_refine=2)),
 }
+ESTIMATE_CASES = {"pinhole_s10_estimate": (6, 8)}       # frames whose visibility is cut down to ~80 tracks
 COMPACT = {"pinhole_s50_c2", "radial_shared_s200", "radial_s120"}
 
 
@@ -54,8 +59,13 @@ def input_digest(inp):
     return h.hexdigest()
 
 
-def inputs(S, N, cam, shared, seed, W=1024):
-    sc = make_scene(S, N, cam, shared_camera=shared, seed=seed, outlier_frac=0.03)
+def inputs(S, N, cam, shared, seed, W=1024, sparse_frames=()):
+    sc = make_scene(S, N, cam, shared_camera=shared, seed=seed, outlier_frac=0.03, full_visibility=bool(sparse_frames))
+    for k, f in enumerate(sparse_frames):                 # only every 7th / 8th track stays visible in these frames
+        keep = np.zeros(N, bool)
+        keep[k::7 + k] = True
+        sc.vis[f, ~keep] = 0.0
+        sc.mask[f, ~keep] = False
     ext0, K0, _, _ = perturb_for_ba(sc, seed=seed, rot_deg=0.5, trans=0.02, focal_rel=0.02)
     rng = np.random.default_rng(seed)
     images = rng.random((1, S, 3, 32, 32), dtype=np.float32)      # colours only; resized to (W,W) by the consumer
@@ -83,8 +93,9 @@ def main():
     for name, (S, N, cam, shared, seed, kw) in CASES.items():
         if only and name not in only:
             continue
-        inp = inputs(S, N, cam, shared, seed)
+        inp = inputs(S, N, cam, shared, seed, sparse_frames=ESTIMATE_CASES.get(name, ()))
         W = int(inp["W"])
+        pycolmap_shim.ESTIMATION.update(enabled=name in ESTIMATE_CASES, rng=np.random.default_rng(1000 + seed), log=[])
         cams = types.SimpleNamespace(R=torch.from_numpy(inp["R"]), T=torch.from_numpy(inp["T"]),
                                      focal_length=torch.from_numpy(np.stack([inp["focal_ndc"]] * 2, -1)))
         images = expand_images(inp["images_small"], W)
@@ -100,7 +111,16 @@ def main():
         print(name, "valid tracks", int(vtracks.sum()), "of", N, "solver calls", len(pycolmap_shim.CALLS),
               [c[1]["num_iterations"] for c in pycolmap_shim.CALLS if c[0] == "bundle_adjustment"])
         stored = dict(S=np.int64(S), N=np.int64(N), seed=np.int64(seed), input_sha256=input_digest(inp), W=inp["W"]) \
-            if name in COMPACT else inp
+            if name in COMPACT else dict(inp)
+        if name in ESTIMATE_CASES:
+            log = pycolmap_shim.ESTIMATION["log"]
+            frames = [l[0] for l in log]
+            print("   absolute_pose_estimation calls for frames", frames, "candidates", [l[1] for l in log])
+            assert len(set(frames)) == len(frames) >= 1, "one estimate per frame expected (no retry with all points)"
+            stored["est_frames"] = np.array(frames, np.int64)
+            stored["est_candidates"] = np.array([l[1] for l in log], np.int64)
+            stored["est_uniforms"] = np.stack([l[2] for l in log])
+        pycolmap_shim.ESTIMATION["enabled"] = False
         np.savez_compressed(
             os.path.join(OUT, f"triangulator_{name}.npz"), camera_type=cam, shared=shared,
             kw_keys=np.array(list(kw.keys())), kw_vals=np.array(list(kw.values())), **stored,

@@ -12,8 +12,14 @@ AbsolutePoseRefinementOptions, AbsolutePoseEstimationOptions, bundle_adjustment,
 absolute_pose_estimation``.  The solvers are ``oracle/ba.py`` (the Ceres/COLMAP restatement, PARITY UNPINNED
 against the real pycolmap 3.10 -- see oracle/ba_oracle.h); what this harness pins is everything AROUND the
 solver: the reference's mask bookkeeping, thresholds schedule, problem construction and result read-back.
-``absolute_pose_estimation`` (P3P LO-RANSAC) is not restated: it returns None, which the reference handles
-(vggsfm/utils/triangulation.py:434) by keeping the pose.
+``absolute_pose_estimation``: COLMAP's own (adaptive LO-RANSAC on its private RNG) cannot be restated bit for bit.  By
+default it returns None, which the reference handles (vggsfm/utils/triangulation.py:434) by keeping the pose.  With
+``ESTIMATION["enabled"]`` it is a DETERMINISTIC restatement of what the drop-in computes on the device
+(vggsfm_amd/pose.py: absolute_pose_estimation_batch): the 30 quadratically spaced focal-length factors, points normalised
+with the scaled camera, a fixed number of P3P minimal samples (oracle/p3p.py) drawn from uniform numbers of a seeded numpy
+generator -- the numbers are recorded per frame so that the GPU test replays them --, winner by (inliers, residual sum,
+first factor), then RefineAbsolutePose on the RANSAC inliers.  That puts the reference's `force_estimate` branch
+(triangulation.py:406-432) into the golden vectors instead of stubbing it out.
 """
 import types
 
@@ -254,5 +260,60 @@ def pose_refinement(cam_from_world, points2D, points3D, inlier_mask, camera, ref
     return {"cam_from_world": Rigid3d(Rotation3d(ext[:, :3]), ext[:, 3]), "num_inliers": int(np.sum(inlier_mask))}
 
 
-def absolute_pose_estimation(*args, **kwargs):
-    return None
+ESTIMATION = {"enabled": False, "rng": None, "num_hypotheses": 1024, "log": []}   # log: (camera_id, n_candidates, uniforms (H,3))
+
+
+def positions_from_uniforms(r, n):
+    """Three DISTINCT positions in [0, n) per row from uniforms r (H,3) -- the arithmetic of vggsfm_amd.pose.draw_minimal_samples."""
+    n = max(int(n), 3)
+    r0 = np.minimum((r[:, 0] * n).astype(np.int64), n - 1)
+    r1 = np.minimum((r[:, 1] * (n - 1)).astype(np.int64), n - 2)
+    r1 = r1 + (r1 >= r0)
+    r2 = np.minimum((r[:, 2] * (n - 2)).astype(np.int64), n - 3)
+    lo, hi = np.minimum(r0, r1), np.maximum(r0, r1)
+    r2 = r2 + (r2 >= lo)
+    r2 = r2 + (r2 >= hi)
+    return np.stack([r0, r1, r2], -1)
+
+
+def absolute_pose_estimation(points2D, points3D, camera, estimation_options=None, refinement_options=None):
+    if not ESTIMATION["enabled"]:
+        return None
+    from . import geometry as OG
+    from . import p3p as OP
+    eo = estimation_options or AbsolutePoseEstimationOptions()
+    x_px = np.asarray(points2D, np.float64)
+    X = np.ascontiguousarray(np.asarray(points3D, np.float64))
+    n = len(X)
+    if n < 3:
+        return None
+    H = ESTIMATION["num_hypotheses"]
+    r = ESTIMATION["rng"].random((H, 3))
+    ESTIMATION["log"].append((int(camera.camera_id), n, r))
+    samples = positions_from_uniforms(r, n).astype(np.int64)
+    if eo.estimate_focal_length:                           # COLMAP EstimateAbsolutePose: 30 factors in [0.2, 5], quadratic spacing
+        factors = np.array([0.2 + (5.0 - 0.2) * (i * (1.0 / 30)) * (i * (1.0 / 30)) for i in range(30)])
+    else:
+        factors = np.array([1.0])
+    G = len(factors)
+    f0, cx, cy = float(camera.params[0]), float(camera.params[1]), float(camera.params[2])
+    foc = f0 * factors
+    K = np.zeros((G, 3, 3))
+    K[:, 0, 0] = K[:, 1, 1] = foc
+    K[:, 0, 2], K[:, 1, 2], K[:, 2, 2] = cx, cy, 1.0
+    extra = np.full((G, 1), float(camera.params[3])) if camera.model == "SIMPLE_RADIAL" else None
+    xn = OG.cam_from_img(np.broadcast_to(x_px[None], (G, n, 2)).copy(), K, extra)
+    best = None
+    mask = np.ones(n, bool)
+    for g in range(G):
+        res = OP.absolute_pose_ransac(xn[g], X, mask, samples, (float(eo.ransac.max_error) / foc[g]) ** 2)
+        if best is None or res["num_inliers"] > best[1]["num_inliers"] or (
+                res["num_inliers"] == best[1]["num_inliers"] and res["residual_sum"] < best[1]["residual_sum"]):
+            best = (g, res)
+    g, res = best
+    if res["num_inliers"] < 3:
+        return None
+    camera.params[0] = foc[g]
+    ans = pose_refinement(Rigid3d(Rotation3d(res["pose"][:, :3]), res["pose"][:, 3]), x_px, X, res["inliers"], camera,
+                          refinement_options)
+    return {"cam_from_world": ans["cam_from_world"], "num_inliers": int(res["num_inliers"]), "inlier_mask": res["inliers"]}

@@ -78,11 +78,18 @@ def focal_length_factors(estoptions):
 def draw_minimal_samples(candidate_mask, num_hypotheses, generator=None):
     """(F,P) bool -> (F,H,3) int32: three DISTINCT candidate indices per hypothesis, uniform (host-seeded torch RNG on the
     device).  Frames with fewer than 3 candidates get zeros (the caller marks them failed)."""
+    F = candidate_mask.shape[0]
+    r = torch.rand((F, num_hypotheses, 3), dtype=torch.float64, device=candidate_mask.device, generator=generator)
+    return samples_from_uniforms(candidate_mask, r)
+
+
+def samples_from_uniforms(candidate_mask, r):
+    """The sampling arithmetic of `draw_minimal_samples` on given uniform numbers r (F,H,3) in [0,1): position among the
+    frame's candidates (in index order) -> point index.  (Separate so that a test can replay recorded numbers.)"""
     F, P = candidate_mask.shape
-    dev = candidate_mask.device
+    num_hypotheses = r.shape[1]
     cnt = candidate_mask.sum(1)
     table = torch.argsort((~candidate_mask).to(torch.uint8), dim=1, stable=True)        # candidates first, in index order
-    r = torch.rand((F, num_hypotheses, 3), dtype=torch.float64, device=dev, generator=generator)
     n = cnt.clamp(min=3).to(torch.float64)[:, None]
     nl = n.long()
     r0 = torch.minimum((r[..., 0] * n).long(), nl - 1)

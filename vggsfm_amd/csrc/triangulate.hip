@@ -195,8 +195,64 @@ __device__ __forceinline__ Cand eval_views(const double* __restrict__ ext, const
   return c;
 }
 
+// eval_views with kGV lanes per hypothesis (second local-optimisation round: 10 hypotheses, which left 54 of 64 lanes
+// idle for two passes over the views -- a quarter of the kernel at 200 views).  The lanes of a group evaluate kGV
+// consecutive views at once; their contributions are then added to the group's accumulators ONE VIEW AT A TIME, in view
+// order, by every lane of the group alike (the values come over with ds_bpermute, a skipped view leaves the accumulator
+// untouched): the same additions in the same order as eval_views -- bit-identical counts, sums and DLT matrices.
+// src0 = first lane of this lane's group, vq = its position inside the group.
+constexpr int kGV = 6;
+template <bool ACC>
+__device__ __forceinline__ Cand eval_views_grouped(const double* __restrict__ ext, const double* tab, int S, double X0,
+                                                   double X1, double X2, bool invalid, bool live, double max_rad,
+                                                   double cos_gate, bool ransac_nan, Sym4* acc, bool* any_behind, int src0,
+                                                   int vq) {
+  int cnt = 0;
+  double sum = 0.0;
+  bool poisoned = false, behind = false;
+  for (int s0 = 0; s0 < ((VGG_TRI_ABLATE & 2) ? 0 : S); s0 += kGV) {
+    const int s = s0 + vq;
+    const bool has = s < S;
+    const int sc = has ? s : S - 1;
+    const double* t = tab + sc * kTab;
+    bool isn;
+    double depth;
+    const double err = view_error(ext + 12 * sc, t, X0, X1, X2, cos_gate, isn, depth);
+    if (has && depth <= 0.0) behind = true;
+    if (has && isn && ransac_nan) poisoned = true;
+    const bool inl = has && live && !invalid && (t[3] == 0.0) && !isn && (err <= max_rad);
+    Sym4 mv;
+    if (ACC) view_dlt_matrix_r(ext + 12 * sc, t[0], t[1], t[2], mv);
+    const unsigned long long inl_mask = __ballot(inl);
+#pragma unroll
+    for (int k = 0; k < kGV; ++k) {
+      const int src = src0 + k;
+      const bool inl_k = ((inl_mask >> src) & 1ull) != 0;
+      const double e_k = __shfl(err, src, 64);
+      cnt += inl_k ? 1 : 0;
+      sum = inl_k ? sum + e_k : sum;
+      if (ACC) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+          const double v = __shfl(mv.a[i], src, 64);
+          acc->a[i] = inl_k ? acc->a[i] + v : acc->a[i];
+        }
+      }
+    }
+  }
+  const unsigned long long gmask = ((1ull << kGV) - 1ull) << src0;
+  behind = (__ballot(behind) & gmask) != 0;
+  poisoned = (__ballot(poisoned) & gmask) != 0;
+  if (any_behind) *any_behind = behind;
+  Cand c;
+  c.n = cnt;
+  c.e = (cnt > 0 && !poisoned) ? sum / (double)cnt : 2.0 * kPi;
+  return c;
+}
+
 template <int HJ>
-__global__ __launch_bounds__(64) void triangulate_kernel(
+__global__ __launch_bounds__(64, 2) void triangulate_kernel(   // (two wavefronts per SIMD: <= 256 registers)
+   
     const double* __restrict__ ext, const double* __restrict__ tn, const uint8_t* __restrict__ ivc,
     const int32_t* __restrict__ pairs_all, int S, int N, int H, int lo1, int lo2, double max_rad, double min_tri_deg,
     const double* __restrict__ thres_all, int chunk_size, double* __restrict__ out_pts, int64_t* __restrict__ out_num,
@@ -368,25 +424,28 @@ __global__ __launch_bounds__(64) void triangulate_kernel(
     }
     __syncthreads();
     {
-      const bool q_live = lane < lo2 && !(VGG_TRI_ABLATE & 2);
-      const int g = q_live ? sel[lane] : 0;
+      // kGV lanes per hypothesis (lo2 <= 10: checked by the host entry) (eval_views_grouped): slot q = lane / kGV, lane q * kGV carries the candidate
+      const int q = lane / kGV, vq = lane - kGV * q, src0 = kGV * q;
+      const bool q_live = q < lo2 && !(VGG_TRI_ABLATE & 2);
+      const int g = q_live ? sel[q] : 0;
       Sym4 m;
 #pragma unroll
       for (int k = 0; k < 10; ++k) m.a[k] = 0.0;
-      eval_views<true>(ext, tab, S, lx[4 * g], lx[4 * g + 1], lx[4 * g + 2], lx[4 * g + 3] != 0.0, q_live, max_rad, cos_gate,
-                       false, &m, nullptr);
+      eval_views_grouped<true>(ext, tab, S, lx[4 * g], lx[4 * g + 1], lx[4 * g + 2], lx[4 * g + 3] != 0.0, q_live, max_rad,
+                               cos_gate, false, &m, nullptr, src0, vq);
       double v[4];
       smallest_eigvec4(m, v);
       const double Q0 = v[0] / v[3], Q1 = v[1] / v[3], Q2 = v[2] / v[3];
       bool behind;
-      Cand qc = eval_views<false>(ext, tab, S, Q0, Q1, Q2, false, q_live, max_rad, cos_gate, false, nullptr, &behind);
+      Cand qc = eval_views_grouped<false>(ext, tab, S, Q0, Q1, Q2, false, q_live, max_rad, cos_gate, false, nullptr, &behind,
+                                          src0, vq);
       const bool tri_ok = any_pair_angle(centers, S, Q0, Q1, Q2, min_tri_deg, q_live);
       const bool q_inv = behind || !tri_ok;
       if (q_inv) { qc.n = 0; qc.e = 2.0 * kPi; }
-      if (q_live) {
+      if (q_live && vq == 0) {
         wave_max_e = fmax(wave_max_e, qc.e);
         const double ind = (thres - qc.e) / thres + (double)qc.n;
-        const int idx = H + lo1 + lane;
+        const int idx = H + lo1 + q;
         if (ind > best_ind || (ind == best_ind && idx < best_idx)) {
           best_ind = ind; best_idx = idx; best = qc; bX0 = Q0; bX1 = Q1; bX2 = Q2; b_inv = q_inv;
         }
@@ -496,7 +555,7 @@ int vgg_triangulate_tracks_chunks(const double* extrinsics, const double* tracks
   if (N == 0) return VGG_OK;
   hipStream_t st = (hipStream_t)stream;
   const int lo1 = lo_num < H ? lo_num : H;
-  const int lo2 = lo1 < 10 ? lo1 : 10;
+  const int lo2 = lo1 < 10 ? lo1 : 10;                   // (<= 64 / kGV: six lanes per hypothesis in the second round)
   const double max_rad = max_angular_error_deg * (kPi / 180.0);
   const size_t lds = sizeof(double) * ((size_t)S * kTab + (size_t)H * 4 + 64 * 4) + sizeof(int) * (((H + 63) / 64) * 64 + 64);
   if (lds > 160 * 1024) return VGG_ERR_UNSUPPORTED;

@@ -163,28 +163,40 @@ struct Cand { double e; int n; };   // mean inlier error (or 2*pi) and inlier co
 
 // Evaluate hypothesis X against all views.  ACC: also accumulate the DLT matrix of its inlier views.
 // ransac_nan: NaN errors poison the mean (residual indicator on raw errors); otherwise NaN -> 100*pi.
+// `vlist[0 .. nv)`: the views in which the track is visible (flag 0), ascending.  Only they can hold inliers, so only they
+// are evaluated; a NaN error cannot appear in one view alone (it needs a non-finite point, which has no inlier anywhere:
+// the mean is 2 pi either way), and the cheirality test over ALL views (`any_behind`) needs the depth of the other views
+// only -- one row of P X, the expression view_error uses.  Same values, same order of the sums; ~4x fewer evaluations at
+// the visibility density of the BASELINE scenes.
 template <bool ACC>
-__device__ __forceinline__ Cand eval_views(const double* __restrict__ ext, const double* tab, int S, double X0,
-                                           double X1, double X2, bool invalid, bool live, double max_rad,
+__device__ __forceinline__ Cand eval_views(const double* __restrict__ ext, const double* tab, const int* vlist, int nv, int S,
+                                           double X0, double X1, double X2, bool invalid, bool live, double max_rad,
                                            double cos_gate, bool ransac_nan, Sym4* acc, bool* any_behind) {
   int cnt = 0;
   double sum = 0.0;
   bool poisoned = false, behind = false;
-  for (int s = 0; s < ((VGG_TRI_ABLATE & 2) ? 0 : S); ++s) {
+  if (any_behind) {
+    for (int s = 0; s < ((VGG_TRI_ABLATE & 2) ? 0 : S); ++s) {
+      const double* P = ext + 12 * s;
+      const double y2 = P[8] * X0 + P[9] * X1 + P[10] * X2 + P[11];
+      if (y2 <= 0.0) behind = true;
+    }
+  }
+  for (int k = 0; k < ((VGG_TRI_ABLATE & 2) ? 0 : nv); ++k) {
+    const int s = vlist[k];
     const double* t = tab + s * kTab;
     bool isn;
     double depth;
     const double err = view_error(ext + 12 * s, t, X0, X1, X2, cos_gate, isn, depth);
-    if (depth <= 0.0) behind = true;
     if (isn && ransac_nan) poisoned = true;
-    const bool inl = live && !invalid && (t[3] == 0.0) && !isn && (err <= max_rad);
+    const bool inl = live && !invalid && !isn && (err <= max_rad);
     if (inl) {
       ++cnt; sum += err;
       if (ACC) {
         Sym4 mv;
         view_dlt_matrix_r(ext + 12 * s, t[0], t[1], t[2], mv);
 #pragma unroll
-        for (int k = 0; k < 10; ++k) acc->a[k] += mv.a[k];
+        for (int k2 = 0; k2 < 10; ++k2) acc->a[k2] += mv.a[k2];
       }
     }
   }
@@ -203,24 +215,29 @@ __device__ __forceinline__ Cand eval_views(const double* __restrict__ ext, const
 // src0 = first lane of this lane's group, vq = its position inside the group.
 constexpr int kGV = 6;
 template <bool ACC>
-__device__ __forceinline__ Cand eval_views_grouped(const double* __restrict__ ext, const double* tab, int S, double X0,
-                                                   double X1, double X2, bool invalid, bool live, double max_rad,
-                                                   double cos_gate, bool ransac_nan, Sym4* acc, bool* any_behind, int src0,
-                                                   int vq) {
+__device__ __forceinline__ Cand eval_views_grouped(const double* __restrict__ ext, const double* tab, const int* vlist, int nv,
+                                                   int S, double X0, double X1, double X2, bool invalid, bool live,
+                                                   double max_rad, double cos_gate, bool ransac_nan, Sym4* acc,
+                                                   bool* any_behind, int src0, int vq) {
   int cnt = 0;
   double sum = 0.0;
   bool poisoned = false, behind = false;
-  for (int s0 = 0; s0 < ((VGG_TRI_ABLATE & 2) ? 0 : S); s0 += kGV) {
-    const int s = s0 + vq;
-    const bool has = s < S;
-    const int sc = has ? s : S - 1;
+  if (any_behind) {                                   // cheirality over all views: the lanes of a group share them out
+    for (int s = vq; s < ((VGG_TRI_ABLATE & 2) ? 0 : S); s += kGV) {
+      const double* P = ext + 12 * s;
+      const double y2 = P[8] * X0 + P[9] * X1 + P[10] * X2 + P[11];
+      if (y2 <= 0.0) behind = true;
+    }
+  }
+  for (int k0 = 0; k0 < ((VGG_TRI_ABLATE & 2) ? 0 : nv); k0 += kGV) {
+    const bool has = k0 + vq < nv;
+    const int sc = vlist[has ? k0 + vq : nv - 1];
     const double* t = tab + sc * kTab;
     bool isn;
     double depth;
     const double err = view_error(ext + 12 * sc, t, X0, X1, X2, cos_gate, isn, depth);
-    if (has && depth <= 0.0) behind = true;
     if (has && isn && ransac_nan) poisoned = true;
-    const bool inl = has && live && !invalid && (t[3] == 0.0) && !isn && (err <= max_rad);
+    const bool inl = has && live && !invalid && !isn && (err <= max_rad);
     Sym4 mv;
     if (ACC) view_dlt_matrix_r(ext + 12 * sc, t[0], t[1], t[2], mv);
     const unsigned long long inl_mask = __ballot(inl);
@@ -263,6 +280,7 @@ __global__ __launch_bounds__(64, 2) void triangulate_kernel(   // (two wavefront
   double* lx = hx + (size_t)H * 4;                      // [64][4] LO1 points + invalid flag
   int* cnts = reinterpret_cast<int*>(lx + 64 * 4);      // [H] inlier counts, later [64] LO1 counts
   int* sel = cnts + ((H + 63) / 64) * 64;               // [64] selected hypothesis per LO slot
+  int* vlist = sel + 64;                                // [S] views in which the track is visible, ascending
   const int lane = threadIdx.x;
   const double cos_gate = cos(max_rad) - 1e-9;
   double wave_max_e = 0.0;
@@ -292,6 +310,15 @@ __global__ __launch_bounds__(64, 2) void triangulate_kernel(   // (two wavefront
       // F.normalize of the same homogeneous ray (eps 1e-12 never binds: norm >= 1)
       t[0] = r0; t[1] = r1; t[2] = r2;
       t[3] = ivc[(size_t)n * S + s] ? 1.0 : 0.0;
+    }
+    // visible views of the track, ascending (one wavefront per track: a ballot per 64 views)
+    int nv = 0;
+    for (int base = 0; base < S; base += 64) {
+      const int s = base + lane;
+      const bool vis = s < S && ivc[(size_t)n * S + s] == 0;
+      const unsigned long long bm = __ballot(vis);
+      if (vis) vlist[nv + __popcll(bm & ((1ull << lane) - 1ull))] = s;
+      nv += __popcll(bm);
     }
     __syncthreads();
 
@@ -330,17 +357,18 @@ __global__ __launch_bounds__(64, 2) void triangulate_kernel(   // (two wavefront
     bool pois[HJ];
 #pragma unroll
     for (int j = 0; j < HJ; ++j) { cnt[j] = 0; sum[j] = 0.0; pois[j] = false; }
-    for (int s = 0; s < ((VGG_TRI_ABLATE & 1) ? 0 : S); ++s) {
+    // (visible views only: see eval_views)
+    for (int k = 0; k < ((VGG_TRI_ABLATE & 1) ? 0 : nv); ++k) {
+      const int s = vlist[k];
       const double* t = tab + s * kTab;
       const double* P = ext + 12 * s;
-      const bool vis_ok = (t[3] == 0.0);
 #pragma unroll
       for (int j = 0; j < HJ; ++j) {
         bool isn;
         double depth;
         const double err = view_error(P, t, X[j][0], X[j][1], X[j][2], cos_gate, isn, depth);
         if (isn) pois[j] = true;
-        if (live[j] && !inv[j] && vis_ok && !isn && err <= max_rad) { ++cnt[j]; sum[j] += err; }
+        if (live[j] && !inv[j] && !isn && err <= max_rad) { ++cnt[j]; sum[j] += err; }
       }
     }
     Cand best;                      // running first-maximum of the residual indicator, candidate order
@@ -389,14 +417,14 @@ __global__ __launch_bounds__(64, 2) void triangulate_kernel(   // (two wavefront
       Sym4 m;
 #pragma unroll
       for (int k = 0; k < 10; ++k) m.a[k] = 0.0;
-      eval_views<true>(ext, tab, S, hx[4 * h], hx[4 * h + 1], hx[4 * h + 2], hx[4 * h + 3] != 0.0, l_live, max_rad, cos_gate,
+      eval_views<true>(ext, tab, vlist, nv, S, hx[4 * h], hx[4 * h + 1], hx[4 * h + 2], hx[4 * h + 3] != 0.0, l_live, max_rad, cos_gate,
                        true, &m, nullptr);
       double v[4];
       smallest_eigvec4(m, v);
       L0 = v[0] / v[3]; L1 = v[1] / v[3]; L2 = v[2] / v[3];
       bool behind;
       // errors of the refined point (NaN -> 100*pi: not an inlier, no poisoning), cheirality over ALL views
-      Cand tmp = eval_views<false>(ext, tab, S, L0, L1, L2, false, l_live, max_rad, cos_gate, false, nullptr, &behind);
+      Cand tmp = eval_views<false>(ext, tab, vlist, nv, S, L0, L1, L2, false, l_live, max_rad, cos_gate, false, nullptr, &behind);
       const bool tri_ok = any_pair_angle(centers, S, L0, L1, L2, min_tri_deg, l_live);
       l_inv = behind || !tri_ok;
       if (!l_inv) lc = tmp;
@@ -431,13 +459,13 @@ __global__ __launch_bounds__(64, 2) void triangulate_kernel(   // (two wavefront
       Sym4 m;
 #pragma unroll
       for (int k = 0; k < 10; ++k) m.a[k] = 0.0;
-      eval_views_grouped<true>(ext, tab, S, lx[4 * g], lx[4 * g + 1], lx[4 * g + 2], lx[4 * g + 3] != 0.0, q_live, max_rad,
+      eval_views_grouped<true>(ext, tab, vlist, nv, S, lx[4 * g], lx[4 * g + 1], lx[4 * g + 2], lx[4 * g + 3] != 0.0, q_live, max_rad,
                                cos_gate, false, &m, nullptr, src0, vq);
       double v[4];
       smallest_eigvec4(m, v);
       const double Q0 = v[0] / v[3], Q1 = v[1] / v[3], Q2 = v[2] / v[3];
       bool behind;
-      Cand qc = eval_views_grouped<false>(ext, tab, S, Q0, Q1, Q2, false, q_live, max_rad, cos_gate, false, nullptr, &behind,
+      Cand qc = eval_views_grouped<false>(ext, tab, vlist, nv, S, Q0, Q1, Q2, false, q_live, max_rad, cos_gate, false, nullptr, &behind,
                                           src0, vq);
       const bool tri_ok = any_pair_angle(centers, S, Q0, Q1, Q2, min_tri_deg, q_live);
       const bool q_inv = behind || !tri_ok;
@@ -557,7 +585,7 @@ int vgg_triangulate_tracks_chunks(const double* extrinsics, const double* tracks
   const int lo1 = lo_num < H ? lo_num : H;
   const int lo2 = lo1 < 10 ? lo1 : 10;                   // (<= 64 / kGV: six lanes per hypothesis in the second round)
   const double max_rad = max_angular_error_deg * (kPi / 180.0);
-  const size_t lds = sizeof(double) * ((size_t)S * kTab + (size_t)H * 4 + 64 * 4) + sizeof(int) * (((H + 63) / 64) * 64 + 64);
+  const size_t lds = sizeof(double) * ((size_t)S * kTab + (size_t)H * 4 + 64 * 4) + sizeof(int) * (((H + 63) / 64) * 64 + 64 + (size_t)S);
   if (lds > 160 * 1024) return VGG_ERR_UNSUPPORTED;
   unsigned long long* gmax = (unsigned long long*)((char*)workspace + 256);
   double* thres = (double*)(gmax + num_chunks);

@@ -941,6 +941,9 @@ __device__ __forceinline__ double dpp_swap_xor1(double v) {
 #if VGG_TILE_TRACE
 __device__ long long g_tile_trace[2048 * 4 * 8];   // [workgroup][wave][batches, fetch+issue, matrix phase, LDS write phase, barrier wait, total]
 #endif
+#ifndef VGG_TILE_PRIO
+#define VGG_TILE_PRIO 2              // wave priority: 2 = raised outside the matrix phase (staging, LDS writes, barrier): a wavefront
+#endif                               // gets back to its matrix instructions sooner (round 3: off-diagonal launch 0.620 -> 0.606 ms); 1 = raised inside
 #ifndef VGG_NO_SKIP
 #define VGG_NO_SKIP 0               // profiling builds: 1 = every sub-tile of every batch runs (no presence skipping)
 #endif
@@ -1106,7 +1109,17 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
 #endif
       VGG_TT(tr_issue)
 #if VGG_ABLATE != 1
+#if VGG_TILE_PRIO == 1                            // experiment: matrix phase at raised wave priority
+      __builtin_amdgcn_s_setprio(2);
+#elif VGG_TILE_PRIO == 2                          // experiment: staging phases at raised wave priority
+      __builtin_amdgcn_s_setprio(0);
+#endif
       mfma_batch(buf, qmask);
+#if VGG_TILE_PRIO == 1
+      __builtin_amdgcn_s_setprio(0);
+#elif VGG_TILE_PRIO == 2
+      __builtin_amdgcn_s_setprio(3);
+#endif
 #endif
       VGG_TT(tr_mfma)
       qmask = qmask_next;

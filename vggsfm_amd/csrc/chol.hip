@@ -951,6 +951,202 @@ __device__ __forceinline__ void factor64(double* D, double* Tl, double* rd, doub
   __syncthreads();
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Round 3: the 64 x 64 diagonal block as FOUR 16 x 16 blocks (blocked right-looking), instead of two 32 x 32 ones.
+//   * A 16 x 16 diagonal block is factored by ONE wavefront out of registers (lane = (row, quarter of the columns),
+//     four pivot columns per step; pivot block, panel entries and multipliers go through a few hundred bytes of LDS
+//     scratch -- LDS is in order per wavefront, so no barrier), its inverse transpose riding along as rows of the
+//     identity (factor16_wave): the dependent fp64 chain of the pivots is what it was, the three workgroup barriers per
+//     step are gone.
+//   * Everything else is 16 x 16 x 16 products on the matrix cores (mm16): the panel (block column kb times T_kk), the
+//     trailing update, and the same column operations on the rows of the identity, which leave T = L^-T in Tl.
+//   * Only A(kb) = [update (kb, kb)] + factor16 sits on the critical path of wavefront 0; the other trailing products of
+//     step kb - 1 are done by wavefronts 1..3 meanwhile; two barriers per 16 columns.
+// The factor differs from factor64_pairs in the last bits only (order of the trailing sums).
+template <class FA, class FB, class FO>
+__device__ __forceinline__ void mm16(FA opA, FB opB, FO out) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(opA(li, 4 * s + lk), opB(li, 4 * s + lk), acc, 0, 0, 0);
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) out(lk + 4 * reg, li, acc[reg]);
+}
+
+// rsqrt / sqrt of a positive double from the hardware estimate + two Newton steps and one correction of the root (the
+// library sqrt and the division behind it are ~70 dependent operations, four times per 64 x 64 block)
+__device__ __forceinline__ void fast_rsqrt_sqrt(double x, double& rs, double& sd) {
+  double r = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  r = r * __builtin_fma(-h * r, r, 1.5);
+  r = r * __builtin_fma(-h * r, r, 1.5);
+  double s = x * r;
+  s = __builtin_fma(0.5 * r, __builtin_fma(-s, s, x), s);
+  rs = r; sd = s;
+}
+
+// wavefront-level ordering of LDS accesses that alias through different pointers (same wavefront: the hardware keeps the
+// order, the compiler must too)
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// the 16 x 16 block at (16 kb, 16 kb) of D (LDS, ld = LD, lower triangle valid) -> L_kk in place, T_kk = L_kk^-T (upper) in
+// the same block of Tl.  Called by ONE wavefront (all 64 lanes).  scr: 16 + 3 * 64 doubles of LDS.
+template <int LD>
+__device__ __forceinline__ bool factor16_wave(double* D, double* Tl, int kb, double* scr) {
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  double* P4 = scr;                 // [4][4] pivot block / [16] diagonal
+  double* U = scr + 16;             // [16][4] unnormalised panel entries of the rows of A
+  double* V = U + 64;               // [16][4] u_rt / d_t
+  double* UE = V + 64;              // [16][4] panel entries of the rows of the identity
+  double a[4], e[4];
+  double* Dr = D + (16 * kb + r) * LD + 16 * kb + 4 * q;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { a[c] = Dr[c]; e[c] = (r == 4 * q + c) ? 1.0 : 0.0; }
+  bool bad = false;
+  constexpr double HUGE_ = 1.7976931348623157e308;
+#pragma unroll
+  for (int j0 = 0; j0 < 16; j0 += 4) {
+    const int qq = j0 / 4;
+    const bool mine = (q == qq);
+    wave_lds_fence();
+    if (mine && r >= j0 && r < j0 + 4) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) P4[(r - j0) * 4 + c] = a[c];
+    }
+    wave_lds_fence();
+    const double d0 = P4[0];
+    const double u10 = P4[4], p11 = P4[5];
+    const double u20 = P4[8], p21 = P4[9], p22 = P4[10];
+    const double u30 = P4[12], p31 = P4[13], p32 = P4[14], p33 = P4[15];
+    const double r0 = fast_rcp<1>((d0 > 0.0) ? d0 : 1.0);
+    const double m10 = u10 * r0, m20 = u20 * r0, m30 = u30 * r0;
+    const double d1 = p11 - u10 * m10;
+    const double u21 = p21 - u20 * m10, u31 = p31 - u30 * m10;
+    const double r1 = fast_rcp<1>((d1 > 0.0) ? d1 : 1.0);
+    const double m21 = u21 * r1, m31 = u31 * r1;
+    const double d2 = (p22 - u20 * m20) - u21 * m21;
+    const double u32 = (p32 - u30 * m20) - u31 * m21;
+    const double r2 = fast_rcp<1>((d2 > 0.0) ? d2 : 1.0);
+    const double m32 = u32 * r2;
+    const double d3 = ((p33 - u30 * m30) - u31 * m31) - u32 * m32;
+    const double r3 = fast_rcp<1>((d3 > 0.0) ? d3 : 1.0);
+    if (!(d0 > 0.0) || !(d0 < HUGE_) || !(d1 > 0.0) || !(d1 < HUGE_) || !(d2 > 0.0) || !(d2 < HUGE_) || !(d3 > 0.0) || !(d3 < HUGE_))
+      bad = true;
+    // panel entries of this lane's row (the lanes that hold the four panel columns)
+    const bool liveA = r >= j0 + 4, liveE = r < j0 + 4;
+    double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0, y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
+    if (mine) {
+      if (liveA) {
+        x0 = a[0];
+        x1 = a[1] - x0 * m10;
+        x2 = (a[2] - x0 * m20) - x1 * m21;
+        x3 = ((a[3] - x0 * m30) - x1 * m31) - x2 * m32;
+      }
+      if (liveE) {
+        y0 = e[0];
+        y1 = e[1] - y0 * m10;
+        y2 = (e[2] - y0 * m20) - y1 * m21;
+        y3 = ((e[3] - y0 * m30) - y1 * m31) - y2 * m32;
+      }
+      double* Ur = U + r * 4;
+      double* Vr = V + r * 4;
+      double* Er = UE + r * 4;
+      Ur[0] = x0; Ur[1] = x1; Ur[2] = x2; Ur[3] = x3;
+      Vr[0] = x0 * r0; Vr[1] = x1 * r1; Vr[2] = x2 * r2; Vr[3] = x3 * r3;
+      Er[0] = y0; Er[1] = y1; Er[2] = y2; Er[3] = y3;
+    }
+    wave_lds_fence();
+    // rank-4 update of this lane's four columns (columns beyond the panel)
+    if (4 * q >= j0 + 4) {
+      const double ui0 = U[r * 4], ui1 = U[r * 4 + 1], ui2 = U[r * 4 + 2], ui3 = U[r * 4 + 3];
+      const double ei0 = UE[r * 4], ei1 = UE[r * 4 + 1], ei2 = UE[r * 4 + 2], ei3 = UE[r * 4 + 3];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int c = 4 * q + cc;
+        const double v0 = V[c * 4], v1 = V[c * 4 + 1], v2 = V[c * 4 + 2], v3 = V[c * 4 + 3];
+        if (r >= c) { double t = a[cc]; t -= ui0 * v0; t -= ui1 * v1; t -= ui2 * v2; t -= ui3 * v3; a[cc] = t; }
+        if (liveE) { double t = e[cc]; t -= ei0 * v0; t -= ei1 * v1; t -= ei2 * v2; t -= ei3 * v3; e[cc] = t; }
+      }
+    }
+    // the panel columns take their unnormalised values
+    if (mine) {
+      if (liveA) { a[0] = x0; a[1] = x1; a[2] = x2; a[3] = x3; }
+      if (liveE) { e[0] = y0; e[1] = y1; e[2] = y2; e[3] = y3; }
+      if (r == j0 + 1) a[1] = d1;
+      if (r == j0 + 2) { a[1] = u21; a[2] = d2; }
+      if (r == j0 + 3) { a[1] = u31; a[2] = u32; a[3] = d3; }
+    }
+  }
+  // column scaling by 1 / sqrt(d_c): the diagonal through LDS
+  wave_lds_fence();
+  if (q == r / 4) P4[r] = a[r & 3];
+  wave_lds_fence();
+  double* Tr = Tl + (16 * kb + r) * LD + 16 * kb + 4 * q;
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) {
+    const int c = 4 * q + cc;
+    const double dc = P4[c];
+    double rs, sd;
+    fast_rsqrt_sqrt((dc > 0.0) ? dc : 1.0, rs, sd);
+    if (r > c) Dr[cc] = a[cc] * rs;
+    else if (r == c) Dr[cc] = sd;
+    Tr[cc] = (r <= c) ? e[cc] * rs : 0.0;
+  }
+  wave_lds_fence();
+  return bad;
+}
+
+__device__ __forceinline__ void factor64_blocked(double* D, double* Tl, double* scr, int32_t* fail) {
+  constexpr int LD = DFB + 1, B = 16;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int e = tid; e < DFB * DFB; e += 256) Tl[(e / DFB) * LD + (e % DFB)] = 0.0;
+  __syncthreads();
+  bool bad = false;
+  // D[ib][jb] -= L[ib][k] L[jb][k]^T   /   E[ib][jb] -= E[ib][k] L[jb][k]^T   (16 x 16 blocks; E = the rows of the identity in Tl)
+  auto trail_A = [&](int ib, int jb, int k) __attribute__((always_inline)) {
+    mm16([&](int i, int kk) { return D[(B * ib + i) * LD + B * k + kk]; }, [&](int j, int kk) { return D[(B * jb + j) * LD + B * k + kk]; },
+         [&](int i, int j, double x) { D[(B * ib + i) * LD + B * jb + j] -= x; });
+  };
+  auto trail_E = [&](int ib, int jb, int k) __attribute__((always_inline)) {
+    mm16([&](int i, int kk) { return Tl[(B * ib + i) * LD + B * k + kk]; }, [&](int j, int kk) { return D[(B * jb + j) * LD + B * k + kk]; },
+         [&](int i, int j, double x) { Tl[(B * ib + i) * LD + B * jb + j] -= x; });
+  };
+#pragma unroll 1
+  for (int kb = 0; kb < 4; ++kb) {
+    if (wave == 0) {
+      if (kb > 0) trail_A(kb, kb, kb - 1);
+      bad = factor16_wave<LD>(D, Tl, kb, scr) || bad;
+    } else if (kb > 0) {
+      // the rest of the trailing update of step k = kb - 1, dealt to wavefronts 1..3
+      const int k = kb - 1;
+      int t = 0;
+      for (int jb = k + 1; jb < 4; ++jb)
+        for (int ib = jb; ib < 4; ++ib) {
+          if (ib == kb && jb == kb) continue;              // wavefront 0 (critical path)
+          if (1 + (t % 3) == wave) trail_A(ib, jb, k);
+          ++t;
+        }
+      for (int ib = 0; ib <= k; ++ib)
+        for (int jb = k + 1; jb < 4; ++jb) {
+          if (1 + (t % 3) == wave) trail_E(ib, jb, k);
+          ++t;
+        }
+    }
+    __syncthreads();                 // L_kk, T_kk and every update of step kb - 1 are in LDS
+    // panels: L[ib][kb] = D[ib][kb] T_kk (ib > kb), E[ib][kb] = E[ib][kb] T_kk (ib < kb): three products
+    if (wave < 3) {
+      const int ib = (wave < 3 - kb) ? kb + 1 + wave : wave - (3 - kb);      // kb+1 .. 3, then 0 .. kb-1
+      double* X = (wave < 3 - kb) ? D : Tl;
+      mm16([&](int i, int kk) { return X[(B * ib + i) * LD + B * kb + kk]; }, [&](int j, int kk) { return Tl[(B * kb + kk) * LD + B * kb + j]; },
+           [&](int i, int j, double x) { X[(B * ib + i) * LD + B * kb + j] = x; });
+    }
+    __syncthreads();
+  }
+  if (bad && (tid & 63) == 0) *fail = 1;
+  __syncthreads();
+}
+
 constexpr int kDfOrderMax = 64;               // block columns up to which the chain and the update order below are used
 
 struct DfShared {
@@ -1148,7 +1344,11 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
   // (which nobody waits for: it only matters through T_b and as output)
   auto factor_and_publish = [&](int bc, int b0, int vb, int trace_tile) __attribute__((always_inline)) {
     (void)trace_tile;
+#ifdef VGG_CHOL_PAIRS                              // A/B: the round-2 form, two 32 x 32 blocks
     factor64(sh.D, sh.T, sh.rd, sh.scr, fail);
+#else
+    factor64_blocked(sh.D, sh.T, sh.scr, fail);
+#endif
     DF_STAMP_AT(trace_tile, 2);                          // factored
     for (int e = tid; e < DFB * DFB; e += 256) {
       const int i = e / DFB, j = e % DFB;

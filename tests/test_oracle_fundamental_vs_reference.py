@@ -9,7 +9,11 @@ reference's OWN arithmetic:
     local_refinement's mask gathering (utils.py:256-298)            vs  the oracle's selection of inlier sets
     calculate_residual_indicator + argmax (utils.py:63-87, fundamental.py:162-176)   vs  oracle _best
 
-Not pinnable: run_7point (needs kornia's solve_cubic / normalize_points) and the RNG."""
+    run_7point (fundamental.py:341-469, float32) with kornia's normalize_points restated and the roots of ITS cubic
+      coefficients taken with numpy.roots                           vs  oracle seven_point
+
+Not pinnable here: kornia's own solve_cubic (third-party, kornia is not in this image: its closed-form root finder is
+replaced by numpy.roots on the coefficients the reference computes) and the sampling RNG."""
 import numpy as np
 import pytest
 import torch

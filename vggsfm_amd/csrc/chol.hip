@@ -228,6 +228,9 @@ __device__ __forceinline__ void factor_diag_lds4_la(double* D, double* Tl, doubl
   }
   // pivot chain of the 4 x 4 block (values given) -> record; every lane of the calling wavefront computes the same
   auto chain = [&](double d0, double u10, double p11, double u20, double p21, double p22, double u30, double p31, double p32, double p33) {
+#if VGG_F16_ABL & 8
+    const double r0 = 1.0, r1 = 1.0, r2 = 1.0, r3 = 1.0, m10 = u10, m20 = u20, m30 = u30, m21 = p21, m31 = p31, m32 = p32, d1 = p11, d2 = p22, d3 = p33, u21 = p21, u31 = p31, u32 = p32;
+#else
     const double r0 = fast_rcp<1>((d0 > 0.0) ? d0 : 1.0);
     const double m10 = u10 * r0, m20 = u20 * r0, m30 = u30 * r0;
     const double d1 = p11 - u10 * m10;
@@ -240,6 +243,7 @@ __device__ __forceinline__ void factor_diag_lds4_la(double* D, double* Tl, doubl
     const double m32 = u32 * r2;
     const double d3 = ((p33 - u30 * m30) - u31 * m31) - u32 * m32;
     const double r3 = fast_rcp<1>((d3 > 0.0) ? d3 : 1.0);
+#endif
     if (!(d0 > 0.0) || !(d0 < HUGE_) || !(d1 > 0.0) || !(d1 < HUGE_) || !(d2 > 0.0) || !(d2 < HUGE_) || !(d3 > 0.0) || !(d3 < HUGE_))
       bad = true;
     if ((tid & 63) == 0) {
@@ -873,11 +877,11 @@ __device__ __forceinline__ void st_agent(double* p, double v) {
 __device__ __forceinline__ double ld_agent(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// all threads: wait until *flag != 0 (set by another workgroup of this launch)
-__device__ __forceinline__ void df_wait(const int32_t* flag, int32_t* fail) {
+// all threads: wait until *flag >= want (raised by another workgroup of this launch; flags only grow)
+__device__ __forceinline__ void df_wait_ge(const int32_t* flag, int32_t want, int32_t* fail) {
   if (threadIdx.x == 0) {
     int spins = 0;
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
       __builtin_amdgcn_s_sleep(4);
       ++spins;
       // (a launch that has already failed is not waited out flag by flag)
@@ -887,11 +891,12 @@ __device__ __forceinline__ void df_wait(const int32_t* flag, int32_t* fail) {
   }
   __syncthreads();
 }
+__device__ __forceinline__ void df_wait(const int32_t* flag, int32_t* fail) { df_wait_ge(flag, 1, fail); }
 // all threads: every store of this workgroup has left the CU, then raise the flag
-__device__ __forceinline__ void df_publish(int32_t* flag) {
+__device__ __forceinline__ void df_publish(int32_t* flag, int32_t value = 1) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 #ifdef VGG_CHOL_TRACE
@@ -973,6 +978,13 @@ __device__ __forceinline__ void mm16(FA opA, FB opB, FO out) {
   for (int reg = 0; reg < 4; ++reg) out(lk + 4 * reg, li, acc[reg]);
 }
 
+#ifdef VGG_F64_TRACE                                // shader-clock stamps of workgroup 0 inside factor64_blocked (scripts/ubench)
+__device__ unsigned long long* g_f64_trace = nullptr;
+#define F64_STAMP(slot) do { if (g_f64_trace && blockIdx.x == 0 && threadIdx.x == 0) g_f64_trace[slot] = __builtin_readcyclecounter(); } while (0)
+#else
+#define F64_STAMP(slot) do { } while (0)
+#endif
+
 // rsqrt / sqrt of a positive double from the hardware estimate + two Newton steps and one correction of the root (the
 // library sqrt and the division behind it are ~70 dependent operations, four times per 64 x 64 block)
 __device__ __forceinline__ void fast_rsqrt_sqrt(double x, double& rs, double& sd) {
@@ -985,9 +997,38 @@ __device__ __forceinline__ void fast_rsqrt_sqrt(double x, double& rs, double& sd
   rs = r; sd = s;
 }
 
+// four at once, stage by stage (four independent dependent chains: written interleaved so that they are issued so)
+__device__ __forceinline__ void fast_rsqrt_sqrt4(const double (&x)[4], double (&rs)[4], double (&sd)[4]) {
+  double r[4], h[4], s[4], t[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { r[c] = __builtin_amdgcn_rsq(x[c]); h[c] = 0.5 * x[c]; }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) t[c] = -h[c] * r[c];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) t[c] = __builtin_fma(t[c], r[c], 1.5);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r[c] = r[c] * t[c];
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) s[c] = x[c] * r[c];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) t[c] = __builtin_fma(-s[c], s[c], x[c]);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { sd[c] = __builtin_fma(0.5 * r[c], t[c], s[c]); rs[c] = r[c]; }
+}
+
 // wavefront-level ordering of LDS accesses that alias through different pointers (same wavefront: the hardware keeps the
 // order, the compiler must too)
-__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#ifndef VGG_F16_ABL
+#define VGG_F16_ABL 0
+#endif
+__device__ __forceinline__ void wave_lds_fence() {
+#if !(VGG_F16_ABL & 1)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
 
 // the 16 x 16 block at (16 kb, 16 kb) of D (LDS, ld = LD, lower triangle valid) -> L_kk in place, T_kk = L_kk^-T (upper) in
 // the same block of Tl.  Called by ONE wavefront (all 64 lanes).  scr: 16 + 3 * 64 doubles of LDS.
@@ -999,15 +1040,18 @@ __device__ __forceinline__ bool factor16_wave(double* D, double* Tl, int kb, dou
   double* V = U + 64;               // [16][4] u_rt / d_t
   double* UE = V + 64;              // [16][4] panel entries of the rows of the identity
   double a[4], e[4];
+  double rsv[4] = {1.0, 1.0, 1.0, 1.0}, sdv[4] = {1.0, 1.0, 1.0, 1.0};      // 1 / sqrt(d_c), sqrt(d_c) of this lane's four columns
+  double dprev[4] = {1.0, 1.0, 1.0, 1.0};
   double* Dr = D + (16 * kb + r) * LD + 16 * kb + 4 * q;
 #pragma unroll
   for (int c = 0; c < 4; ++c) { a[c] = Dr[c]; e[c] = (r == 4 * q + c) ? 1.0 : 0.0; }
   bool bad = false;
   constexpr double HUGE_ = 1.7976931348623157e308;
 #pragma unroll
-  for (int j0 = 0; j0 < 16; j0 += 4) {
+  for (int j0 = 0; j0 < ((VGG_F16_ABL & 16) ? 0 : 16); j0 += 4) {
     const int qq = j0 / 4;
     const bool mine = (q == qq);
+    F64_STAMP(32 + 8 * kb + qq);
     wave_lds_fence();
     if (mine && r >= j0 && r < j0 + 4) {
 #pragma unroll
@@ -1018,6 +1062,18 @@ __device__ __forceinline__ bool factor16_wave(double* D, double* Tl, int kb, dou
     const double u10 = P4[4], p11 = P4[5];
     const double u20 = P4[8], p21 = P4[9], p22 = P4[10];
     const double u30 = P4[12], p31 = P4[13], p32 = P4[14], p33 = P4[15];
+    // the column scales of the PREVIOUS four pivots: independent work that fills the wait for the block just read
+    if (j0 > 0) {
+      double rs[4], sd[4];
+      fast_rsqrt_sqrt4(dprev, rs, sd);
+      if (q == qq - 1) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { rsv[c] = rs[c]; sdv[c] = sd[c]; }
+      }
+    }
+#if VGG_F16_ABL & 8
+    const double r0 = 1.0, r1 = 1.0, r2 = 1.0, r3 = 1.0, m10 = u10, m20 = u20, m30 = u30, m21 = p21, m31 = p31, m32 = p32, d1 = p11, d2 = p22, d3 = p33, u21 = p21, u31 = p31, u32 = p32;
+#else
     const double r0 = fast_rcp<1>((d0 > 0.0) ? d0 : 1.0);
     const double m10 = u10 * r0, m20 = u20 * r0, m30 = u30 * r0;
     const double d1 = p11 - u10 * m10;
@@ -1030,8 +1086,10 @@ __device__ __forceinline__ bool factor16_wave(double* D, double* Tl, int kb, dou
     const double m32 = u32 * r2;
     const double d3 = ((p33 - u30 * m30) - u31 * m31) - u32 * m32;
     const double r3 = fast_rcp<1>((d3 > 0.0) ? d3 : 1.0);
+#endif
     if (!(d0 > 0.0) || !(d0 < HUGE_) || !(d1 > 0.0) || !(d1 < HUGE_) || !(d2 > 0.0) || !(d2 < HUGE_) || !(d3 > 0.0) || !(d3 < HUGE_))
       bad = true;
+    dprev[0] = (d0 > 0.0) ? d0 : 1.0; dprev[1] = (d1 > 0.0) ? d1 : 1.0; dprev[2] = (d2 > 0.0) ? d2 : 1.0; dprev[3] = (d3 > 0.0) ? d3 : 1.0;
     // panel entries of this lane's row (the lanes that hold the four panel columns)
     const bool liveA = r >= j0 + 4, liveE = r < j0 + 4;
     double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0, y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
@@ -1042,7 +1100,7 @@ __device__ __forceinline__ bool factor16_wave(double* D, double* Tl, int kb, dou
         x2 = (a[2] - x0 * m20) - x1 * m21;
         x3 = ((a[3] - x0 * m30) - x1 * m31) - x2 * m32;
       }
-      if (liveE) {
+      if (liveE && !(VGG_F16_ABL & 2)) {
         y0 = e[0];
         y1 = e[1] - y0 * m10;
         y2 = (e[2] - y0 * m20) - y1 * m21;
@@ -1064,8 +1122,8 @@ __device__ __forceinline__ bool factor16_wave(double* D, double* Tl, int kb, dou
       for (int cc = 0; cc < 4; ++cc) {
         const int c = 4 * q + cc;
         const double v0 = V[c * 4], v1 = V[c * 4 + 1], v2 = V[c * 4 + 2], v3 = V[c * 4 + 3];
-        if (r >= c) { double t = a[cc]; t -= ui0 * v0; t -= ui1 * v1; t -= ui2 * v2; t -= ui3 * v3; a[cc] = t; }
-        if (liveE) { double t = e[cc]; t -= ei0 * v0; t -= ei1 * v1; t -= ei2 * v2; t -= ei3 * v3; e[cc] = t; }
+        if (r >= c && !(VGG_F16_ABL & 4)) { double t = a[cc]; t -= ui0 * v0; t -= ui1 * v1; t -= ui2 * v2; t -= ui3 * v3; a[cc] = t; }
+        if (liveE && !(VGG_F16_ABL & 2)) { double t = e[cc]; t -= ei0 * v0; t -= ei1 * v1; t -= ei2 * v2; t -= ei3 * v3; e[cc] = t; }
       }
     }
     // the panel columns take their unnormalised values
@@ -1077,26 +1135,121 @@ __device__ __forceinline__ bool factor16_wave(double* D, double* Tl, int kb, dou
       if (r == j0 + 3) { a[1] = u31; a[2] = u32; a[3] = d3; }
     }
   }
-  // column scaling by 1 / sqrt(d_c): the diagonal through LDS
-  wave_lds_fence();
-  if (q == r / 4) P4[r] = a[r & 3];
-  wave_lds_fence();
+  // column scaling by 1 / sqrt(d_c)
+  F64_STAMP(32 + 8 * kb + 4);
+  {
+    double rs[4], sd[4];
+    fast_rsqrt_sqrt4(dprev, rs, sd);
+    if (q == 3) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { rsv[c] = rs[c]; sdv[c] = sd[c]; }
+    }
+  }
   double* Tr = Tl + (16 * kb + r) * LD + 16 * kb + 4 * q;
 #pragma unroll
   for (int cc = 0; cc < 4; ++cc) {
     const int c = 4 * q + cc;
-    const double dc = P4[c];
-    double rs, sd;
-    fast_rsqrt_sqrt((dc > 0.0) ? dc : 1.0, rs, sd);
-    if (r > c) Dr[cc] = a[cc] * rs;
-    else if (r == c) Dr[cc] = sd;
-    Tr[cc] = (r <= c) ? e[cc] * rs : 0.0;
+    if (r > c) Dr[cc] = a[cc] * rsv[cc];
+    else if (r == c) Dr[cc] = sdv[cc];
+    Tr[cc] = (r <= c) ? e[cc] * rsv[cc] : 0.0;
   }
   wave_lds_fence();
   return bad;
 }
 
-__device__ __forceinline__ void factor64_blocked(double* D, double* Tl, double* scr, int32_t* fail) {
+// The same 16 x 16 factorisation with the block in ONE matrix-core accumulator and no LDS traffic inside the loop.
+//   * The (symmetric, fully kept) block sits in the C layout of v_mfma_f64_16x16x4: lane (li, lk) holds the entries
+//     (row lk + 4 reg, column li) -- by symmetry also row li, columns lk + 4 reg.  So the four panel columns 4 qq .. 4 qq + 3
+//     of ALL rows are register acc[qq], and they are laid out exactly as a matrix-core operand (row li, k = lk).
+//   * A step of four pivots is then four matrix instructions on registers the lanes already hold:
+//       X^T = W^T A_panel^T      the elimination inside the panel (W: 4 x 4 unit upper triangular, from the multipliers)
+//       A   -= X (X R)^T         the rank-4 update (R = diag 1/d_t), rows / columns of finished pivots masked to zero
+//       Y^T = W^T E_panel^T,  E^T -= (X R) Y^T     the same column operations on the rows of the identity (T = L^-T)
+//     The only cross-lane traffic is the 4 x 4 pivot block, broadcast with v_readlane (ten doubles); its elimination
+//     (reciprocals, multipliers) is computed redundantly by every lane as before.
+//   * The column scales 1 / sqrt(d) are taken once at the end (each lane needs the four of its own columns).
+// Measured (scripts/ubench/factor64_bench): see DESIGN.md section 6.
+template <int LD>
+__device__ __forceinline__ bool factor16_mfma(double* D, double* Tl, int kb) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  double* Db = D + (16 * kb) * LD + 16 * kb;
+  double* Tb = Tl + (16 * kb) * LD + 16 * kb;
+  f64x4 acc, accE;
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int row = lk + 4 * reg, hi = max(row, li), lo = min(row, li);
+    acc[reg] = Db[hi * LD + lo];
+    accE[reg] = (li == row) ? 1.0 : 0.0;
+  }
+  double xfin[4], yfin[4], dsel[4];
+  bool bad = false;
+  constexpr double HUGE_ = 1.7976931348623157e308;
+  const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int j0 = 0; j0 < 16; j0 += 4) {
+    const int qq = j0 / 4;
+    const double pa = acc[qq], pe = accE[qq];
+    // p_ab = A[j0 + a][j0 + b] is register acc[qq] of lane (li = j0 + a, lk = b)
+    const double d0 = readlane_f64(pa, j0);
+    const double u10 = readlane_f64(pa, j0 + 1), p11 = readlane_f64(pa, j0 + 1 + 16);
+    const double u20 = readlane_f64(pa, j0 + 2), p21 = readlane_f64(pa, j0 + 2 + 16), p22 = readlane_f64(pa, j0 + 2 + 32);
+    const double u30 = readlane_f64(pa, j0 + 3), p31 = readlane_f64(pa, j0 + 3 + 16), p32 = readlane_f64(pa, j0 + 3 + 32);
+    const double p33 = readlane_f64(pa, j0 + 3 + 48);
+    const double r0 = fast_rcp<1>((d0 > 0.0) ? d0 : 1.0);
+    const double m10 = u10 * r0, m20 = u20 * r0, m30 = u30 * r0;
+    const double d1 = p11 - u10 * m10;
+    const double u21 = p21 - u20 * m10, u31 = p31 - u30 * m10;
+    const double r1 = fast_rcp<1>((d1 > 0.0) ? d1 : 1.0);
+    const double m21 = u21 * r1, m31 = u31 * r1;
+    const double d2 = (p22 - u20 * m20) - u21 * m21;
+    const double u32 = (p32 - u30 * m20) - u31 * m21;
+    const double r2 = fast_rcp<1>((d2 > 0.0) ? d2 : 1.0);
+    const double m32 = u32 * r2;
+    const double d3 = ((p33 - u30 * m30) - u31 * m31) - u32 * m32;
+    const double r3 = fast_rcp<1>((d3 > 0.0) ? d3 : 1.0);
+    if (!(d0 > 0.0) || !(d0 < HUGE_) || !(d1 > 0.0) || !(d1 < HUGE_) || !(d2 > 0.0) || !(d2 < HUGE_) || !(d3 > 0.0) || !(d3 < HUGE_))
+      bad = true;
+    // x_t = sum_k a_k W[k][t]:  W[k][t] = -sum_{k <= s < t} W[k][s] m_ts,  W[k][k] = 1
+    const double w01 = -m10, w12 = -m21, w23 = -m32;
+    const double w02 = __builtin_fma(m10, m21, -m20), w13 = __builtin_fma(m21, m32, -m31);
+    const double w03 = __builtin_fma(-w02, m32, __builtin_fma(m10, m31, -m30));
+    // operand lane (li = n, lk = k) carries W[k][n] (n < 4, k <= n), zero elsewhere
+    double wsel = 0.0;
+    wsel = (li == 0 && lk == 0) ? 1.0 : wsel;
+    wsel = (li == 1) ? (lk == 0 ? w01 : lk == 1 ? 1.0 : 0.0) : wsel;
+    wsel = (li == 2) ? (lk == 0 ? w02 : lk == 1 ? w12 : lk == 2 ? 1.0 : 0.0) : wsel;
+    wsel = (li == 3) ? (lk == 0 ? w03 : lk == 1 ? w13 : lk == 2 ? w23 : 1.0) : wsel;
+    const f64x4 xt = __builtin_amdgcn_mfma_f64_16x16x4f64(wsel, pa, zero4, 0, 0, 0);
+    const f64x4 yt = __builtin_amdgcn_mfma_f64_16x16x4f64(wsel, pe, zero4, 0, 0, 0);
+    const double x = xt[0], y = yt[0];               // X[li][lk], Y[li][lk]
+    const double rsel = (lk == 0) ? r0 : (lk == 1) ? r1 : (lk == 2) ? r2 : r3;
+    dsel[qq] = (lk == 0) ? d0 : (lk == 1) ? d1 : (lk == 2) ? d2 : d3;
+    xfin[qq] = x; yfin[qq] = y;
+    if (j0 < 12) {
+      const double xm = (li >= j0 + 4) ? x : 0.0;
+      const double v = xm * rsel;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xm, v, acc, 0, 0, 0);
+      accE = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, y, accE, 0, 0, 0);
+    }
+  }
+  double rs[4], sd[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) dsel[c] = (dsel[c] > 0.0) ? dsel[c] : 1.0;
+  fast_rsqrt_sqrt4(dsel, rs, sd);
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq) {
+    const int c = 4 * qq + lk;
+    if (li > c) Db[li * LD + c] = xfin[qq] * rs[qq];
+    else if (li == c) Db[li * LD + c] = sd[qq];
+    Tb[li * LD + c] = (li <= c) ? yfin[qq] * rs[qq] : 0.0;
+  }
+  return bad;
+}
+
+// slab(kb): called by wavefront 1 alone (all 64 lanes) once the 16 columns 16 kb .. 16 kb + 15 of T are final (kb = 0, 1, 2;
+// the last 16 columns are final on return): the caller hands them on while the factorisation goes on.
+template <class FS>
+__device__ __forceinline__ void factor64_blocked(double* D, double* Tl, double* scr, int32_t* fail, FS slab) {
   constexpr int LD = DFB + 1, B = 16;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1114,16 +1267,24 @@ __device__ __forceinline__ void factor64_blocked(double* D, double* Tl, double* 
   };
 #pragma unroll 1
   for (int kb = 0; kb < 4; ++kb) {
+    F64_STAMP(8 * kb);
     if (wave == 0) {
-      if (kb > 0) trail_A(kb, kb, kb - 1);
+      F64_STAMP(8 * kb + 1);
+#ifdef VGG_CHOL_F16_LDS                           // A/B: the LDS form of the 16 x 16 factorisation
       bad = factor16_wave<LD>(D, Tl, kb, scr) || bad;
+#else
+      bad = factor16_mfma<LD>(D, Tl, kb) || bad;
+#endif
+      F64_STAMP(8 * kb + 2);
     } else if (kb > 0) {
-      // the rest of the trailing update of step k = kb - 1, dealt to wavefronts 1..3
+      // the rest of the trailing update of step k = kb - 1, dealt to wavefronts 2, 3, 1, 2, 3, 1 ...; wavefront 1 first hands
+      // on the columns of T that step k completed (they are not touched again)
       const int k = kb - 1;
-      int t = 0;
+      if (wave == 1) slab(k);
+      int t = 1;
       for (int jb = k + 1; jb < 4; ++jb)
         for (int ib = jb; ib < 4; ++ib) {
-          if (ib == kb && jb == kb) continue;              // wavefront 0 (critical path)
+          if (ib == kb && jb == kb) continue;              // wavefront 0 did it with the panel (critical path)
           if (1 + (t % 3) == wave) trail_A(ib, jb, k);
           ++t;
         }
@@ -1134,14 +1295,34 @@ __device__ __forceinline__ void factor64_blocked(double* D, double* Tl, double* 
         }
     }
     __syncthreads();                 // L_kk, T_kk and every update of step kb - 1 are in LDS
-    // panels: L[ib][kb] = D[ib][kb] T_kk (ib > kb), E[ib][kb] = E[ib][kb] T_kk (ib < kb): three products
-    if (wave < 3) {
+    F64_STAMP(8 * kb + 3);
+    // panels: L[ib][kb] = D[ib][kb] T_kk (ib > kb), E[ib][kb] = E[ib][kb] T_kk (ib < kb): three products.
+    // Wavefront 0 has the block under the diagonal, the one the next diagonal block waits for: it forms the product
+    // TRANSPOSED, so that its accumulator registers are the matrix-core operands of X X^T as they stand (k taken in the
+    // order lk + 4 reg on both sides), and updates the next diagonal block at once -- no pass through LDS, no barrier.
+    if (wave == 0 && kb < 3) {
+      const int lane = tid & 63, li = lane & 15, lk = lane >> 4, ib = kb + 1;
+      f64x4 xt = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+        xt = __builtin_amdgcn_mfma_f64_16x16x4f64(Tl[(B * kb + 4 * s4 + lk) * LD + B * kb + li], D[(B * ib + li) * LD + B * kb + 4 * s4 + lk], xt, 0, 0, 0);
+      f64x4 xx = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        D[(B * ib + li) * LD + B * kb + lk + 4 * reg] = xt[reg];
+        xx = __builtin_amdgcn_mfma_f64_16x16x4f64(xt[reg], xt[reg], xx, 0, 0, 0);
+      }
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) D[(B * ib + lk + 4 * reg) * LD + B * ib + li] -= xx[reg];
+    } else if (wave < 3) {
       const int ib = (wave < 3 - kb) ? kb + 1 + wave : wave - (3 - kb);      // kb+1 .. 3, then 0 .. kb-1
       double* X = (wave < 3 - kb) ? D : Tl;
       mm16([&](int i, int kk) { return X[(B * ib + i) * LD + B * kb + kk]; }, [&](int j, int kk) { return Tl[(B * kb + kk) * LD + B * kb + j]; },
            [&](int i, int j, double x) { X[(B * ib + i) * LD + B * kb + j] = x; });
     }
+    F64_STAMP(8 * kb + 4);
     __syncthreads();
+    F64_STAMP(8 * kb + 5);
   }
   if (bad && (tid & 63) == 0) *fail = 1;
   __syncthreads();
@@ -1342,19 +1523,36 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
 
   // the factorisation of the diagonal block in sh.D, then T first -- the tiles of the column wait for it -- and L_bb
   // (which nobody waits for: it only matters through T_b and as output)
+  // T is handed on in four slabs of 16 columns, tready[bc] = number of slabs out: the tiles of the column multiply by the
+  // first three while the factorisation is still running (columns 16 kb .. of T are final after step kb)
   auto factor_and_publish = [&](int bc, int b0, int vb, int trace_tile) __attribute__((always_inline)) {
     (void)trace_tile;
-#ifdef VGG_CHOL_PAIRS                              // A/B: the round-2 form, two 32 x 32 blocks
+    double* Tg = Tinv + (size_t)bc * DFB * DFB;
+#ifdef VGG_CHOL_PAIRS                              // A/B: the round-2 form, two 32 x 32 blocks, T in one piece
     factor64(sh.D, sh.T, sh.rd, sh.scr, fail);
-#else
-    factor64_blocked(sh.D, sh.T, sh.scr, fail);
-#endif
     DF_STAMP_AT(trace_tile, 2);                          // factored
     for (int e = tid; e < DFB * DFB; e += 256) {
       const int i = e / DFB, j = e % DFB;
-      st_agent(&Tinv[(size_t)bc * DFB * DFB + e], (j >= i) ? sh.T[i * LD + j] : 0.0);
+      st_agent(&Tg[e], (j >= i) ? sh.T[i * LD + j] : 0.0);
     }
-    df_publish(&tready[bc]);
+#else
+    factor64_blocked(sh.D, sh.T, sh.scr, fail, [&](int kb) {
+      // one wavefront: 64 rows x 16 columns (rows below the diagonal block are zero), its own drain, then the count
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int i = 4 * q + (lane >> 4), j = 16 * kb + (lane & 15);
+        st_agent(&Tg[i * DFB + j], sh.T[i * LD + j]);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(&tready[bc], kb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    });
+    DF_STAMP_AT(trace_tile, 2);                          // factored
+    for (int e = tid; e < DFB * 16; e += 256) {
+      const int i = e / 16, j = 48 + e % 16;
+      st_agent(&Tg[i * DFB + j], sh.T[i * LD + j]);
+    }
+#endif
+    df_publish(&tready[bc], 4);
     DF_STAMP_AT(trace_tile, 3);                          // published
     for (int e = tid; e < DFB * DFB; e += 256) {
       const int i = e / DFB, j = e % DFB;
@@ -1371,56 +1569,61 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
     return;
   }
 
-  // off-diagonal (and rhs) tile: X = tile * T_c, T_c = L_cc^-T;  X[i][j] = sum_k tile[i][k] T[k][j]
-  df_wait(&tready[c], fail);
-  DF_STAMP(2);                                           // T of the column arrived
-  f64x4 x[2][2];
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int q = 0; q < 2; ++q) x[m][q] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  // off-diagonal (and rhs) tile: X = tile * T_c, T_c = L_cc^-T;  X[i][j] = sum_k tile[i][k] T[k][j], by slabs of 16 columns
+  // as the column's workgroup hands them on (T is upper triangular: slab kb needs the rows k < 16 (kb + 1) only, in the
+  // plain k order -- the sums are those of the one-piece product).  Wavefront w owns the rows 16 w .. 16 w + 15 of X.  A
+  // merged workgroup adds each slab's share of X X^T to the diagonal tile's sum at once (X through sh.T): when the last
+  // slab arrives, a quarter of the product and a quarter of X X^T are left to do.
   const double* Tc = Tinv + (size_t)c * DFB * DFB;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    double a[2][8], b[2][8];
+  for (int kb = 0; kb < 4; ++kb) {
+    df_wait_ge(&tready[c], kb + 1, fail);
+    if (kb == 3) DF_STAMP(2);                            // the last columns of T arrived
+    const int ns = 4 * (kb + 1);
+    double a[16], b[16];
 #pragma unroll
-    for (int s8 = 0; s8 < 8; ++s8) {
-      const int kk = 4 * (8 * half + s8) + lk;             // MFMA step s supplies k = 4 s + lk (plain order)
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        a[m][s8] = sh.D[(32 * wy + 16 * m + li) * LD + kk];
-        b[m][s8] = ld_agent(Tc + (size_t)kk * DFB + 32 * wx + 16 * m + li);
+    for (int s4 = 0; s4 < 16; ++s4)
+      if (s4 < ns) {
+        a[s4] = sh.D[(16 * wave + li) * LD + 4 * s4 + lk];
+        b[s4] = ld_agent(Tc + (size_t)(4 * s4 + lk) * DFB + 16 * kb + li);
       }
+    f64x4 xa = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s4 = 0; s4 < 16; ++s4)
+      if (s4 < ns) xa = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], b[s4], xa, 0, 0, 0);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int i = 16 * wave + lk + 4 * reg, j = 16 * kb + li;
+      if (i < vr && j < vc) st_agent(&A[(size_t)(r0 + i) * n + c0 + j], xa[reg]);
+      if (merged) sh.T[i * LD + j] = xa[reg];            // (rows past the end of the matrix are zero)
     }
+    if (merged) {
+      __syncthreads();
+      double a2[2][4], b2[2][4];
 #pragma unroll
-    for (int s8 = 0; s8 < 8; ++s8)
+      for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 2; ++m) {
+          a2[m][s4] = sh.T[(32 * wy + 16 * m + li) * LD + 16 * kb + 4 * s4 + lk];
+          b2[m][s4] = sh.T[(32 * wx + 16 * m + li) * LD + 16 * kb + 4 * s4 + lk];
+        }
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-          x[m][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][s8], b[q][s8], x[m][q], 0, 0, 0);
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            accd[m][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[m][s4], b2[q][s4], accd[m][q], 0, 0, 0);
+    }
   }
-  if (merged) __syncthreads();                           // the tile value in sh.D is consumed: X goes there
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int i = 32 * wy + 16 * m + lk + 4 * reg, j = 32 * wx + 16 * q + li;
-        if (i < vr && j < vc) st_agent(&A[(size_t)(r0 + i) * n + c0 + j], x[m][q][reg]);
-        if (merged) sh.D[i * LD + j] = x[m][q][reg];     // (rows past the end of the matrix are zero)
-      }
   DF_STAMP(4);                                           // product done, stores issued
   if (!merged) {
     df_publish(&ready[(size_t)r * nbk + c]);
     DF_STAMP(3);
     return;
   }
-  // merged: the last update of the diagonal tile (r,r) with the X just formed, then its factorisation
-  __syncthreads();
-  multiply_staged(sh.D, sh.D, accd);
-  __syncthreads();
+  // merged: the diagonal tile (r,r) has its last update; its value into sh.D (every wavefront is past its reads of the
+  // tile there: the barrier of the last slab), then its factorisation
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -1432,7 +1635,7 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
         if (i >= vr || j >= vr) v = (i == j) ? 1.0 : 0.0;
         sh.D[i * LD + j] = v;
       }
-  df_publish(&ready[(size_t)r * nbk + c]);               // (X was stored two products ago: the drain is short; + barrier)
+  df_publish(&ready[(size_t)r * nbk + c]);               // (+ the barrier between the reads of X in sh.T and the factorisation)
   DF_STAMP(3);
   DF_STAMP_AT(dtile, 1);                                 // diagonal tile r: updates applied
   factor_and_publish(r, r0, vr, dtile);

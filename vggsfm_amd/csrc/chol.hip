@@ -1169,19 +1169,30 @@ __device__ __forceinline__ bool factor16_wave(double* D, double* Tl, int kb, dou
 //     (reciprocals, multipliers) is computed redundantly by every lane as before.
 //   * The column scales 1 / sqrt(d) are taken once at the end (each lane needs the four of its own columns).
 // Measured (scripts/ubench/factor64_bench): see DESIGN.md section 6.
+// the block (kb, kb) of D (lower triangle valid) in that layout, filled symmetrically
 template <int LD>
-__device__ __forceinline__ bool factor16_mfma(double* D, double* Tl, int kb) {
+__device__ __forceinline__ f64x4 load_block16_sym(const double* D, int kb) {
   const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
-  double* Db = D + (16 * kb) * LD + 16 * kb;
-  double* Tb = Tl + (16 * kb) * LD + 16 * kb;
-  f64x4 acc, accE;
+  const double* Db = D + (16 * kb) * LD + 16 * kb;
+  f64x4 acc;
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
     const int row = lk + 4 * reg, hi = max(row, li), lo = min(row, li);
     acc[reg] = Db[hi * LD + lo];
-    accE[reg] = (li == row) ? 1.0 : 0.0;
   }
-  double xfin[4], yfin[4], dsel[4];
+  return acc;
+}
+
+template <int LD>
+__device__ __forceinline__ bool factor16_mfma(f64x4 acc, double* D, double* Tl, int kb) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  double* Db = D + (16 * kb) * LD + 16 * kb;
+  double* Tb = Tl + (16 * kb) * LD + 16 * kb;
+  f64x4 accE;
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) accE[reg] = (li == lk + 4 * reg) ? 1.0 : 0.0;
+  double xfin[4], yfin[4], rs[4], sd[4];
+  double dlast = 1.0;
   bool bad = false;
   constexpr double HUGE_ = 1.7976931348623157e308;
   const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
@@ -1195,6 +1206,8 @@ __device__ __forceinline__ bool factor16_mfma(double* D, double* Tl, int kb) {
     const double u20 = readlane_f64(pa, j0 + 2), p21 = readlane_f64(pa, j0 + 2 + 16), p22 = readlane_f64(pa, j0 + 2 + 32);
     const double u30 = readlane_f64(pa, j0 + 3), p31 = readlane_f64(pa, j0 + 3 + 16), p32 = readlane_f64(pa, j0 + 3 + 32);
     const double p33 = readlane_f64(pa, j0 + 3 + 48);
+    // the scale of this lane's column of the PREVIOUS step: one short chain per lane in the shadow of the matrix instructions
+    if (j0 > 0) fast_rsqrt_sqrt(dlast, rs[qq - 1], sd[qq - 1]);
     const double r0 = fast_rcp<1>((d0 > 0.0) ? d0 : 1.0);
     const double m10 = u10 * r0, m20 = u20 * r0, m30 = u30 * r0;
     const double d1 = p11 - u10 * m10;
@@ -1223,7 +1236,8 @@ __device__ __forceinline__ bool factor16_mfma(double* D, double* Tl, int kb) {
     const f64x4 yt = __builtin_amdgcn_mfma_f64_16x16x4f64(wsel, pe, zero4, 0, 0, 0);
     const double x = xt[0], y = yt[0];               // X[li][lk], Y[li][lk]
     const double rsel = (lk == 0) ? r0 : (lk == 1) ? r1 : (lk == 2) ? r2 : r3;
-    dsel[qq] = (lk == 0) ? d0 : (lk == 1) ? d1 : (lk == 2) ? d2 : d3;
+    const double dsel = (lk == 0) ? d0 : (lk == 1) ? d1 : (lk == 2) ? d2 : d3;
+    dlast = (dsel > 0.0) ? dsel : 1.0;
     xfin[qq] = x; yfin[qq] = y;
     if (j0 < 12) {
       const double xm = (li >= j0 + 4) ? x : 0.0;
@@ -1232,15 +1246,12 @@ __device__ __forceinline__ bool factor16_mfma(double* D, double* Tl, int kb) {
       accE = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, y, accE, 0, 0, 0);
     }
   }
-  double rs[4], sd[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) dsel[c] = (dsel[c] > 0.0) ? dsel[c] : 1.0;
-  fast_rsqrt_sqrt4(dsel, rs, sd);
+  fast_rsqrt_sqrt(dlast, rs[3], sd[3]);
+  // (the upper triangle of the block in D is never read: it takes whatever the product left there)
 #pragma unroll
   for (int qq = 0; qq < 4; ++qq) {
     const int c = 4 * qq + lk;
-    if (li > c) Db[li * LD + c] = xfin[qq] * rs[qq];
-    else if (li == c) Db[li * LD + c] = sd[qq];
+    Db[li * LD + c] = (li == c) ? sd[qq] : xfin[qq] * rs[qq];
     Tb[li * LD + c] = (li <= c) ? yfin[qq] * rs[qq] : 0.0;
   }
   return bad;
@@ -1265,6 +1276,10 @@ __device__ __forceinline__ void factor64_blocked(double* D, double* Tl, double* 
     mm16([&](int i, int kk) { return Tl[(B * ib + i) * LD + B * k + kk]; }, [&](int j, int kk) { return D[(B * jb + j) * LD + B * k + kk]; },
          [&](int i, int j, double x) { Tl[(B * ib + i) * LD + B * jb + j] -= x; });
   };
+  f64x4 dacc = {0.0, 0.0, 0.0, 0.0};               // wavefront 0: the diagonal block it is about to factor
+#ifndef VGG_CHOL_F16_LDS
+  if (wave == 0) dacc = load_block16_sym<LD>(D, 0);
+#endif
 #pragma unroll 1
   for (int kb = 0; kb < 4; ++kb) {
     F64_STAMP(8 * kb);
@@ -1273,7 +1288,7 @@ __device__ __forceinline__ void factor64_blocked(double* D, double* Tl, double* 
 #ifdef VGG_CHOL_F16_LDS                           // A/B: the LDS form of the 16 x 16 factorisation
       bad = factor16_wave<LD>(D, Tl, kb, scr) || bad;
 #else
-      bad = factor16_mfma<LD>(D, Tl, kb) || bad;
+      bad = factor16_mfma<LD>(dacc, D, Tl, kb) || bad;
 #endif
       F64_STAMP(8 * kb + 2);
     } else if (kb > 0) {
@@ -1299,21 +1314,32 @@ __device__ __forceinline__ void factor64_blocked(double* D, double* Tl, double* 
     // panels: L[ib][kb] = D[ib][kb] T_kk (ib > kb), E[ib][kb] = E[ib][kb] T_kk (ib < kb): three products.
     // Wavefront 0 has the block under the diagonal, the one the next diagonal block waits for: it forms the product
     // TRANSPOSED, so that its accumulator registers are the matrix-core operands of X X^T as they stand (k taken in the
-    // order lk + 4 reg on both sides), and updates the next diagonal block at once -- no pass through LDS, no barrier.
+    // order lk + 4 reg on both sides), and takes the next diagonal block (every earlier update is in LDS by now) minus
+    // X X^T straight into the registers it factors from -- no pass through LDS, no barrier on that path.
     if (wave == 0 && kb < 3) {
       const int lane = tid & 63, li = lane & 15, lk = lane >> 4, ib = kb + 1;
-      f64x4 xt = {0.0, 0.0, 0.0, 0.0};
+#ifndef VGG_CHOL_F16_LDS
+      dacc = load_block16_sym<LD>(D, ib);
+#endif
+      f64x4 xa = {0.0, 0.0, 0.0, 0.0}, xb = {0.0, 0.0, 0.0, 0.0};
+      xa = __builtin_amdgcn_mfma_f64_16x16x4f64(Tl[(B * kb + lk) * LD + B * kb + li], D[(B * ib + li) * LD + B * kb + lk], xa, 0, 0, 0);
+      xb = __builtin_amdgcn_mfma_f64_16x16x4f64(Tl[(B * kb + 4 + lk) * LD + B * kb + li], D[(B * ib + li) * LD + B * kb + 4 + lk], xb, 0, 0, 0);
+      xa = __builtin_amdgcn_mfma_f64_16x16x4f64(Tl[(B * kb + 8 + lk) * LD + B * kb + li], D[(B * ib + li) * LD + B * kb + 8 + lk], xa, 0, 0, 0);
+      xb = __builtin_amdgcn_mfma_f64_16x16x4f64(Tl[(B * kb + 12 + lk) * LD + B * kb + li], D[(B * ib + li) * LD + B * kb + 12 + lk], xb, 0, 0, 0);
+      const f64x4 xt = xa + xb;
+      f64x4 xx = {0.0, 0.0, 0.0, 0.0}, xy = {0.0, 0.0, 0.0, 0.0};
+      xx = __builtin_amdgcn_mfma_f64_16x16x4f64(xt[0], xt[0], xx, 0, 0, 0);
+      xy = __builtin_amdgcn_mfma_f64_16x16x4f64(xt[1], xt[1], xy, 0, 0, 0);
+      xx = __builtin_amdgcn_mfma_f64_16x16x4f64(xt[2], xt[2], xx, 0, 0, 0);
+      xy = __builtin_amdgcn_mfma_f64_16x16x4f64(xt[3], xt[3], xy, 0, 0, 0);
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4)
-        xt = __builtin_amdgcn_mfma_f64_16x16x4f64(Tl[(B * kb + 4 * s4 + lk) * LD + B * kb + li], D[(B * ib + li) * LD + B * kb + 4 * s4 + lk], xt, 0, 0, 0);
-      f64x4 xx = {0.0, 0.0, 0.0, 0.0};
+      for (int reg = 0; reg < 4; ++reg) D[(B * ib + li) * LD + B * kb + lk + 4 * reg] = xt[reg];
+#ifdef VGG_CHOL_F16_LDS
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        D[(B * ib + li) * LD + B * kb + lk + 4 * reg] = xt[reg];
-        xx = __builtin_amdgcn_mfma_f64_16x16x4f64(xt[reg], xt[reg], xx, 0, 0, 0);
-      }
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) D[(B * ib + lk + 4 * reg) * LD + B * ib + li] -= xx[reg];
+      for (int reg = 0; reg < 4; ++reg) D[(B * ib + lk + 4 * reg) * LD + B * ib + li] -= xx[reg] + xy[reg];
+#else
+      dacc = dacc - (xx + xy);
+#endif
     } else if (wave < 3) {
       const int ib = (wave < 3 - kb) ? kb + 1 + wave : wave - (3 - kb);      // kb+1 .. 3, then 0 .. kb-1
       double* X = (wave < 3 - kb) ? D : Tl;

@@ -103,6 +103,7 @@ struct Ws {  // device workspace carve-up (pointers into the caller's buffer)
   double* gmax_pts;           // reduce buffer 2 (MAX): 1 double (padded to 8)
   double* stepsum;            // reduce buffer 3: cost, mcc, step_sq, xnorm_sq  (padded to 8)
   double *G, *hs, *Ms;        // per point: 6, 3, 3*kdsh
+  double *pdamp;              // per point: the damping of its block in unscaled coordinates, D^2 = dd / s^2 (3)
   double* T;                  // [C][BDp][1+kdsh]
   double* part_B;             // [kMaxWG] per-workgroup gradient max
   double* part_F;             // [kMaxWG][4]
@@ -159,6 +160,7 @@ static Ws carve(const Dims& d, int max_iters, int num_chunks, int num_segments, 
   w.gmax_pts = (double*)take(64);
   w.stepsum = (double*)take(64);
   w.G = (double*)take(8ull * 6 * d.P); w.hs = (double*)take(8ull * 3 * d.P);
+  w.pdamp = (double*)take(8ull * 3 * d.P);
   w.Ms = (double*)take(8ull * 3 * (d.kdsh ? d.kdsh : 1) * d.P);
   w.T = (double*)take(8ull * d.C * d.BDp * (1 + d.kdsh));
   w.part_B = (double*)take(8ull * kMaxWG);
@@ -730,7 +732,7 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
 #pragma unroll
       for (int k = 0; k < 3; ++k) s[k] = w.scale_p[3 * p + k];
     }
-    double Gm[6] = {0, 0, 0, 0, 0, 0}, hs[3] = {0, 0, 0};
+    double Gm[6] = {0, 0, 0, 0, 0, 0}, hs[3] = {0, 0, 0}, pd[3] = {0, 0, 0};
     double Ms[3 * (KD ? KD : 1)];
 #pragma unroll
     for (int i = 0; i < 3 * (KD ? KD : 1); ++i) Ms[i] = 0;
@@ -738,6 +740,8 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
       double dd[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) dd[k] = fmin(fmax(colsq[k] * s[k] * s[k], opt.min_lm_diagonal), opt.max_lm_diagonal) / radius;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pd[k] = dd[k] / (s[k] * s[k]);
       const double a00 = V[0] * s[0] * s[0] + dd[0], a10 = V[1] * s[0] * s[1], a20 = V[2] * s[0] * s[2];
       const double a11 = V[3] * s[1] * s[1] + dd[1], a21 = V[4] * s[1] * s[2], a22 = V[5] * s[2] * s[2] + dd[2];
       bool ok = a00 > 0;
@@ -864,7 +868,7 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
 #pragma unroll
       for (int i = 0; i < 6; ++i) w.G[6 * (size_t)p + i] = Gm[i];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) w.hs[3 * (size_t)p + i] = hs[i];
+      for (int i = 0; i < 3; ++i) { w.hs[3 * (size_t)p + i] = hs[i]; w.pdamp[3 * (size_t)p + i] = pd[i]; }
       if (KD > 0 && kdsh) {
 #pragma unroll
         for (int i = 0; i < 3 * KD; ++i) w.Ms[(size_t)p * 3 * kdsh + i] = Ms[i];
@@ -1527,10 +1531,14 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
       }
     }
     double t3[3] = {0, 0, 0};
-    // cached values of this lane's first observation (tracks longer than LPP recompute)
-    double c_r[2] = {0, 0}, c_fy[2] = {0, 0}, c_E[6] = {0, 0, 0, 0, 0, 0};
+    // Model cost change without a second evaluation of the Jacobians.  With m = -(F dy + E ys) the model residual of an
+    // observation (Ceres: -sum m.(r + m/2)), the sum over the observations of a point is
+    //   sum [F dy . r - |F dy|^2 / 2]  +  ys^T g - ys^T t3 - ys^T V ys / 2        (g = sum E^T r, t3 = sum E^T F dy, V = sum E^T E)
+    // and with (V + D^2) ys = g - t3 and (V + D^2)^-1 = G G^T (point_pass):  ys^T (g - t3) = |G^-1 ys|^2 =: |z|^2, so
+    //   = sum [F dy . r - |F dy|^2 / 2]  +  |z|^2 / 2  +  ys^T D^2 ys / 2.
+    // The bracket is accumulated in the first sweep; the second sweep only evaluates the candidate's residuals.
     for (int o = o0 + sl; o < o1; o += LPP) {
-      const int pass = (o - o0) / LPP; const bool head = pass == 0;
+      const int pass = (o - o0) / LPP;
       const int c = f_pf.cam(pass, pb.obs_cam, o);
       const float2 uv = f_pf.uv(pass, pb.obs_uv, o);
       const int a = d.shared ? 0 : c;
@@ -1547,11 +1555,7 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
 #pragma unroll
       for (int k = 0; k < KD; ++k) { const double v = w.dy[6 * d.C + KD * a + k]; fy0 += F[6 + k] * v; fy1 += F[BD + 6 + k] * v; }
       t3[0] += E[0] * fy0 + E[3] * fy1; t3[1] += E[1] * fy0 + E[4] * fy1; t3[2] += E[2] * fy0 + E[5] * fy1;
-      if (head) {
-        c_r[0] = r[0]; c_r[1] = r[1]; c_fy[0] = fy0; c_fy[1] = fy1;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) c_E[k] = E[k];
-      }
+      s_mcc += fy0 * (r[0] - 0.5 * fy0) + fy1 * (r[1] - 0.5 * fy1);
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) t3[i] = group_sum<LPP>(t3[i]);
@@ -1568,35 +1572,17 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
       w.cand_pts[3 * (size_t)p] = Xn[0]; w.cand_pts[3 * (size_t)p + 1] = Xn[1]; w.cand_pts[3 * (size_t)p + 2] = Xn[2];
       s_step += ys[0] * ys[0] + ys[1] * ys[1] + ys[2] * ys[2];
       if (!pt_c) s_xn += X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
+      if (G22 != 0.0) {                                  // (constant / unobserved points: G = 0, ys = 0)
+        const double z2 = ys[2] / G22, z1 = (ys[1] - G12 * z2) / G11, z0 = (ys[0] - G01 * z1 - G02 * z2) / G00;
+        const double* pd = w.pdamp + 3 * (size_t)p;
+        s_mcc += 0.5 * (z0 * z0 + z1 * z1 + z2 * z2) + 0.5 * (pd[0] * ys[0] * ys[0] + pd[1] * ys[1] * ys[1] + pd[2] * ys[2] * ys[2]);
+      }
     }
     for (int o = o0 + sl; o < o1; o += LPP) {
-      const int pass = (o - o0) / LPP; const bool head = pass == 0;
+      const int pass = (o - o0) / LPP;
       const int c = f_pf.cam(pass, pb.obs_cam, o);
       const int a = d.shared ? 0 : c;
       const float2 uv = f_pf.uv(pass, pb.obs_uv, o);
-      double r[2], fy[2], E[6];
-      if (head) {
-        r[0] = c_r[0]; r[1] = c_r[1]; fy[0] = c_fy[0]; fy[1] = c_fy[1];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) E[k] = c_E[k];
-      } else {
-        double F[2 * BD];
-        if (LDSCAM)
-          eval_full<KD>(d, lq + 9 * c, lt + 3 * c, pb.intr + 4 * a, X, uv, (unsigned)lfl[c],
-                        pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
-        else
-          eval_full<KD>(d, CamR(pb.cam_q + 4 * c).R, pb.cam_t + 3 * c, pb.intr + 4 * a, X, uv,
-                        pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E);
-        fy[0] = 0; fy[1] = 0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) { const double v = LDSCAM ? ldy[6 * c + k] : w.dy[6 * c + k]; fy[0] += F[k] * v; fy[1] += F[BD + k] * v; }
-#pragma unroll
-        for (int k = 0; k < KD; ++k) { const double v = w.dy[6 * d.C + KD * a + k]; fy[0] += F[6 + k] * v; fy[1] += F[BD + 6 + k] * v; }
-      }
-      // model residual of the step s = -y:  m = -(F dy + E ys)
-      const double m0 = -(fy[0] + E[0] * ys[0] + E[1] * ys[1] + E[2] * ys[2]);
-      const double m1 = -(fy[1] + E[3] * ys[0] + E[4] * ys[1] + E[5] * ys[2]);
-      s_mcc += -(m0 * (r[0] + m0 / 2.0) + m1 * (r[1] + m1 / 2.0));
       double rc[2];
       if (LDSCAM) obs_residual_R(d.model, lcq + 9 * c, lct + 3 * c, w.cand_intr + 4 * a, Xn, (double)uv.x, (double)uv.y, rc);
       else obs_residual_R(d.model, CamR(w.cand_q + 4 * c).R, w.cand_t + 3 * c, w.cand_intr + 4 * a, Xn, (double)uv.x, (double)uv.y, rc);

@@ -71,24 +71,6 @@ int main(int argc, char** argv) {
     tr = nullptr; hipMemcpyToSymbol(HIP_SYMBOL(vgg::g_chol_trace), &tr, sizeof(tr));
   }
 #endif
-#ifdef VGG_F64_TRACE
-  {
-    unsigned long long* tr; hipMalloc(&tr, 64 * 8); hipMemset(tr, 0, 64 * 8);
-    hipMemcpyToSymbol(HIP_SYMBOL(vgg::g_f64_trace), &tr, sizeof(tr));
-    hipMemcpyAsync(dA, d0, A.size() * 8, hipMemcpyDeviceToDevice, st);
-    vgg::cholesky_solve_enqueue(dA, dA + (size_t)n * n, n, ws, fail, nullptr, st, nullptr, split_a, split_b, nullptr, false);
-    hipStreamSynchronize(st);
-    unsigned long long h[64]; hipMemcpy(h, tr, sizeof(h), hipMemcpyDeviceToHost);
-    printf("factor64_blocked of workgroup 0, shader clocks: per 16-block [update(kb,kb) factor16 barrier panel barrier] / factor16 steps\n");
-    for (int kb = 0; kb < 4; ++kb) {
-      const unsigned long long* s = h + 8 * kb; const unsigned long long* f = h + 32 + 8 * kb;
-      printf("kb=%d: %5llu %5llu %5llu %5llu %5llu | steps %5llu %5llu %5llu %5llu scale %5llu\n", kb, s[1] - s[0], s[2] - s[1], s[3] - s[2], s[4] - s[3], s[5] - s[4],
-             f[1] - f[0], f[2] - f[1], f[3] - f[2], f[4] - f[3], s[2] - f[4]);
-    }
-    printf("total %llu clocks\n", h[29] - h[0]);
-    tr = nullptr; hipMemcpyToSymbol(HIP_SYMBOL(vgg::g_f64_trace), &tr, sizeof(tr));
-  }
-#endif
   // residual check
   std::vector<double> x(n);
   hipMemcpy(x.data(), dA + (size_t)n * n, n * 8, hipMemcpyDeviceToHost);

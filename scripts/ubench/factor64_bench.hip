@@ -1,5 +1,7 @@
 // factor64_blocked (csrc/chol.hip) alone: one workgroup factors the same 64 x 64 block ITERS times out of LDS.
-// Compile-time ablations: -DVGG_F16_ABL=<mask> (chol.hip), -DNOFACTOR (load/copy only: the harness overhead).
+// -DNOFACTOR: load / copy only (the harness overhead, 1.8 us).  The ablation switches of the first, LDS-based 16 x 16
+// routine (-DVGG_F16_ABL=<mask>: no fences / no identity rows / no update / no pivot chain / empty loop) went with it:
+// commit 9f5c616 has both.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

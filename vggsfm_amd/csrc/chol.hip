@@ -228,9 +228,6 @@ __device__ __forceinline__ void factor_diag_lds4_la(double* D, double* Tl, doubl
   }
   // pivot chain of the 4 x 4 block (values given) -> record; every lane of the calling wavefront computes the same
   auto chain = [&](double d0, double u10, double p11, double u20, double p21, double p22, double u30, double p31, double p32, double p33) {
-#if VGG_F16_ABL & 8
-    const double r0 = 1.0, r1 = 1.0, r2 = 1.0, r3 = 1.0, m10 = u10, m20 = u20, m30 = u30, m21 = p21, m31 = p31, m32 = p32, d1 = p11, d2 = p22, d3 = p33, u21 = p21, u31 = p31, u32 = p32;
-#else
     const double r0 = fast_rcp<1>((d0 > 0.0) ? d0 : 1.0);
     const double m10 = u10 * r0, m20 = u20 * r0, m30 = u30 * r0;
     const double d1 = p11 - u10 * m10;
@@ -243,7 +240,6 @@ __device__ __forceinline__ void factor_diag_lds4_la(double* D, double* Tl, doubl
     const double m32 = u32 * r2;
     const double d3 = ((p33 - u30 * m30) - u31 * m31) - u32 * m32;
     const double r3 = fast_rcp<1>((d3 > 0.0) ? d3 : 1.0);
-#endif
     if (!(d0 > 0.0) || !(d0 < HUGE_) || !(d1 > 0.0) || !(d1 < HUGE_) || !(d2 > 0.0) || !(d2 < HUGE_) || !(d3 > 0.0) || !(d3 < HUGE_))
       bad = true;
     if ((tid & 63) == 0) {
@@ -958,16 +954,15 @@ __device__ __forceinline__ void factor64(double* D, double* Tl, double* rd, doub
 
 // ------------------------------------------------------------------------------------------------------------------
 // Round 3: the 64 x 64 diagonal block as FOUR 16 x 16 blocks (blocked right-looking), instead of two 32 x 32 ones.
-//   * A 16 x 16 diagonal block is factored by ONE wavefront out of registers (lane = (row, quarter of the columns),
-//     four pivot columns per step; pivot block, panel entries and multipliers go through a few hundred bytes of LDS
-//     scratch -- LDS is in order per wavefront, so no barrier), its inverse transpose riding along as rows of the
-//     identity (factor16_wave): the dependent fp64 chain of the pivots is what it was, the three workgroup barriers per
-//     step are gone.
+//   * A 16 x 16 diagonal block is factored by ONE wavefront with the block in a matrix-core accumulator (factor16_mfma
+//     below), its inverse transpose coming out of the same pass.
 //   * Everything else is 16 x 16 x 16 products on the matrix cores (mm16): the panel (block column kb times T_kk), the
 //     trailing update, and the same column operations on the rows of the identity, which leave T = L^-T in Tl.
-//   * Only A(kb) = [update (kb, kb)] + factor16 sits on the critical path of wavefront 0; the other trailing products of
-//     step kb - 1 are done by wavefronts 1..3 meanwhile; two barriers per 16 columns.
-// The factor differs from factor64_pairs in the last bits only (order of the trailing sums).
+//   * Only the panel block under the diagonal + the 16 x 16 factorisation sit on the critical path (wavefront 0, the next
+//     diagonal block carried in its registers); the other trailing products of step kb - 1 are done by wavefronts 1..3
+//     meanwhile; two barriers per 16 columns.
+// (The first form of the 16 x 16 routine -- lane = (row, quarter of the columns), panel and multipliers exchanged through
+//  LDS -- and its compile-time ablations are in the history: commit 9f5c616)
 template <class FA, class FB, class FO>
 __device__ __forceinline__ void mm16(FA opA, FB opB, FO out) {
   const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
@@ -977,13 +972,6 @@ __device__ __forceinline__ void mm16(FA opA, FB opB, FO out) {
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) out(lk + 4 * reg, li, acc[reg]);
 }
-
-#ifdef VGG_F64_TRACE                                // shader-clock stamps of workgroup 0 inside factor64_blocked (scripts/ubench)
-__device__ unsigned long long* g_f64_trace = nullptr;
-#define F64_STAMP(slot) do { if (g_f64_trace && blockIdx.x == 0 && threadIdx.x == 0) g_f64_trace[slot] = __builtin_readcyclecounter(); } while (0)
-#else
-#define F64_STAMP(slot) do { } while (0)
-#endif
 
 // rsqrt / sqrt of a positive double from the hardware estimate + two Newton steps and one correction of the root (the
 // library sqrt and the division behind it are ~70 dependent operations, four times per 64 x 64 block)
@@ -997,167 +985,8 @@ __device__ __forceinline__ void fast_rsqrt_sqrt(double x, double& rs, double& sd
   rs = r; sd = s;
 }
 
-// four at once, stage by stage (four independent dependent chains: written interleaved so that they are issued so)
-__device__ __forceinline__ void fast_rsqrt_sqrt4(const double (&x)[4], double (&rs)[4], double (&sd)[4]) {
-  double r[4], h[4], s[4], t[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) { r[c] = __builtin_amdgcn_rsq(x[c]); h[c] = 0.5 * x[c]; }
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) t[c] = -h[c] * r[c];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) t[c] = __builtin_fma(t[c], r[c], 1.5);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) r[c] = r[c] * t[c];
-  }
-#pragma unroll
-  for (int c = 0; c < 4; ++c) s[c] = x[c] * r[c];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) t[c] = __builtin_fma(-s[c], s[c], x[c]);
-#pragma unroll
-  for (int c = 0; c < 4; ++c) { sd[c] = __builtin_fma(0.5 * r[c], t[c], s[c]); rs[c] = r[c]; }
-}
-
-// wavefront-level ordering of LDS accesses that alias through different pointers (same wavefront: the hardware keeps the
-// order, the compiler must too)
-#ifndef VGG_F16_ABL
-#define VGG_F16_ABL 0
-#endif
-__device__ __forceinline__ void wave_lds_fence() {
-#if !(VGG_F16_ABL & 1)
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-}
-
-// the 16 x 16 block at (16 kb, 16 kb) of D (LDS, ld = LD, lower triangle valid) -> L_kk in place, T_kk = L_kk^-T (upper) in
-// the same block of Tl.  Called by ONE wavefront (all 64 lanes).  scr: 16 + 3 * 64 doubles of LDS.
-template <int LD>
-__device__ __forceinline__ bool factor16_wave(double* D, double* Tl, int kb, double* scr) {
-  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-  double* P4 = scr;                 // [4][4] pivot block / [16] diagonal
-  double* U = scr + 16;             // [16][4] unnormalised panel entries of the rows of A
-  double* V = U + 64;               // [16][4] u_rt / d_t
-  double* UE = V + 64;              // [16][4] panel entries of the rows of the identity
-  double a[4], e[4];
-  double rsv[4] = {1.0, 1.0, 1.0, 1.0}, sdv[4] = {1.0, 1.0, 1.0, 1.0};      // 1 / sqrt(d_c), sqrt(d_c) of this lane's four columns
-  double dprev[4] = {1.0, 1.0, 1.0, 1.0};
-  double* Dr = D + (16 * kb + r) * LD + 16 * kb + 4 * q;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) { a[c] = Dr[c]; e[c] = (r == 4 * q + c) ? 1.0 : 0.0; }
-  bool bad = false;
-  constexpr double HUGE_ = 1.7976931348623157e308;
-#pragma unroll
-  for (int j0 = 0; j0 < ((VGG_F16_ABL & 16) ? 0 : 16); j0 += 4) {
-    const int qq = j0 / 4;
-    const bool mine = (q == qq);
-    F64_STAMP(32 + 8 * kb + qq);
-    wave_lds_fence();
-    if (mine && r >= j0 && r < j0 + 4) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) P4[(r - j0) * 4 + c] = a[c];
-    }
-    wave_lds_fence();
-    const double d0 = P4[0];
-    const double u10 = P4[4], p11 = P4[5];
-    const double u20 = P4[8], p21 = P4[9], p22 = P4[10];
-    const double u30 = P4[12], p31 = P4[13], p32 = P4[14], p33 = P4[15];
-    // the column scales of the PREVIOUS four pivots: independent work that fills the wait for the block just read
-    if (j0 > 0) {
-      double rs[4], sd[4];
-      fast_rsqrt_sqrt4(dprev, rs, sd);
-      if (q == qq - 1) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { rsv[c] = rs[c]; sdv[c] = sd[c]; }
-      }
-    }
-#if VGG_F16_ABL & 8
-    const double r0 = 1.0, r1 = 1.0, r2 = 1.0, r3 = 1.0, m10 = u10, m20 = u20, m30 = u30, m21 = p21, m31 = p31, m32 = p32, d1 = p11, d2 = p22, d3 = p33, u21 = p21, u31 = p31, u32 = p32;
-#else
-    const double r0 = fast_rcp<1>((d0 > 0.0) ? d0 : 1.0);
-    const double m10 = u10 * r0, m20 = u20 * r0, m30 = u30 * r0;
-    const double d1 = p11 - u10 * m10;
-    const double u21 = p21 - u20 * m10, u31 = p31 - u30 * m10;
-    const double r1 = fast_rcp<1>((d1 > 0.0) ? d1 : 1.0);
-    const double m21 = u21 * r1, m31 = u31 * r1;
-    const double d2 = (p22 - u20 * m20) - u21 * m21;
-    const double u32 = (p32 - u30 * m20) - u31 * m21;
-    const double r2 = fast_rcp<1>((d2 > 0.0) ? d2 : 1.0);
-    const double m32 = u32 * r2;
-    const double d3 = ((p33 - u30 * m30) - u31 * m31) - u32 * m32;
-    const double r3 = fast_rcp<1>((d3 > 0.0) ? d3 : 1.0);
-#endif
-    if (!(d0 > 0.0) || !(d0 < HUGE_) || !(d1 > 0.0) || !(d1 < HUGE_) || !(d2 > 0.0) || !(d2 < HUGE_) || !(d3 > 0.0) || !(d3 < HUGE_))
-      bad = true;
-    dprev[0] = (d0 > 0.0) ? d0 : 1.0; dprev[1] = (d1 > 0.0) ? d1 : 1.0; dprev[2] = (d2 > 0.0) ? d2 : 1.0; dprev[3] = (d3 > 0.0) ? d3 : 1.0;
-    // panel entries of this lane's row (the lanes that hold the four panel columns)
-    const bool liveA = r >= j0 + 4, liveE = r < j0 + 4;
-    double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0, y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
-    if (mine) {
-      if (liveA) {
-        x0 = a[0];
-        x1 = a[1] - x0 * m10;
-        x2 = (a[2] - x0 * m20) - x1 * m21;
-        x3 = ((a[3] - x0 * m30) - x1 * m31) - x2 * m32;
-      }
-      if (liveE && !(VGG_F16_ABL & 2)) {
-        y0 = e[0];
-        y1 = e[1] - y0 * m10;
-        y2 = (e[2] - y0 * m20) - y1 * m21;
-        y3 = ((e[3] - y0 * m30) - y1 * m31) - y2 * m32;
-      }
-      double* Ur = U + r * 4;
-      double* Vr = V + r * 4;
-      double* Er = UE + r * 4;
-      Ur[0] = x0; Ur[1] = x1; Ur[2] = x2; Ur[3] = x3;
-      Vr[0] = x0 * r0; Vr[1] = x1 * r1; Vr[2] = x2 * r2; Vr[3] = x3 * r3;
-      Er[0] = y0; Er[1] = y1; Er[2] = y2; Er[3] = y3;
-    }
-    wave_lds_fence();
-    // rank-4 update of this lane's four columns (columns beyond the panel)
-    if (4 * q >= j0 + 4) {
-      const double ui0 = U[r * 4], ui1 = U[r * 4 + 1], ui2 = U[r * 4 + 2], ui3 = U[r * 4 + 3];
-      const double ei0 = UE[r * 4], ei1 = UE[r * 4 + 1], ei2 = UE[r * 4 + 2], ei3 = UE[r * 4 + 3];
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        const int c = 4 * q + cc;
-        const double v0 = V[c * 4], v1 = V[c * 4 + 1], v2 = V[c * 4 + 2], v3 = V[c * 4 + 3];
-        if (r >= c && !(VGG_F16_ABL & 4)) { double t = a[cc]; t -= ui0 * v0; t -= ui1 * v1; t -= ui2 * v2; t -= ui3 * v3; a[cc] = t; }
-        if (liveE && !(VGG_F16_ABL & 2)) { double t = e[cc]; t -= ei0 * v0; t -= ei1 * v1; t -= ei2 * v2; t -= ei3 * v3; e[cc] = t; }
-      }
-    }
-    // the panel columns take their unnormalised values
-    if (mine) {
-      if (liveA) { a[0] = x0; a[1] = x1; a[2] = x2; a[3] = x3; }
-      if (liveE) { e[0] = y0; e[1] = y1; e[2] = y2; e[3] = y3; }
-      if (r == j0 + 1) a[1] = d1;
-      if (r == j0 + 2) { a[1] = u21; a[2] = d2; }
-      if (r == j0 + 3) { a[1] = u31; a[2] = u32; a[3] = d3; }
-    }
-  }
-  // column scaling by 1 / sqrt(d_c)
-  F64_STAMP(32 + 8 * kb + 4);
-  {
-    double rs[4], sd[4];
-    fast_rsqrt_sqrt4(dprev, rs, sd);
-    if (q == 3) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { rsv[c] = rs[c]; sdv[c] = sd[c]; }
-    }
-  }
-  double* Tr = Tl + (16 * kb + r) * LD + 16 * kb + 4 * q;
-#pragma unroll
-  for (int cc = 0; cc < 4; ++cc) {
-    const int c = 4 * q + cc;
-    if (r > c) Dr[cc] = a[cc] * rsv[cc];
-    else if (r == c) Dr[cc] = sdv[cc];
-    Tr[cc] = (r <= c) ? e[cc] * rsv[cc] : 0.0;
-  }
-  wave_lds_fence();
-  return bad;
-}
-
-// The same 16 x 16 factorisation with the block in ONE matrix-core accumulator and no LDS traffic inside the loop.
+// The 16 x 16 block at (16 kb, 16 kb): L_kk into D, T_kk = L_kk^-T (upper triangular) into the same block of Tl, by ONE
+// wavefront with the block in ONE matrix-core accumulator and no LDS traffic inside the loop.
 //   * The (symmetric, fully kept) block sits in the C layout of v_mfma_f64_16x16x4: lane (li, lk) holds the entries
 //     (row lk + 4 reg, column li) -- by symmetry also row li, columns lk + 4 reg.  So the four panel columns 4 qq .. 4 qq + 3
 //     of ALL rows are register acc[qq], and they are laid out exactly as a matrix-core operand (row li, k = lk).
@@ -1277,20 +1106,11 @@ __device__ __forceinline__ void factor64_blocked(double* D, double* Tl, double* 
          [&](int i, int j, double x) { Tl[(B * ib + i) * LD + B * jb + j] -= x; });
   };
   f64x4 dacc = {0.0, 0.0, 0.0, 0.0};               // wavefront 0: the diagonal block it is about to factor
-#ifndef VGG_CHOL_F16_LDS
   if (wave == 0) dacc = load_block16_sym<LD>(D, 0);
-#endif
 #pragma unroll 1
   for (int kb = 0; kb < 4; ++kb) {
-    F64_STAMP(8 * kb);
     if (wave == 0) {
-      F64_STAMP(8 * kb + 1);
-#ifdef VGG_CHOL_F16_LDS                           // A/B: the LDS form of the 16 x 16 factorisation
-      bad = factor16_wave<LD>(D, Tl, kb, scr) || bad;
-#else
       bad = factor16_mfma<LD>(dacc, D, Tl, kb) || bad;
-#endif
-      F64_STAMP(8 * kb + 2);
     } else if (kb > 0) {
       // the rest of the trailing update of step k = kb - 1, dealt to wavefronts 2, 3, 1, 2, 3, 1 ...; wavefront 1 first hands
       // on the columns of T that step k completed (they are not touched again)
@@ -1310,7 +1130,6 @@ __device__ __forceinline__ void factor64_blocked(double* D, double* Tl, double* 
         }
     }
     __syncthreads();                 // L_kk, T_kk and every update of step kb - 1 are in LDS
-    F64_STAMP(8 * kb + 3);
     // panels: L[ib][kb] = D[ib][kb] T_kk (ib > kb), E[ib][kb] = E[ib][kb] T_kk (ib < kb): three products.
     // Wavefront 0 has the block under the diagonal, the one the next diagonal block waits for: it forms the product
     // TRANSPOSED, so that its accumulator registers are the matrix-core operands of X X^T as they stand (k taken in the
@@ -1318,9 +1137,7 @@ __device__ __forceinline__ void factor64_blocked(double* D, double* Tl, double* 
     // X X^T straight into the registers it factors from -- no pass through LDS, no barrier on that path.
     if (wave == 0 && kb < 3) {
       const int lane = tid & 63, li = lane & 15, lk = lane >> 4, ib = kb + 1;
-#ifndef VGG_CHOL_F16_LDS
       dacc = load_block16_sym<LD>(D, ib);
-#endif
       f64x4 xa = {0.0, 0.0, 0.0, 0.0}, xb = {0.0, 0.0, 0.0, 0.0};
       xa = __builtin_amdgcn_mfma_f64_16x16x4f64(Tl[(B * kb + lk) * LD + B * kb + li], D[(B * ib + li) * LD + B * kb + lk], xa, 0, 0, 0);
       xb = __builtin_amdgcn_mfma_f64_16x16x4f64(Tl[(B * kb + 4 + lk) * LD + B * kb + li], D[(B * ib + li) * LD + B * kb + 4 + lk], xb, 0, 0, 0);
@@ -1334,21 +1151,14 @@ __device__ __forceinline__ void factor64_blocked(double* D, double* Tl, double* 
       xy = __builtin_amdgcn_mfma_f64_16x16x4f64(xt[3], xt[3], xy, 0, 0, 0);
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) D[(B * ib + li) * LD + B * kb + lk + 4 * reg] = xt[reg];
-#ifdef VGG_CHOL_F16_LDS
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) D[(B * ib + lk + 4 * reg) * LD + B * ib + li] -= xx[reg] + xy[reg];
-#else
       dacc = dacc - (xx + xy);
-#endif
     } else if (wave < 3) {
       const int ib = (wave < 3 - kb) ? kb + 1 + wave : wave - (3 - kb);      // kb+1 .. 3, then 0 .. kb-1
       double* X = (wave < 3 - kb) ? D : Tl;
       mm16([&](int i, int kk) { return X[(B * ib + i) * LD + B * kb + kk]; }, [&](int j, int kk) { return Tl[(B * kb + kk) * LD + B * kb + j]; },
            [&](int i, int j, double x) { X[(B * ib + i) * LD + B * kb + j] = x; });
     }
-    F64_STAMP(8 * kb + 4);
     __syncthreads();
-    F64_STAMP(8 * kb + 5);
   }
   if (bad && (tid & 63) == 0) *fail = 1;
   __syncthreads();

@@ -37,13 +37,29 @@ def depth_order(first_of, kstart, c):
     return sorted(ks, key=lambda k: (depth[k], k))
 
 
-def schedule(nbk, first_of, chain):
+def tile_map(nbk, first_of, chain):
+    """df_tile_map_kernel restated: the launch order used with a row envelope -- columns by dependency depth (the merged
+    workgroup of tile (c + 1, c) also takes the updates of row c + 1), then by index; tiles outside the envelope and the
+    diagonal tiles finished by a merged workgroup are left out.  -> list of (c, r)"""
+    def chained(x):
+        return chain and 1 <= x < nbk and first_of(x) <= x - 1
+    dep = []
+    for c in range(nbk):
+        lo = first_of(c)
+        if chained(c + 1):
+            lo = min(lo, first_of(c + 1))
+        dep.append(1 + max([dep[k] for k in range(lo, c)], default=0))
+    cols = sorted(range(nbk), key=lambda c: (dep[c], c))
+    return [(c, r) for c in cols for r in range(c, nbk + 1) if first_of(r) <= c and not (r == c and chained(c))]
+
+
+def schedule(nbk, first_of, chain, order=None):
     """-> list of workgroups in launch order: dict(tile, waits [flag names in program order], raises [flag names])"""
     def chained(x):
         return chain and 1 <= x < nbk and first_of(x) <= x - 1
     wgs = []
-    for c in range(nbk):
-        for r in range(c, nbk + 1):
+    for c, r in (order if order is not None else [(c, r) for c in range(nbk) for r in range(c, nbk + 1)]):
+        if True:
             wg = dict(tile=(r, c), waits=[], raises=[])
             wgs.append(wg)
             if c < first_of(r):
@@ -70,8 +86,8 @@ def schedule(nbk, first_of, chain):
     return wgs
 
 
-def check(nbk, first_of, chain):
-    wgs = schedule(nbk, first_of, chain)
+def check(nbk, first_of, chain, order=None):
+    wgs = schedule(nbk, first_of, chain, order)
     raised_by = {}
     for i, wg in enumerate(wgs):
         for f in wg["raises"]:
@@ -108,7 +124,12 @@ def test_envelope_schedules_wait_only_for_earlier_workgroups(chain):
                 start = r                                             # a new decoupled block starts here
             first[r] = rng.integers(start, r + 1) if rng.random() < 0.7 else start
         first[-1] = 0
-        check(nbk, first_of_factory(nbk, first), chain)
+        fo = first_of_factory(nbk, first)
+        plain = check(nbk, fo, chain)
+        # the depth-ordered launch map of the enveloped launch: the same workgroups (minus the idle ones), still a topological order
+        mapped = check(nbk, fo, chain, tile_map(nbk, fo, chain))
+        busy = sorted(w["tile"] for w in plain if w["waits"] or w["raises"])
+        assert sorted(w["tile"] for w in mapped) == busy
 
 
 def test_video_envelope_from_the_camera_order():
@@ -125,7 +146,16 @@ def test_video_envelope_from_the_camera_order():
     nbk = (n + DFB - 1) // DFB
     assert (first_blk[1:nbk - 1] > 0).any()
     for chain in (False, True):
-        check(nbk, first_of_factory(nbk, first_blk), chain)
+        fo = first_of_factory(nbk, first_blk)
+        check(nbk, fo, chain)
+        order = tile_map(nbk, fo, chain)
+        check(nbk, fo, chain, order)
+    # every interior run starts on a 64-column block: its pivot chain is its own (block row r with first_blk[r] == r)
+    starts = [r for r in range(nbk) if first_blk[r] == r]
+    assert len(starts) >= 4, starts
+    # ... and the depth order interleaves the chains: the launch begins with the first column of EVERY run
+    cols_in_order = list(dict.fromkeys(c for c, r in order))
+    assert sorted(cols_in_order[:len(starts)]) == starts
 
 
 def test_depth_order_is_ascending_for_a_dense_matrix_and_puts_the_shorter_chain_first():

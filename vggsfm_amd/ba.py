@@ -464,7 +464,14 @@ def find_camera_order(masks, group=GROUP, adjacency_reduce=None):
         return None, None
     chain, k = best
     rem = Gfull - (k - 1) * w
-    sizes = [rem // k + (1 if j < rem % k else 0) for j in range(k)]
+    # interior runs of an EVEN number of groups (96 columns each): every run then starts on a 64-column block of the
+    # factorisation -- a run that starts inside a block shares that block with its neighbour and the two pivot chains
+    # become one (c5: four runs, two chains).  An odd group left over goes to the last run.
+    pairs = rem // 2
+    sizes = [2 * (pairs // k + (1 if j < pairs % k else 0)) for j in range(k)]
+    sizes[-1] += rem - 2 * pairs
+    if min(sizes) < 1:
+        return None, None
     interiors, separators, pos = [], [], 0
     for j in range(k):
         interiors.append(list(range(pos, pos + sizes[j])))

@@ -901,7 +901,7 @@ __device__ unsigned long long* g_chol_trace = nullptr;      // [tiles][8] wall-c
 #else
 #define DF_STAMP_AT(tile, slot) do { } while (0)
 #endif
-#define DF_STAMP(slot) DF_STAMP_AT(blockIdx.x, slot)
+#define DF_STAMP(slot) DF_STAMP_AT(nat_tile, slot)
 
 // 32 x 32 x 32 product on the matrix cores by the four wavefronts of a workgroup, operands read from LDS through
 // accessors: out(i, j) <- sum_k opA(i, k) * opB(j, k); wavefront w owns the 16 x 16 tile (w >> 1, w & 1).
@@ -1189,7 +1189,7 @@ template <bool OVERLAP, bool CHAIN>
 __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__ A, int n, int nbk, double* __restrict__ Tinv,
                                                             int32_t* __restrict__ flags, int32_t* fail, const int32_t* skip,
                                                             int split_a, int split_b, const int32_t* __restrict__ first_blk,
-                                                            DfOverlap ov) {
+                                                            DfOverlap ov, const int32_t* __restrict__ tile_map) {
   static_assert(!(OVERLAP && CHAIN), "the chained form does not take the overlap flags");
   extern __shared__ double df_smem[];
   DfShared& sh = *reinterpret_cast<DfShared*>(df_smem);
@@ -1198,10 +1198,19 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
   // This launch is a latency chain with one wavefront per SIMD: whatever else is resident on the CU (a tile batch in
   // overlap mode; DESIGN.md section 6 on the boxes where something outside the process is) must not take its issue slots
   __builtin_amdgcn_s_setprio(3);
-  // tile of this workgroup: column c holds rows c .. nbk-1 and the rhs row block nbk
+  // tile of this workgroup: column c holds rows c .. nbk-1 and the rhs row block nbk; launch order = (column, row), or --
+  // with a row envelope -- the order of df_tile_map_kernel: columns by dependency depth, tiles outside the envelope left out
   int c = 0, t = blockIdx.x;
-  while (t >= nbk - c + 1) { t -= nbk - c + 1; ++c; }
+  if (tile_map) {
+    if (t >= tile_map[0]) return;
+    const int32_t e = tile_map[1 + t];
+    c = e & 0xffff; t = (e >> 16) - c;
+  } else {
+    while (t >= nbk - c + 1) { t -= nbk - c + 1; ++c; }
+  }
   const int r = c + t;                                  // r == nbk: the appended right-hand side (one row)
+  const int nat_tile = c * (nbk + 1) - c * (c - 1) / 2 + t;        // position in the (column, row) order: trace slot
+  (void)nat_tile;
   auto first_of = [&](int br) {
     if (first_blk) return (br < nbk) ? first_blk[br] : 0;                  // row envelope given by the caller
     return (split_b > 0 && br < nbk && DFB * br >= split_a && DFB * (br + 1) <= split_a + split_b) ? split_a / DFB : 0;
@@ -1401,7 +1410,7 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
     // (ready[b][b] is never waited for: L_bb only matters through T_b)
   };
   if (diag) {
-    factor_and_publish(c, c0, vc, blockIdx.x);
+    factor_and_publish(c, c0, vc, nat_tile);
     return;
   }
 
@@ -1544,12 +1553,65 @@ __global__ __launch_bounds__(256) void chol_backward_dataflow_kernel(const doubl
   df_publish(&xready[c]);
 }
 
+// LAUNCH ORDER with a row envelope.  In (column, row) order the tiles of a pivot chain that starts late in the matrix
+// (k-way camera order: the second, third ... interior run) are dispatched behind every tile of the columns before it, and
+// those wait, resident, for their own chain: at c5 (94 block columns, three side-by-side chains + separators) the 512
+// workgroup slots of the chip were taken by the first chain's columns and the chains ran one after the other (1.56 ms = 94
+// block columns back to back).  Here the columns are ordered by DEPTH in the dependence graph -- depth(c) = 1 + max depth
+// of the columns a tile of column c waits for -- then by index, tiles outside the envelope and the diagonal tiles that a
+// merged workgroup finishes are left out.  Still a topological order: a workgroup only ever waits for earlier ones.
+// map[0] = number of tiles, map[1 + i] = c | r << 16.  One workgroup; the depth recursion by its first wavefront.
+constexpr int kDfMapCols = 1024;
+__global__ __launch_bounds__(256) void df_tile_map_kernel(const int32_t* __restrict__ first_blk, int nbk, int chain, int32_t* __restrict__ map) {
+  __shared__ int32_t fo[kDfMapCols + 1], dep[kDfMapCols], cnt[kDfMapCols], off[kDfMapCols];
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int r = tid; r <= nbk; r += 256) fo[r] = (r < nbk) ? first_blk[r] : 0;
+  __syncthreads();
+  auto chained = [&](int x) { return chain && x >= 1 && x < nbk && fo[x] <= x - 1; };
+  if (tid < 64) {
+    volatile int32_t* d = dep;
+    for (int c = 0; c < nbk; ++c) {
+      int lo = fo[c];
+      if (chained(c + 1)) lo = min(lo, fo[c + 1]);           // (the merged workgroup of tile (c + 1, c) also takes row c + 1's updates)
+      int m = 0;
+      for (int k = lo + lane; k < c; k += 64) m = max(m, d[k]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+      if (lane == 0) d[c] = m + 1;
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < nbk; c += 256) {
+    int n = 0;
+    for (int r = c; r <= nbk; ++r) n += (fo[r] <= c) && !(r == c && chained(c));
+    cnt[c] = n;
+  }
+  __syncthreads();
+  for (int c = tid; c < nbk; c += 256) {
+    int o = 0;
+    const int dc = dep[c];
+    for (int k = 0; k < nbk; ++k) { const int dk = dep[k]; if (dk < dc || (dk == dc && k < c)) o += cnt[k]; }
+    off[c] = o;
+  }
+  __syncthreads();
+  for (int c = tid; c < nbk; c += 256) {
+    int o = off[c];
+    for (int r = c; r <= nbk; ++r)
+      if ((fo[r] <= c) && !(r == c && chained(c))) map[1 + o++] = c | (r << 16);
+  }
+  if (tid == 0) { int tot = 0; for (int c = 0; c < nbk; ++c) tot += cnt[c]; map[0] = tot; }
+}
+
 static size_t dataflow_flag_count(int n) {
   const int nbk = div_up(n, DFB);
   return (size_t)(nbk + 1) * nbk + 2 * (size_t)nbk;        // ready[(nbk + 1) nbk], tready[nbk], xready[nbk]
 }
-static size_t dataflow_workspace_bytes(int n) {
-  return (size_t)div_up(n, DFB) * DFB * DFB * sizeof(double) + dataflow_flag_count(n) * sizeof(int32_t) + 256;
+static size_t dataflow_tile_count(int n) {
+  const size_t nbk = div_up(n, DFB);
+  return nbk * (nbk + 1) / 2 + nbk;
+}
+static size_t dataflow_workspace_bytes(int n) {     // T blocks | flags | launch-order map (1 + tiles)
+  return (size_t)div_up(n, DFB) * DFB * DFB * sizeof(double) + (dataflow_flag_count(n) + 1 + dataflow_tile_count(n)) * sizeof(int32_t) + 256;
 }
 
 static inline int block_size_for(int n) { (void)n; return 32; }
@@ -1603,14 +1665,21 @@ static int enqueue_dataflow(double* A, double* b, int n, double* ws, int32_t* de
   }
   if (!(split_a >= DFB && split_b >= DFB && split_a % DFB == 0 && split_a + split_b <= n)) split_a = split_b = 0;
   const int tiles = nbk * (nbk + 1) / 2 + nbk;
+  // launch order by dependency depth when the caller gave a row envelope (VGG_CHOL_TILE_MAP=0: the plain order, A/B)
+  static const bool map_on = [] { const char* e = getenv("VGG_CHOL_TILE_MAP"); return !(e && e[0] == '0'); }();
+  int32_t* tile_map = nullptr;
+  if (first_blk && map_on && nbk <= kDfMapCols && !(overlap && overlap->dev_flags)) {
+    tile_map = flags + dataflow_flag_count(n);
+    df_tile_map_kernel<<<1, 256, 0, st>>>(first_blk, nbk, chain, tile_map);
+  }
   DfOverlap ov = {};
   if (overlap && overlap->dev_flags) {
     ov.S2 = overlap->S2; ov.flags = overlap->dev_flags; ov.first_col = overlap->first_col; ov.num_waits = overlap->num_waits;
     for (int k = 0; k < overlap->num_waits && k < 8; ++k) ov.wait_col[k] = overlap->wait_col[k];
   }
-  if (ov.S2) chol_dataflow_kernel<true, false><<<tiles, 256, sizeof(DfShared), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b, first_blk, ov);
-  else if (chain) chol_dataflow_kernel<false, true><<<tiles, 256, sizeof(DfShared), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b, first_blk, ov);
-  else chol_dataflow_kernel<false, false><<<tiles, 256, sizeof(DfShared), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b, first_blk, ov);
+  if (ov.S2) chol_dataflow_kernel<true, false><<<tiles, 256, sizeof(DfShared), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b, first_blk, ov, tile_map);
+  else if (chain) chol_dataflow_kernel<false, true><<<tiles, 256, sizeof(DfShared), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b, first_blk, ov, tile_map);
+  else chol_dataflow_kernel<false, false><<<tiles, 256, sizeof(DfShared), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b, first_blk, ov, tile_map);
   int32_t* xready = flags + (size_t)(nbk + 1) * nbk + nbk;
   chol_backward_dataflow_kernel<<<nbk, 256, 0, st>>>(A, b, n, nbk, Tinv, xready, device_fail, skip, split_a, split_b, first_blk);
   if (hipGetLastError() != hipSuccess) return VGG_ERR_HIP;

@@ -331,7 +331,9 @@ int vgg_cholesky_solve_split(double* A, double* b, int n, int split_a, int split
                              void* stream);
 /* the same with a row envelope: first_blk[r] (device, ceil(n / 64) entries) = first 64-column block in which rows
  * 64 r .. 64 r + 63 of A can be non-zero (see vgg_ba_problem.chol_first_blk); b must be stored directly behind A
- * (b == A + n * n) and n >= 128 for the envelope to be used (exposed for tests) */
+ * (b == A + n * n) and n >= 128 for the envelope to be used (exposed for tests).  With an envelope the tiles are launched
+ * in the order of their dependency depth and those outside it are not launched at all (one small set-up launch per call;
+ * VGG_CHOL_TILE_MAP=0 in the environment keeps the (column, row) order for measurements) */
 int vgg_cholesky_solve_envelope(double* A, double* b, int n, const int32_t* first_blk, void* workspace, int32_t* device_fail,
                                 void* stream);
 

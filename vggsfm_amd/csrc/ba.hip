@@ -685,8 +685,13 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
     // Jacobians of this lane's first observation for the Y sweep (tracks > LPP recompute): F and E, or -- compressed
     // factors -- the 2 x 3 d r / d (R X + t) instead of F
     double cF[CY ? 6 : 2 * BD], cE[6];
-    for (int o = o0 + sl; o < o1; o += LPP) {
-      const int pass = (o - o0) / LPP; const bool head = pass == 0;
+    // compressed factors (round 3): the 2 x 3 d r / d (R X + t) of the lane's first NPF observations is kept for the Y sweep,
+    // which then needs no second evaluation (E = Jw R, a = R X from the camera table); the sweeps are unrolled over those
+    // slices so that the kept values sit in registers; longer tracks re-evaluate the rest
+    constexpr bool KEEPJ = CY;
+    double cJ[KEEPJ ? NPF : 1][6];
+    auto sweep1 = [&](const int pass, const int o, double* keepJ) __attribute__((always_inline)) {
+      const bool head = pass == 0;
       const int c = f_pf.cam(pass, pb.obs_cam, o);
       const float2 uv = f_pf.uv(pass, pb.obs_uv, o);
       const int a = d.shared ? 0 : c;
@@ -698,11 +703,15 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
         eval_full<KD>(d, CamR(pb.cam_q + 4 * c).R, pb.cam_t + 3 * c, pb.intr + 4 * a, X, uv,
                       pb.cam_const ? pb.cam_const[c] : 0u, pb.intr_const ? pb.intr_const[a] != 0 : false, pt_c, r, F, E,
                       CY ? Jw : nullptr);
-      if (CACHEJ && head) {
+      if (CACHEJ && !KEEPJ && head) {
 #pragma unroll
         for (int i = 0; i < (CY ? 6 : 2 * BD); ++i) cF[i] = CY ? Jw[i] : F[i];
 #pragma unroll
         for (int i = 0; i < 6; ++i) cE[i] = E[i];
+      }
+      if (KEEPJ && keepJ) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) keepJ[i] = Jw[i];
       }
       V[0] += E[0] * E[0] + E[3] * E[3]; V[1] += E[0] * E[1] + E[3] * E[4]; V[2] += E[0] * E[2] + E[3] * E[5];
       V[3] += E[1] * E[1] + E[4] * E[4]; V[4] += E[1] * E[2] + E[4] * E[5]; V[5] += E[2] * E[2] + E[5] * E[5];
@@ -713,6 +722,16 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
 #pragma unroll
           for (int b = 0; b < 3; ++b) Wa[m * 3 + b] += F[6 + m] * E[b] + F[BD + 6 + m] * E[3 + b];
       }
+    };
+    if constexpr (KEEPJ) {
+#pragma unroll
+      for (int ps = 0; ps < NPF; ++ps) {
+        const int o = o0 + sl + ps * LPP;
+        if (o < o1) sweep1(ps, o, cJ[ps]);
+      }
+      for (int o = o0 + sl + NPF * LPP; o < o1; o += LPP) sweep1((o - o0) / LPP, o, nullptr);
+    } else {
+      for (int o = o0 + sl; o < o1; o += LPP) sweep1((o - o0) / LPP, o, nullptr);
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) V[i] = group_sum<LPP>(V[i]);
@@ -782,11 +801,22 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
     // segment buffer consumed by schur_tile_kernel
     if (VGG_PP_ABLATE != 2) {
       const int bdt = d.shared ? 6 : BD;          // rows of the tile block (intrinsics only when per camera)
-      for (int o = o0 + sl; o < o1; o += LPP) {
-        const int pass = (o - o0) / LPP; const bool head = pass == 0;
+      auto emit = [&](const int pass, const int o, const double* keptJ) __attribute__((always_inline)) {
+        const bool head = pass == 0;
         const int c = f_pf.cam(pass, pb.obs_cam, o);
         double F[CY ? 6 : 2 * BD], E[6];          // (CY: F holds the 2 x 3 Jw)
-        if (CACHEJ && head) {                     // cached Jacobians of the first slice
+        if (KEEPJ && keptJ) {                     // kept from the first sweep: E = Jw R as obs_eval_R forms it
+          double Rl[9];
+          const double* Rc = Rl;
+          if (LDSCAM) Rc = lq + 9 * c; else quat_to_R(pb.cam_q + 4 * c, Rl);
+#pragma unroll
+          for (int i = 0; i < 6; ++i) F[i] = keptJ[i];
+#pragma unroll
+          for (int row = 0; row < 2; ++row)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+              E[3 * row + k] = pt_c ? 0.0 : keptJ[3 * row] * Rc[k] + keptJ[3 * row + 1] * Rc[3 + k] + keptJ[3 * row + 2] * Rc[6 + k];
+        } else if (CACHEJ && !KEEPJ && head) {    // cached Jacobians of the first slice
 #pragma unroll
           for (int i = 0; i < (CY ? 6 : 2 * BD); ++i) F[i] = cF[i];
 #pragma unroll
@@ -861,6 +891,16 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
           }
         }
         }
+      };
+      if constexpr (KEEPJ) {
+#pragma unroll
+        for (int ps = 0; ps < NPF; ++ps) {
+          const int o = o0 + sl + ps * LPP;
+          if (o < o1) emit(ps, o, cJ[ps]);
+        }
+        for (int o = o0 + sl + NPF * LPP; o < o1; o += LPP) emit((o - o0) / LPP, o, nullptr);
+      } else {
+        for (int o = o0 + sl; o < o1; o += LPP) emit((o - o0) / LPP, o, nullptr);
       }
     }
     if (sl == 0) {

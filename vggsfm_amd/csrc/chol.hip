@@ -888,6 +888,10 @@ __device__ __forceinline__ void df_wait_ge(const int32_t* flag, int32_t want, in
   __syncthreads();
 }
 __device__ __forceinline__ void df_wait(const int32_t* flag, int32_t* fail) { df_wait_ge(flag, 1, fail); }
+// workgroup barrier for data that went through LDS only: __syncthreads() is a workgroup-scope release, which on gfx9 waits
+// for every outstanding global STORE of the wavefront as well (s_waitcnt vmcnt(0)) -- ~0.7 us when agent-scope stores of a
+// tile are in flight, and the flag that publishes them has its own drain anyway
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // all threads: every store of this workgroup has left the CU, then raise the flag
 __device__ __forceinline__ void df_publish(int32_t* flag, int32_t value = 1) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1443,7 +1447,7 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
       if (merged) sh.T[i * LD + j] = xa[reg];            // (rows past the end of the matrix are zero)
     }
     if (merged) {
-      __syncthreads();
+      lds_barrier();                                     // (X went to sh.T; its stores to A drain behind the products)
       double a2[2][4], b2[2][4];
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4)

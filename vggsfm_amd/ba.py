@@ -18,6 +18,7 @@ import ctypes
 from dataclasses import dataclass
 from typing import Optional
 
+import os
 import torch
 
 from . import _lib
@@ -625,6 +626,9 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
     # resident schur_tile workgroups per CU (occupancy of the kernel variant): off-diagonal launch 3 (BD = 6) or 2,
     # diagonal launch 4 or 2 -- one full round each
     slots = (cus * TILE_WGS_PER_CU[0], cus * TILE_WGS_PER_CU[1]) if shared_camera else (cus * 2, cus * 2)
+    if os.environ.get("VGGSFM_TILE_WGS"):              # measurement hook: workgroups per CU as floats, "off,diag"
+        fo, fd = (float(x) for x in os.environ["VGGSFM_TILE_WGS"].split(","))
+        slots = (max(1, int(cus * fo)), max(1, int(cus * fd)))
     # three batches when the factorisation can overlap the later ones (enough camera groups, enough work per batch)
     overlap = OVERLAP_FACTORIZATION if overlap is None else bool(overlap)
     nb = TILE_BATCHES if (overlap and int(obs_cam.shape[0]) >= OVERLAP_MIN_OBS and S >= OVERLAP_MIN_FRAMES) else 1

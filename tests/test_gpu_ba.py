@@ -143,6 +143,16 @@ def test_cholesky_envelope_matches_lapack(n, band, arrow):
     xr = np.linalg.solve(Ap, b)
     np.testing.assert_allclose(bt.cpu().numpy(), xr, rtol=1e-8, atol=1e-10 * np.abs(xr).max())
     np.testing.assert_allclose(np.tril(At.cpu().numpy().reshape(n, n)), np.linalg.cholesky(Ap), rtol=1e-9, atol=1e-11)
+    # the launch order the device derived from the envelope (df_tile_map_kernel; behind the T blocks and the flags in the
+    # workspace) is the host model's, whose wait graph tests/test_chol_schedule_model.py checks
+    from tests.test_chol_schedule_model import first_of_factory, tile_map
+    words = ws.cpu().numpy().view(np.int32)
+    base = nbk * 64 * 64 * 2 + (nbk + 1) * nbk + 2 * nbk
+    chain = nbk <= 64                                                # (enqueue_dataflow: chained up to 64 block columns)
+    want = tile_map(nbk, first_of_factory(nbk, first_blk), chain)
+    assert int(words[base]) == len(want)
+    got = words[base + 1: base + 1 + len(want)]
+    assert [(int(e) & 0xffff, int(e) >> 16) for e in got] == want
 
 
 def test_ba_kway_camera_order_matches_frame_order(monkeypatch):

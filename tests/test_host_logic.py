@@ -99,7 +99,20 @@ def _check_views_and_work_list(prob, S, vi, row_ptr, obs_cam):
     for gI, gJ, tb, te, j, J in desc:
         # workgroup j of J of the tile sweeps the strided sub-chunks j, j+J, ... of SUB entries
         assert gI <= gJ and 0 <= j < J and J <= max(1, -(-(te - tb) // BA.MIN_CHUNK))
-        assert (np.diff(ent[tb:te, 0]) > 0).all()                   # inside a tile: ascending sweep positions, one entry per point
+        # inside a tile: one entry per point; ascending sweep positions from window to window (QUAD_SORT_WINDOW entries), and
+        # inside a window grouped by the pattern of 16-row blocks the tile kernel can skip, ascending inside a group
+        pos_t = ent[tb:te, 0].astype(np.int64)
+        assert len(np.unique(pos_t)) == len(pos_t)
+        bd = 6 if prob.intr.shape[0] == 1 else 6 + (2 if prob.camera_model == BA.MODEL_ID["SIMPLE_RADIAL"] else 1)
+        W = BA.QUAD_SORT_WINDOW if BA.QUAD_SORT_WINDOW > 0 else 1
+        for w0 in range(0, te - tb, W):
+            blk = pos_t[w0:w0 + W]
+            if w0:
+                assert blk.min() > pos_t[w0 - W:w0].max()
+            pats = [(_block_pattern(seg_mask[sa], bd), _block_pattern(seg_mask[sb], bd)) for sa, sb in ent[tb + w0:tb + w0 + len(blk), 1:3]]
+            assert pats == sorted(pats)
+            for a in range(1, len(blk)):
+                assert pats[a] != pats[a - 1] or blk[a] > blk[a - 1]
         own = [k for s0 in range(tb + j * BA.SUB, te, J * BA.SUB) for k in range(s0, min(s0 + BA.SUB, te))]
         for k in own:
             assert not seen_entries[k]
@@ -144,6 +157,17 @@ def _check_views_and_work_list(prob, S, vi, row_ptr, obs_cam):
             for bb in cams[i:]:
                 expect.add((p, int(a), int(bb)))
     assert set(covered) == expect and all(v == 1 for v in covered.values())
+
+def _block_pattern(mask, bd=6, group=16):
+    """bit b <=> a camera of the segment has rows in the 16-row block b of the tile side (what schur_tile_kernel skips by)"""
+    out = 0
+    for b in range(bd * group // 16):
+        s0, s1 = (16 * b) // bd, min(group - 1, (16 * b + 15) // bd)
+        if int(mask) & (((2 << s1) - 1) & ~((1 << s0) - 1)):
+            out |= 1 << b
+    return out
+
+
 
 @pytest.mark.parametrize("density_cut", [0.0, 2.0])    # in-place filtering of the grid / the observation-list construction
 @pytest.mark.parametrize("S,N", [(5, 40), (40, 300), (70, 150)])

@@ -88,6 +88,143 @@ def pmc_traffic(kernel, workload):
     return None, None
 
 
+def trajectory_divergence(gpu_its, port_its):
+    """Where two LM iteration logs part: the first iteration whose accept / reject decision differs or whose cost differs by
+    more than 1e-9 relative, with both sides' step quality and cost change there, and whether that iteration already sits
+    at the rounding-noise floor (|cost change| < 1e-12 cost: the step quality is a quotient of two rounding errors)."""
+    for a, b in zip(gpu_its, port_its):
+        if a["successful"] != b["successful"] or abs(a["cost"] - b["cost"]) > 1e-9 * abs(b["cost"]):
+            return dict(iteration=int(b["iteration"]), gpu=dict(successful=bool(a["successful"]), cost_change=a["cost_change"],
+                                                                relative_decrease=a["relative_decrease"]),
+                        port=dict(successful=bool(b["successful"]), cost_change=b["cost_change"],
+                                  relative_decrease=b["relative_decrease"]),
+                        rel_cost_change_port=abs(b["cost_change"]) / abs(b["cost"]),
+                        at_noise_floor=bool(abs(b["cost_change"]) < 1e-12 * abs(b["cost"])))
+    return None
+
+
+def last_iteration_above_noise(its, floor=1e-12):
+    """Index of the last iteration whose cost change is still >= floor x cost (beyond it accept / reject is rounding)."""
+    last = 0
+    for it in its:
+        if it["iteration"] > 0 and abs(it["cost_change"]) >= floor * abs(it["cost"]):
+            last = int(it["iteration"])
+    return last
+
+
+class StageTimer:
+    """Synchronising timers around the stages of Triangulator.forward (profiling run only: the synchronisations serialise
+    host and device, the untimed run next to it gives the wall time).  `top` stages are the calls forward itself makes --
+    together they are the whole forward, what is left is `unaccounted`; `inner` are the device entries below them."""
+
+    def __init__(self):
+        self.top, self.inner, self._undo, self._depth = {}, {}, [], 0
+
+    def _wrap(self, owner, name, table, is_top):
+        fn = getattr(owner, name)
+        timer = self
+
+        def wrapper(*a, **k):
+            if is_top:
+                timer._depth += 1
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            try:
+                return fn(*a, **k)
+            finally:
+                torch.cuda.synchronize()
+                if not is_top or timer._depth == 1:
+                    table[name] = table.get(name, 0.0) + time.perf_counter() - t0
+                if is_top:
+                    timer._depth -= 1
+        setattr(owner, name, wrapper)
+        self._undo.append((owner, name, fn))
+
+    def install(self):
+        from vggsfm_amd.models import triangulator as TM
+        from vggsfm_amd.utils import triangulation as TU
+        for name in ("get_EFP", "cam_from_img", "triangulate_by_pair", "find_best_initial_pair", "init_BA", "init_refine_pose",
+                     "refine_pose", "iterative_global_BA", "build_reconstruction"):
+            self._wrap(TM, name, self.top, True)
+        self._wrap(TM.Triangulator, "triangulate_tracks_and_BA", self.top, True)
+        self._wrap(BA, "compile_problem", self.inner, False)
+        self._wrap(BA, "solve", self.inner, False)
+        for name in ("triangulate_tracks", "filter_all_points3D", "pose_refinement_batch", "cam_from_img", "project_3D_points"):
+            for mod in (TU, TM):
+                if hasattr(mod, name) and not (mod is TM and name in self.top):
+                    self._wrap(mod, name, self.inner, False)
+        return self
+
+    def remove(self):
+        for owner, name, fn in reversed(self._undo):
+            setattr(owner, name, fn)
+        self._undo = []
+
+
+def pipeline_leg(dev, configs=("c2", "c3")):
+    """End-to-end geometry stage: vggsfm_amd.models.Triangulator.forward -- what demo.py calls after
+    the tracker (reference vggsfm/models/triangulator.py:44-363) -- on the synthetic scenes of BASELINE configs[1] / [2]:
+    wall time of an untimed run, then the same call under stage timers."""
+    import types
+    from vggsfm_amd.models import Triangulator
+    out = {}
+    W = 1024
+    for name in configs:
+        S, N, cam, shared = WORKLOADS[name]
+        sc = make_scene(S, N, cam, shared_camera=shared, seed=0)
+        ext0, K0, _, _ = perturb_for_ba(sc, seed=0, rot_deg=0.5, trans=0.02, focal_rel=0.02)
+        cams = types.SimpleNamespace(R=D(ext0[:, :, :3], dev).float(), T=D(ext0[:, :, 3], dev).float(),
+                                     focal_length=torch.stack([D(K0[:, 0, 0] / (W / 2.0), dev).float()] * 2, -1))
+        img = types.SimpleNamespace(shape=(1, S, 3, W, W))             # (only .shape is read when extract_color=False)
+        tracks, vis, score = D(sc.tracks, dev)[None], D(sc.vis, dev)[None], D(sc.score, dev)[None]
+        prelim = {"fmat_inlier_mask": D(sc.mask[1:] & sc.mask[0:1], dev)[None]}
+        tri = Triangulator()
+        kw = dict(pred_score=score, shared_camera=shared, camera_type=cam, BA_iters=2, robust_refine=2, extract_color=False)
+        import contextlib
+        import io
+        quiet = lambda: contextlib.redirect_stdout(io.StringIO())      # (forward prints the reference's milestones)
+        with quiet():
+            tri(cams, tracks[:, :, :2000], vis[:, :, :2000], img, {"fmat_inlier_mask": prelim["fmat_inlier_mask"][:, :, :2000]},
+                pred_score=score[:, :, :2000], shared_camera=shared, camera_type=cam, BA_iters=1, robust_refine=1,
+                extract_color=False)                                    # warm-up: library load, allocator, first launches
+            walls = []
+            for _ in range(2):
+                torch.manual_seed(0)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                res = tri(cams, tracks, vis, img, prelim, **kw)
+                torch.cuda.synchronize()
+                walls.append(time.perf_counter() - t0)
+            timer = StageTimer().install()
+            try:
+                torch.manual_seed(0)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                tri(cams, tracks, vis, img, prelim, **kw)
+                torch.cuda.synchronize()
+                wall_timed = time.perf_counter() - t0
+            finally:
+                timer.remove()
+        ext, K, extra, pts, _, rec, vframes, v2d, vtracks = res
+        vt = vtracks.cpu().numpy()
+        e_gt, p_gt = BA.normalize_reconstruction(D(sc.extrinsics, dev), D(sc.points3D[vt], dev))
+        Rrel = torch.einsum("sij,skj->sik", ext[:, :, :3], e_gt[:, :, :3])
+        ang = torch.acos(((Rrel.diagonal(dim1=1, dim2=2).sum(-1) - 1) / 2).clamp(-1, 1))
+        top_sum = sum(timer.top.values())
+        out[name] = dict(workload=f"Triangulator.forward, synthetic {S} frames x {N} tracks {cam}{' shared' if shared else ''}, "
+                                  "BA_iters 2, robust_refine 2 (reference defaults)",
+                         wall_s=min(walls), wall_s_runs=walls, wall_s_under_stage_timers=wall_timed,
+                         stages_s={k: round(v, 4) for k, v in sorted(timer.top.items(), key=lambda kv: -kv[1])},
+                         device_entries_s={k: round(v, 4) for k, v in sorted(timer.inner.items(), key=lambda kv: -kv[1])},
+                         unaccounted_s=round(wall_timed - top_sum, 4), unaccounted_frac=(wall_timed - top_sum) / wall_timed,
+                         valid_tracks=int(vt.sum()), valid_frames=int(vframes.sum()),
+                         max_rot_err_deg_vs_ground_truth=float(ang.max()) * 180 / np.pi,
+                         median_point_err_vs_ground_truth=float((pts - p_gt).norm(dim=-1).median()))
+        del tracks, vis, score, res, pts
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,6 +237,8 @@ def main():
     ap.add_argument("--weak-steps", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-triangulation", action="store_true", help="skip the triangulation leg (tracks/s of the same scene)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="skip the end-to-end leg (Triangulator.forward at configs[1] and configs[2], wall time + stage breakdown)")
     ap.add_argument("--no-strong-leg", action="store_true",
                     help="skip the short strong-scaling leg on BASELINE configs[3] (400 x 300k split over the ranks)")
     ap.add_argument("--strong-steps", type=int, default=10)
@@ -457,12 +596,24 @@ def main():
             ge, gp, gK = ge.cpu().numpy(), gp.cpu().numpy(), gK.cpu().numpy()
             rel = lambda a, b: float(np.max(np.linalg.norm((a - b).reshape(len(a), -1), axis=1)
                                             / np.maximum(np.linalg.norm(b.reshape(len(b), -1), axis=1), 1e-12)))
+            from vggsfm_amd.ba_options import TERMINATION
             parity = dict(workload=f"synthetic {ps} frames x {pn} tracks SIMPLE_PINHOLE, full solve with the reference's BA options",
                           lm_iterations_gpu=int(gs["num_iterations"]), lm_iterations_port=int(osum["num_iterations"]),
+                          termination_gpu=gs["termination_str"], termination_port=TERMINATION.get(osum["termination"], "?"),
+                          # exits: up to which iteration the two logs are the same trajectory, and
+                          # whether the iteration on which they part is already rounding noise
+                          last_iteration_above_noise_floor_port=last_iteration_above_noise(osum["iterations"]),
+                          first_divergence=trajectory_divergence(gs["iterations"], osum["iterations"]),
                           final_cost_rel_delta=abs(gs["final_cost"] - osum["final_cost"]) / osum["final_cost"],
                           max_rel_rotation_delta=rel(ge[:, :, :3], oe[:, :, :3]), max_rel_translation_delta=rel(ge[1:, :, 3], oe[1:, :, 3]),
                           max_rel_point_delta=rel(gp, op), max_rel_focal_delta=float(np.max(np.abs(gK[:, 0, 0] / oK[:, 0, 0] - 1))),
                           tolerance=1e-4, reference="oracle/ba_oracle.c (Ceres/COLMAP restatement; unpinned vs pycolmap)")
+        pipeline = None
+        chol_split = list(prob.chol_split)
+        if world == 1 and not args.no_pipeline and args.workload == "c3":
+            del prob
+            torch.cuda.empty_cache()
+            pipeline = pipeline_leg(dev)
         out = {
             "metric": "BA LM-iterations/sec",
             "value": args.steps / dt if strong_main else args.steps * world / dt,
@@ -487,7 +638,7 @@ def main():
                        "parallelism": f"points sharded x{world}, cameras replicated, RCCL all-reduce of the camera blocks, "
                                       "reduce-scatter + all-gather of the packed reduced system",
                        "episode_iterations": EPISODE,
-                       "camera_split_columns": list(prob.chol_split),   # block-diagonal leading part factorised side by side
+                       "camera_split_columns": chol_split,   # block-diagonal leading part factorised side by side
                        "successful_steps_last_episode": int(fin["num_successful_steps"]),
                        "kernel_ms": kernel_ms},
             "roofline": roof,
@@ -501,6 +652,7 @@ def main():
             "speedup_vs_n1": (args.steps / dt) / n1["lm_iterations_per_s"] if (n1 and strong_main) else None,
             "weak_scaling_c3": weak,
             "triangulation": tri,
+            "pipeline": pipeline,
         }
         print(json.dumps(out))
     if dist:

@@ -221,6 +221,12 @@ int vgg_ba_solve(const vgg_ba_problem* problem, const vgg_ba_options* options, v
  *   phase 4 / 5      : pack / unpack the lower triangle of the reduced system + rhs into / from reduce buffer 4
  *                      (n(n+1)/2 + n doubles): all-reducing buffer 4 between them replaces the all-reduce of
  *                      buffer 1 (n^2 + n doubles, upper triangle all zero) at half the payload
+ *   phase 6          : unpack from the OUTPUT of a reduce-scatter + all-gather of buffer 4, read in place: with W ranks
+ *                      and c = ceil(count / W), phase 4 also zeroes buffer 4 up to W c doubles (it is carved with that
+ *                      padding: the reduce-scatter input, no staging copy) and puts the rank's gradient maximum at
+ *                      element c of buffer 5 (c + 1 doubles: reduce-scatter output = all-gather input); buffer 6
+ *                      (W (c + 1) doubles) is the all-gather output; phase 6 rebuilds S | rhs from its W slices and
+ *                      takes the maximum of the W riding gradient norms (replaces the MAX reduce of buffer 2).  W <= 1024
  * vgg_ba_reduce_buffer returns the device address / element count (doubles) of each reduce buffer. */
 int vgg_ba_begin(const vgg_ba_problem* problem, const vgg_ba_options* options, void* workspace, size_t workspace_bytes,
                  int rank, int world_size, void* stream);

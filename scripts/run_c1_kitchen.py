@@ -49,7 +49,9 @@ def prepare():
     print("wrote", FIXTURE, names, np.array(crops)[0])
 
 
-def run(out):
+def run(out, model_dir=None):
+    """-> the result dict (also printed / written to `out`); the COLMAP model goes to `model_dir`
+    (tests/test_gpu_runner.py::test_c1_kitchen_plumbing calls this with a temporary directory)."""
     import torch
 
     from vggsfm_amd.pycolmap_compat import Reconstruction
@@ -80,7 +82,7 @@ def run(out):
     torch.cuda.synchronize()
     seconds = time.perf_counter() - t0
     rec = pred["reconstruction"]
-    model_dir = os.path.join(os.path.dirname(out) if out else "/tmp", "c1_kitchen_sparse")
+    model_dir = model_dir or os.path.join(os.path.dirname(out) if out else "/tmp", "c1_kitchen_sparse")
     rec.write(model_dir)
     back = Reconstruction(model_dir)
     cam0 = back.cameras[0]
@@ -96,6 +98,8 @@ def run(out):
     if out:
         with open(out, "w") as fh:
             json.dump(res, fh, indent=1)
+    res["_reconstruction"], res["_read_back"], res["_predictions"] = rec, back, pred
+    return res
 
 
 if __name__ == "__main__":

@@ -286,6 +286,30 @@ def _gpu_opts(kind):
     return prepare_ba_options() if kind == "prep" else BundleAdjustmentOptions()
 
 
+def _compare_trajectories(sg, so, min_compared):
+    """Iteration logs of the GPU solve (sg) and of the oracle (so) side by side: same accept / reject pattern, costs to
+    1e-9, radii and gradient norms to 1e-5 for as long as the decisions are not made of rounding noise -- once
+    |cost change| < 1e-9 * cost the step quality (cost change / model change) is noise in BOTH implementations and the
+    accept / reject pattern is not comparable.  EXITS: when the oracle's whole log stays above that
+    floor, the two solves must also END alike -- same termination type, same number of iterations."""
+    compared, hit_floor = 0, False
+    for a, b in zip(sg["iterations"], so["iterations"]):
+        if b["iteration"] > 0 and abs(b["cost_change"]) < 1e-9 * b["cost"]:
+            hit_floor = True
+            break
+        assert a["iteration"] == b["iteration"] and a["successful"] == b["successful"], (a, b)
+        assert abs(a["cost"] - b["cost"]) <= 1e-9 * b["cost"], (a, b)
+        assert abs(a["radius"] - b["radius"]) <= 1e-5 * b["radius"], (a, b)
+        assert abs(a["gradient_max_norm"] - b["gradient_max_norm"]) <= 1e-5 * b["gradient_max_norm"] + 1e-9, (a, b)
+        compared += 1
+    assert compared >= min(min_compared, so["num_iterations"])
+    if not hit_floor:
+        assert sg["termination"] == so["termination"], (sg["termination_str"], so["termination"])
+        assert sg["num_iterations"] == so["num_iterations"]
+        assert len(sg["iterations"]) == len(so["iterations"])
+    return compared, hit_floor
+
+
 @pytest.mark.parametrize("S,N,cam,shared,kind", CASES)
 def test_ba_matches_oracle_trajectory(S, N, cam, shared, kind):
     sc = make_scene(S, N, cam, shared_camera=shared, seed=S + N, full_visibility=(S <= 3))
@@ -296,19 +320,7 @@ def test_ba_matches_oracle_trajectory(S, N, cam, shared, kind):
     assert np.array_equal(sg["valid_idx"].cpu().numpy(), so["valid_idx"])
     assert sg["n_reduced"] == so["n_reduced"]
     assert abs(sg["initial_cost"] - so["initial_cost"]) <= 1e-11 * so["initial_cost"]
-    # Same LM trajectory (accept/reject pattern, radii, costs) for as long as the decisions are not
-    # made of rounding noise: once |cost change| < 1e-9 * cost the step quality (cost change / model
-    # change) is noise in BOTH implementations and the accept/reject pattern is not comparable.
-    compared = 0
-    for a, b in zip(sg["iterations"], so["iterations"]):
-        if b["iteration"] > 0 and abs(b["cost_change"]) < 1e-9 * b["cost"]:
-            break
-        assert a["iteration"] == b["iteration"] and a["successful"] == b["successful"], (a, b)
-        assert abs(a["cost"] - b["cost"]) <= 1e-9 * b["cost"], (a, b)
-        assert abs(a["radius"] - b["radius"]) <= 1e-5 * b["radius"], (a, b)
-        assert abs(a["gradient_max_norm"] - b["gradient_max_norm"]) <= 1e-5 * b["gradient_max_norm"] + 1e-9, (a, b)
-        compared += 1
-    assert compared >= min(6, so["num_iterations"])
+    _compare_trajectories(sg, so, 6)
     assert abs(sg["final_cost"] - so["final_cost"]) <= 1e-8 * so["final_cost"]
     np.testing.assert_allclose(ext.cpu().numpy(), eo, rtol=0, atol=5e-6)
     # (final values: both sides stop at the gradient tolerance, not at the exact optimum, and the last accept /
@@ -320,6 +332,76 @@ def test_ba_matches_oracle_trajectory(S, N, cam, shared, kind):
     # gauge: image 0 untouched, x-translation of image 1 untouched
     np.testing.assert_allclose(ext.cpu().numpy()[0], ext0[0], atol=1e-15)
     assert float(ext[1, 0, 3]) == ext0[1, 0, 3]
+
+
+EXIT_CASES = [
+    # solves that END on the gradient test well above the rounding-noise floor (a loose tolerance on a noisy scene): the
+    # termination type and the iteration on which it fires are part of the parity claim
+    # (gradient max-norms are in pixel^2 units: 1e3 .. 1e4 a few iterations in; with the reference's own 1e-3 / 1e-4 the
+    #  test is only met where the cost changes by < 1e-14 of itself -- see DESIGN.md section 5, "exits")
+    (12, 900, "SIMPLE_RADIAL", True, 100.0),         # oracle: iteration 15
+    (30, 2500, "SIMPLE_PINHOLE", False, 2000.0),     # 5
+    (70, 1200, "SIMPLE_RADIAL", True, 300.0),        # 7
+    (50, 20000, "SIMPLE_PINHOLE", False, 5000.0),    # 5
+    (200, 10000, "SIMPLE_RADIAL", True, 1000.0),     # 7
+]
+
+
+@pytest.mark.parametrize("S,N,cam,shared,gtol", EXIT_CASES)
+def test_ba_exit_matches_oracle(S, N, cam, shared, gtol):
+    """the gradient tolerance is reached while every decision is still far above rounding noise; GPU
+    and oracle must stop on the SAME iteration with the SAME termination type (Ceres checks the gradient norm at the
+    start of an iteration and only behind a successful step)."""
+    sc = make_scene(S, N, cam, shared_camera=shared, seed=3 * S + N)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=3 * S + N)
+    oo = OB.ceres_options(50, 0.0, gtol, 0.0)
+    go = BundleAdjustmentOptions()
+    go.solver_options.max_num_iterations, go.solver_options.gradient_tolerance = 50, gtol
+    po, eo, Ko, xo, so = OB.bundle_adjustment(pts0, ext0, K0, sc.tracks, sc.mask, extra0, shared, cam, oo)
+    pts, ext, K, extra, sg = BA.bundle_adjustment(D(pts0), D(ext0), D(K0), D(sc.tracks), D(sc.mask), None, D(extra0),
+                                                  shared, cam, go)
+    compared, hit_floor = _compare_trajectories(sg, so, 2)
+    assert not hit_floor, "pick a looser tolerance: the case is meant to end above the noise floor"
+    assert so["termination"] == 1 and 2 <= so["num_iterations"] < 50      # CONVERGENCE (gradient tolerance), not the cap
+    assert sg["termination"] == 1 and sg["num_iterations"] == so["num_iterations"]
+    np.testing.assert_allclose(ext.cpu().numpy(), eo, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(pts.cpu().numpy(), po, rtol=0, atol=1e-7)
+
+
+def _video_scene(S, N, span, seed):
+    """Video-like visibility: every track ends `span` frames after it starts (vggsfm/runners/video_runner.py: a track lives
+    in one window of <= 33 frames), shared SIMPLE_RADIAL camera."""
+    sc = make_scene(S, N, "SIMPLE_RADIAL", shared_camera=True, seed=seed)
+    first = np.argmax(sc.mask, axis=0)
+    cut = np.arange(S)[:, None] >= (first + span)[None]
+    sc.mask[cut] = False
+    sc.vis[cut] = 0.0
+    return sc
+
+
+def test_ba_video_shape_matches_oracle_trajectory():
+    """VERDICT r3 item 1a / missing 4: the joint BA of the video path (vggsfm/runners/video_runner.py:494-541) at its own
+    shape -- 640 frames x 14 k tracks of at most 30 frames, shared SIMPLE_RADIAL, n = 3842 -- where compile_problem orders
+    the cameras k-way [interior runs, separators] and the factorisation runs on the row envelope: 10 LM iterations against
+    ba_oracle.c (frame order, dense Cholesky), not only against the same GPU solve in frame order."""
+    sc = _video_scene(640, 14000, 30, 29)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=29)
+    perm, fg = BA.find_camera_order(D(sc.mask))
+    assert perm is not None and int((fg == torch.arange(len(fg))).sum()) >= 3          # >= 3 independent leading blocks
+    oo = OB.prepare_ba_options()
+    oo.max_num_iterations = 10
+    go = prepare_ba_options()
+    go.solver_options.max_num_iterations = 10
+    po, eo, Ko, xo, so = OB.bundle_adjustment(pts0, ext0, K0, sc.tracks, sc.mask, extra0, True, "SIMPLE_RADIAL", oo)
+    pts, ext, K, extra, sg = BA.bundle_adjustment(D(pts0), D(ext0), D(K0), D(sc.tracks), D(sc.mask), None, D(extra0),
+                                                  True, "SIMPLE_RADIAL", go)
+    assert np.array_equal(sg["valid_idx"].cpu().numpy(), so["valid_idx"]) and sg["n_reduced"] == so["n_reduced"] == 3842
+    compared, _ = _compare_trajectories(sg, so, 8)
+    assert abs(sg["final_cost"] - so["final_cost"]) <= 1e-8 * so["final_cost"]
+    np.testing.assert_allclose(ext.cpu().numpy(), eo, rtol=0, atol=5e-6)        # (in the order of the INPUT frames)
+    np.testing.assert_allclose(pts.cpu().numpy(), po, rtol=0, atol=5e-5)
+    np.testing.assert_allclose(float(K[0, 0, 0]), Ko[0, 0, 0], rtol=1e-6)
+    np.testing.assert_allclose(extra.cpu().numpy(), xo, rtol=0, atol=1e-7)
 
 
 def test_ba_deleted_points_and_constant_blocks():
@@ -357,11 +439,14 @@ def test_ba_converges_to_ground_truth_without_noise():
     np.testing.assert_allclose(float(K[0, 0, 0]), 1000.0, rtol=1e-6)
 
 
-@pytest.mark.parametrize("cam,shared", [("SIMPLE_RADIAL", True), ("SIMPLE_PINHOLE", True)])
-def test_window_bundle_adjustment_matches_oracle(cam, shared):
+@pytest.mark.parametrize("cam,shared,S,N,n_exist", [("SIMPLE_RADIAL", True, 17, 900, 500), ("SIMPLE_PINHOLE", True, 17, 900, 500),
+                                                     # the INITIAL window of the video runner: 2 x window_size + 1 frames
+                                                     # (vggsfm/runners/video_runner.py:200-230), 2 x 1024 new tracks
+                                                     ("SIMPLE_RADIAL", True, 33, 4000, 1900)])
+def test_window_bundle_adjustment_matches_oracle(cam, shared, S, N, n_exist):
     """Local BA of a video window (vggsfm/runners/video_runner.py:800-838): frame 0 constant, carried-over points
     constant, new points variable, intrinsics not refined, no negative-depth filter."""
-    S, N, n_exist = 17, 900, 500                    # window_size + 1 frames; existing + newly triangulated tracks
+    # window_size + 1 (or 2 x window_size + 1) frames; existing + newly triangulated tracks
     sc = make_scene(S, N, cam, shared_camera=shared, seed=12, full_visibility=False, outlier_frac=0.0)
     ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=12)
     ext0[0] = sc.extrinsics[0]

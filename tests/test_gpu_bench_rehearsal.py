@@ -1,0 +1,55 @@
+"""the driver's multi-GPU command line, rehearsed end to end before its first real run.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus 2 --steps K --warmup W
+
+Only one GPU is visible on the test box, so the two ranks SHARE it and the collectives go over gloo, staged through the host
+(``VGGSFM_BENCH_BACKEND=gloo`` -- bench.py's rehearsal switch; the measured path is RCCL).  Everything else is the code the
+8-GPU run executes: RANK / LOCAL_RANK / WORLD_SIZE handling, rank 0's solo run of the whole configs[3] problem, the
+agreed camera order, the sharded solve with its three exchanges per iteration (camera blocks; reduce-scatter + all-gather of
+the packed reduced system on the solver's own buffers, phases 4 / 6; step scalars), barrier + max-over-ranks timing, the
+weak-scaling leg, the ONE JSON line on rank 0."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_bench_two_ranks_command_line_over_gloo():
+    env = dict(os.environ, VGGSFM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--strong-steps", "3", "--weak-steps", "2"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                         # ONE JSON line, printed by rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["unit"] == "LM-iterations/s"
+    assert out["scaling"] == "strong" and out["higher_is_better"] is True and out["dtype"] == "f64"
+    assert out["value"] > 0 and abs(out["value"] - 1e3 / out["ms_per_step"]) <= 1e-6 * out["value"]
+    cfg = out["config"]
+    assert cfg["frames"] == 400 and cfg["tracks_per_gpu"] == 150000 and cfg["reduced_system"] == 3200
+    assert "configs[3]" in cfg["workload"]
+    n1 = out["n1_same_problem"]
+    assert n1["observations"] > 2 * cfg["observations_per_gpu"] * 0.9 and n1["lm_iterations_per_s"] > 0
+    assert out["speedup_vs_n1"] == pytest.approx(out["value"] / n1["lm_iterations_per_s"])
+    weak = out["weak_scaling_c3"]
+    assert weak["scaling"] == "weak" and weak["shard_iterations_per_s"] == pytest.approx(2 * weak["lm_iterations_per_s_global"])
+    assert out["roofline"]["bound"] in ("mfma", "hbm") and 0 < out["roofline"]["frac"] < 1
+    assert out["cpu_baseline"] is None                                # rank 0 at N = 1 only

@@ -31,8 +31,13 @@ class _LockStep:
             t.copy_(red)
 
 
+@pytest.mark.parametrize("in_place", [False, True])
 @pytest.mark.parametrize("cam,shared,world", [("SIMPLE_RADIAL", True, 2), ("SIMPLE_PINHOLE", False, 3)])
-def test_sharded_equals_single_rank(cam, shared, world):
+def test_sharded_equals_single_rank(cam, shared, world, in_place):
+    """in_place: the exchange of the reduced system as dist.Collectives.system_scatter does it -- a reduce-scatter of the
+    padded packed buffer (phase 4 pads it) into every rank's slice buffer and an all-gather of the slices, each with the
+    rank's gradient maximum behind it, into the buffer phase 6 unpacks from (no staging copies, no MAX collective);
+    emulated here slice by slice on the solvers' own reduce buffers 4 / 5 / 6."""
     sc = make_scene(24, 1500, cam, shared_camera=shared, seed=17)
     ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=17)
     opts = prepare_ba_options()
@@ -60,10 +65,21 @@ def test_sharded_equals_single_rank(cam, shared, world):
             s._phase(4)                                     # pack lower triangle + rhs (the real collective's payload)
         n = ref["n_reduced"]
         assert solvers[0].bufs[4].numel() == n * (n + 1) // 2 + n
-        hub.exchange([s.bufs[4] for s in solvers], "sum")
-        for s in solvers:
-            s._phase(5)
-        hub.exchange([s.bufs[2] for s in solvers], "max")
+        if in_place:
+            chunk = -(-solvers[0].bufs[4].numel() // world)
+            assert all(s._padded.numel() == world * chunk and s._mine.numel() == chunk + 1 for s in solvers)
+            total = torch.stack([s._padded for s in solvers]).sum(0)            # reduce-scatter: rank r keeps slice r of the sum
+            for r, s in enumerate(solvers):
+                s._mine[:chunk].copy_(total[r * chunk:(r + 1) * chunk])
+            allm = torch.cat([s._mine for s in solvers])                         # all-gather of the (chunk + 1)-element slices
+            for s in solvers:
+                s._gathered.copy_(allm)
+                s._phase(6)
+        else:
+            hub.exchange([s.bufs[4] for s in solvers], "sum")
+            for s in solvers:
+                s._phase(5)
+            hub.exchange([s.bufs[2] for s in solvers], "max")
         for s in solvers:
             s._phase(2)
         hub.exchange([s.bufs[3] for s in solvers], "sum")

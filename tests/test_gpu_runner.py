@@ -103,3 +103,42 @@ def test_sparse_reconstruct_from_tracks_with_extra_points(tmp_path):
     assert back.num_points3D() == rec.num_points3D() == n_sfm + n_add and back.num_reg_images() == S
     assert all(back.points3D[p].track.length() == 0 for p in (n_sfm + 1, n_sfm + n_add))
     assert np.array_equal(back.images[2].points2D._xy, rec.images[2].points2D._xy)
+
+
+@pytest.mark.gpu
+def test_c1_kitchen_plumbing(tmp_path):
+    """BASELINE configs[0] ("examples/kitchen, 8 frames, 2048 query points, plumbing only") from the committed fixture
+    tests/golden/c1_kitchen_inputs.npz (file names, crop parameters and thumbnails of 8 of the reference's 25 kitchen images,
+    made by scripts/run_c1_kitchen.py --stage prepare where /root/reference exists): synthetic tracks / cameras are injected at
+    the Triangulator boundary, the post-tracker path runs on the GPU, the COLMAP model is written at the ORIGINAL 1558 x 1039
+    resolution and read back with the committed .bin reader."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "run_c1_kitchen.py")
+    spec = importlib.util.spec_from_file_location("run_c1_kitchen", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = np.load(mod.FIXTURE)
+    names = [str(n) for n in g["names"]]
+    assert len(names) == 8 and g["thumbs"].shape == (8, 64, 64, 3) and g["crop_params"].shape == (8, 8)
+    assert tuple(g["crop_params"][0, :2]) == (1558.0, 1039.0)
+    res = mod.run(None, model_dir=str(tmp_path))
+    rec, back, pred = res["_reconstruction"], res["_read_back"], res["_predictions"]
+    assert res["registered_images"] == 8 and res["image_names"] == names
+    assert res["camera0"]["model"] in ("SIMPLE_PINHOLE", 0) and (res["camera0"]["width"], res["camera0"]["height"]) == (1558, 1039)
+    # most of the 3 x 2048 injected tracks (97 % inliers, visible in the content rows of the padded images) become points
+    assert res["valid_tracks"] > 0.6 * 3 * 2048 and res["points3D"] == res["valid_tracks"] == back.num_points3D() == rec.num_points3D()
+    assert res["mean_track_length"] >= 2.0
+    # principal point = centre of the original image, every registered image keeps its 2D points through the round trip
+    assert abs(res["camera0"]["params"][1] - 1558 // 2) <= 1 and abs(res["camera0"]["params"][2] - 1039 // 2) <= 1
+    for i in sorted(back.images):
+        assert np.array_equal(back.images[i].points2D._xy, rec.images[i].points2D._xy)
+        assert back.images[i].camera_id == rec.images[i].camera_id
+    assert all(os.path.getsize(os.path.join(str(tmp_path), f)) > 0 for f in ("cameras.bin", "images.bin", "points3D.bin"))
+    # the poses are the injected ground truth up to the gauge: relative rotation of frame 0 -> frame 7 within 1e-2 rad
+    E = pred["extrinsics_opencv"].double().cpu().numpy()
+    from vggsfm_amd.scene import make_scene
+    sc = make_scene(8, 3 * 2048, "SIMPLE_PINHOLE", shared_camera=False, seed=7, outlier_frac=0.03)
+    rel = lambda X: X[7, :, :3] @ X[0, :, :3].T
+    dR = rel(E) @ rel(sc.extrinsics).T
+    assert np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1)) < 1e-2

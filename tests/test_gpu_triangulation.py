@@ -91,3 +91,35 @@ def test_triangulation_recovers_ground_truth_at_scale():
     assert float(err.median()) < 2e-2 and float(err.quantile(0.9)) < 0.25 and float(err.quantile(0.99)) < 1.5
     # (the synthetic outliers are +-50 px, i.e. mostly INSIDE the reference's 2 degree = 35 px inlier cone at
     #  f = 1000 px, so no statement about them is made here)
+
+
+@pytest.mark.parametrize("bad", [float("inf"), float("nan")])
+def test_nonfinite_ray_in_invisible_view(bad):
+    """ADVICE r3.  Finite normalised tracks are a precondition the reference enforces by failing (its eigh raises:
+    tests/test_oracle_live_vs_reference.py::test_reference_rejects_nonfinite_rays); the host entry raises the same exception
+    type.  The KERNEL (called below the check, through the chunk entry) has defined behaviour on such input: the kernel only
+    evaluates the visible views, and a non-finite ray in any other view poisons every RANSAC hypothesis of that track --
+    what the reference's NaN mean over all views would do -- while every other track is untouched, bit for bit."""
+    S, N = 12, 90
+    sc = make_scene(S, N, "SIMPLE_PINHOLE", seed=117, outlier_frac=0.05)
+    ext, K, _, _ = perturb_for_ba(sc, seed=117, rot_deg=0.1, trans=0.005, focal_rel=0.002)
+    vis = sc.vis.copy()
+    tn = G.cam_from_img(sc.tracks.astype(np.float64), K)
+    hit = np.arange(0, N, 5)
+    for n in hit:
+        if (vis[:, n] > 0.05).all():
+            vis[S - 1, n] = 0.0
+    clean = T.triangulate_tracks(D(ext), D(tn), max_ransac_iters=256, track_vis=D(vis), track_score=D(sc.score))
+    tb = tn.copy()
+    for n in hit:
+        tb[np.nonzero(vis[:, n] <= 0.05)[0][0], n, n % 2] = bad
+    with pytest.raises(torch.linalg.LinAlgError):
+        T.triangulate_tracks(D(ext), D(tb), max_ransac_iters=256, track_vis=D(vis), track_score=D(sc.score))
+    dirty = T.triangulate_tracks(D(ext), D(tb), max_ransac_iters=256, track_vis=D(vis), track_score=D(sc.score), check_finite=False)
+    keep = np.ones(N, bool)
+    keep[hit] = False
+    for a, b in zip(clean, dirty):
+        assert torch.equal(a[torch.from_numpy(keep).cuda()], b[torch.from_numpy(keep).cuda()])
+    num, msk = dirty[1].cpu().numpy(), dirty[2].cpu().numpy()
+    assert not (msk[hit] & (vis[:, hit].T <= 0.05)).any()           # never an inlier in an invisible view
+    assert (num[hit] == msk[hit].sum(1)).all() and (num[hit] <= clean[1].cpu().numpy()[hit] + 1).all()

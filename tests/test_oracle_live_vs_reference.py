@@ -91,3 +91,22 @@ def test_triangulate_tracks_live(seed, S, N, cam, iters):
     assert np.array_equal(msk, mskr.numpy())
     ok = numr.numpy() >= 2
     np.testing.assert_allclose(p[ok], pr.numpy()[ok], rtol=1e-7, atol=1e-8)
+
+
+@pytest.mark.parametrize("bad", [float("inf"), float("nan")])
+def test_reference_rejects_nonfinite_rays(bad):
+    """ADVICE r3 (a NaN / inf normalised coordinate in a view the track is NOT visible in): the reference does not get as far
+    as its all-view mean -- the view pairs of its RANSAC stage include the invisible views, the DLT matrix of such a pair is
+    non-finite and ``torch.linalg.eigh`` raises (triangulation_helpers.py:87).  Finite normalised tracks are therefore a
+    PRECONDITION of ``triangulate_tracks``; the drop-in raises the same exception type up front
+    (vggsfm_amd/utils/triangulation.py), and the kernel's behaviour on such input is defined anyway (every RANSAC hypothesis of
+    the track poisoned: tests/test_gpu_triangulation.py::test_nonfinite_ray_in_invisible_view)."""
+    tri, helpers, _ = ref_harness.load()
+    seed, S, N = 117, 12, 90
+    sc, ext, K, extra, _ = _scene(seed, S, N, "SIMPLE_PINHOLE", False)
+    vis = sc.vis.copy()
+    tn = helpers.cam_from_img(T(sc.tracks), T(K), T(extra)).numpy().copy()
+    vis[S - 1, 3] = 0.0
+    tn[S - 1, 3, 0] = bad
+    with pytest.raises(torch.linalg.LinAlgError):
+        tri.triangulate_tracks(T(ext), tc(T(tn)), max_ransac_iters=256, track_vis=tc(T(vis)), track_score=tc(T(sc.score)))

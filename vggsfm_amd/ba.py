@@ -518,14 +518,18 @@ def envelope_blocks(first_group, num_cams, n_reduced, group=GROUP, block=64):
 
 def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_params=None, shared_camera=False,
                     camera_type="SIMPLE_PINHOLE", max_points3D_val=3000, filter_negative_depth=True,
-                    gauge="colmap", overlap=None, camera_split=False, adjacency_reduce=None):
+                    gauge="colmap", overlap=None, camera_split=False, adjacency_reduce=None, refine_focal_length=True,
+                    refine_extra_params=True):
     """tensors (reference layout, on the GPU) -> DeviceProblem + bookkeeping.
     Returns (problem, valid_idx (P',) long, deleted (P',) bool).
     overlap: cut the Schur tiles into TILE_BATCHES batches so that a single-GPU solve can factorise beside the later
     ones (default OVERLAP_FACTORIZATION; pass False for a multi-GPU shard, whose system is all-reduced first).
     camera_split: look for a block-diagonal leading part (find_camera_split) and order the cameras accordingly --
     problem.cam_perm then maps the problem's cameras to the input frames (cam_q / cam_t / per-camera intr / cam_const
-    are in THAT order).  With several ranks pass `adjacency_reduce` so that every rank orders alike."""
+    are in THAT order).  With several ranks pass `adjacency_reduce` so that every rank orders alike.
+    refine_focal_length / refine_extra_params: what the solve will refine (``BundleAdjustmentOptions``) -- they decide the
+    rows per camera of the Schur tile blocks (6, or 6 + refined intrinsics when those are per camera), hence the tile
+    kernel variant, its occupancy and the balance of the work list (the video window BA refines neither)."""
     if camera_type not in MODEL_ID:
         raise ValueError(f"Camera type {camera_type} is not supported yet")
     dev = tracks.device
@@ -641,7 +645,9 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
     cus = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == "cuda" else 256
     # resident schur_tile workgroups per CU (occupancy of the kernel variant): off-diagonal launch 3 (BD = 6) or 2,
     # diagonal launch 4 or 2 -- one full round each
-    slots = (cus * TILE_WGS_PER_CU[0], cus * TILE_WGS_PER_CU[1]) if shared_camera else (cus * 2, cus * 2)
+    kd = int(bool(refine_focal_length)) + int(bool(refine_extra_params) and camera_type == "SIMPLE_RADIAL")
+    block_rows = 6 if (shared_camera or kd == 0) else 6 + kd          # BD of schur_tile_kernel (make_dims in csrc/ba.hip)
+    slots = (cus * TILE_WGS_PER_CU[0], cus * TILE_WGS_PER_CU[1]) if block_rows == 6 else (cus * 2, cus * 2)
     if os.environ.get("VGGSFM_TILE_WGS"):              # measurement hook: workgroups per CU as floats, "off,diag"
         fo, fd = (float(x) for x in os.environ["VGGSFM_TILE_WGS"].split(","))
         slots = (max(1, int(cus * fo)), max(1, int(cus * fd)))
@@ -652,14 +658,14 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
     merged = nb == 1 and int(obs_cam.shape[0]) < MERGED_TILE_MAX_OBS
     chunk_desc, entries, tile_desc, obs_slot, nseg, batch_desc = build_schur_tiles(
         row_ptr, obs_cam, max_chunks=slots, num_batches=nb, later_scale=(cus - CHOL_CUS) / cus,
-        merged_slots=(slots[0] if merged else None),
-        block_rows=6 if shared_camera else 6 + (2 if camera_type == "SIMPLE_RADIAL" else 1))
+        merged_slots=(slots[0] if merged else None), block_rows=block_rows)
     prob = DeviceProblem(cam_q, cam_t, intr, pts, row_ptr, obs_cam, obs_uv, col_ptr, cobs_pt, cobs_uv, chunk_desc,
                          entries, tile_desc, obs_slot, nseg, MODEL_ID[camera_type], cam_const=cam_const,
-                         batch_desc=batch_desc, chol_split=chol_split, cam_perm=cam_perm, merged_tile_launch=merged)
+                         batch_desc=batch_desc, chol_split=chol_split, cam_perm=cam_perm, merged_tile_launch=merged,
+                         refine_focal=bool(refine_focal_length), refine_extra=bool(refine_extra_params))
     if first_group is not None:
-        kd = 2 if camera_type == "SIMPLE_RADIAL" else 1              # upper bound of the intrinsics unknowns per block
-        prob.chol_first_blk = envelope_blocks(first_group, S, 6 * S + kd * n_intr).to(dev)
+        kd_max = 2 if camera_type == "SIMPLE_RADIAL" else 1          # upper bound of the intrinsics unknowns per block
+        prob.chol_first_blk = envelope_blocks(first_group, S, 6 * S + kd_max * n_intr).to(dev)
     return prob, valid_idx, deleted
 
 
@@ -772,10 +778,12 @@ def bundle_adjustment(points3d, extrinsics, intrinsics, tracks, masks, image_siz
     (frame 0 pose + frame 1 t_x constant).  `filter_negative_depth=False` for the BundleAdjuster-level entry
     (``solve_bundle_adjustment``), which does not run the ObservationManager filter."""
     _lib.require_gpu(points3d, extrinsics, intrinsics, tracks, masks)
+    options = options or BundleAdjustmentOptions()
     prob, valid_idx, deleted = compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_params,
                                                shared_camera, camera_type, filter_negative_depth=filter_negative_depth,
                                                gauge="colmap" if constant_pose_frames is None else "config",
-                                               camera_split=True)
+                                               camera_split=True, refine_focal_length=options.refine_focal_length,
+                                               refine_extra_params=options.refine_extra_params)
     S = extrinsics.shape[0]
     inv_perm = None
     if prob.cam_perm is not None:

@@ -67,6 +67,7 @@ constexpr int kSub = 32;         // entries per strided sub-chunk of a Schur wor
 constexpr int kMaxWG = 2048;
 constexpr int kCamSplitMax = 16;  // workgroups per camera in the camera passes
 constexpr int kCamNV = 48;        // >= values a camera pass accumulates (BD(BD+1)/2 + BD + 1 <= 45)
+constexpr int kPackPad = 1024;    // >= ranks of a sharded solve (padding of the packed reduced system to equal slices)
 
 struct Ctl {
   double radius, decrease_factor, x_cost, initial_cost, gmax_cams, gmax, cand_cost, mcc, step_norm, rel;
@@ -107,8 +108,11 @@ struct Ws {  // device workspace carve-up (pointers into the caller's buffer)
   double* T;                  // [C][BDp][1+kdsh]
   double* part_B;             // [kMaxWG] per-workgroup gradient max
   double* part_F;             // [kMaxWG][4]
-  double* packed;             // lower triangle of S (row by row) + rhs: the multi-GPU reduce payload
-  size_t packed_count;
+  double* packed;             // lower triangle of S (row by row) + rhs: the multi-GPU reduce payload, followed by kPackPad
+  size_t packed_count;        //   doubles of padding (the reduce-scatter input is W equal slices: W ceil(count / W) doubles)
+  double* pk_mine;            // [ceil(count / W) + 1] this rank's reduced slice + its local gradient maximum (reduce-scatter
+                              //   output = all-gather input)
+  double* pk_gathered;        // [W (ceil(count / W) + 1)] the all-gather output, read in place by the unpack (phase 6)
   double* cam_part;           // [C+1][2] step^2 / x^2 of camera-side parameters
   double* cam_split;          // [C][kCamSplitMax][kCamNV] partial sums of the split camera passes
   double* Y;                  // [num_segments][16][BDt*3] zero-padded per-observation Schur factors s_c o (F^T E G_p)
@@ -156,7 +160,9 @@ static Ws carve(const Dims& d, int max_iters, int num_chunks, int num_segments, 
   w.S = w.sys; w.rhs = w.S + (size_t)d.n_red * d.n_red;
   w.S2 = (double*)take(8ull * (size_t)d.n_red * d.n_red);
   w.packed_count = (size_t)d.n_red * (d.n_red + 1) / 2 + d.n_red;
-  w.packed = (double*)take(8ull * w.packed_count);
+  w.packed = (double*)take(8ull * (w.packed_count + kPackPad));
+  w.pk_mine = (double*)take(8ull * ((w.packed_count + 1) / 2 + 2));            // (W >= 2)
+  w.pk_gathered = (double*)take(8ull * (w.packed_count + 2 * kPackPad));
   w.gmax_pts = (double*)take(64);
   w.stepsum = (double*)take(64);
   w.G = (double*)take(8ull * 6 * d.P); w.hs = (double*)take(8ull * 3 * d.P);
@@ -1751,15 +1757,36 @@ struct Launch {
 
 // Multi-GPU payload of the reduced system: only the lower triangle is ever filled, so the all-reduce carries
 // n(n+1)/2 + n doubles instead of n^2 + n (phases 4 / 5, called by the distributed host loop only).
-__global__ __launch_bounds__(256) void pack_lower_kernel(Ws w, int n, int unpack) {
+// mode 0: S, rhs -> packed (+ the zero tail up to W equal slices, + this rank's gradient maximum behind its slice buffer);
+// mode 1: packed -> S, rhs;  mode 2: the all-gather output -> S, rhs (slice r of ceil(count / W) elements sits at
+// r (ceil(count / W) + 1), followed by rank r's gradient maximum) and the maximum over the ranks -> gmax_pts.
+__global__ __launch_bounds__(256) void pack_lower_kernel(Ws w, int n, int mode) {
   if (w.ctl->done) return;
   const int i = blockIdx.x;                                   // row i, or row n = the right-hand side
   const size_t base = (i < n) ? (size_t)i * (i + 1) / 2 : (size_t)n * (n + 1) / 2;
   const int len = (i < n) ? i + 1 : n;
   double* full = (i < n) ? w.S + (size_t)i * n : w.rhs;
-  for (int j = threadIdx.x; j < len; j += 256) {
-    if (unpack) full[j] = w.packed[base + j];
-    else w.packed[base + j] = full[j];
+  const int W = w.ctl->world > 0 ? w.ctl->world : 1;
+  const size_t chunk = (w.packed_count + W - 1) / W;
+  if (mode == 0) {
+    for (int j = threadIdx.x; j < len; j += 256) w.packed[base + j] = full[j];
+    if (i == n) {
+      for (size_t j = w.packed_count + threadIdx.x; j < (size_t)W * chunk; j += 256) w.packed[j] = 0.0;
+      if (threadIdx.x == 0) w.pk_mine[chunk] = w.gmax_pts[0];
+    }
+  } else if (mode == 1) {
+    for (int j = threadIdx.x; j < len; j += 256) full[j] = w.packed[base + j];
+  } else {
+    for (int j = threadIdx.x; j < len; j += 256) {
+      const size_t e = base + j, r = e / chunk;
+      full[j] = w.pk_gathered[r * (chunk + 1) + (e - r * chunk)];
+    }
+    if (i == n && threadIdx.x < 64) {
+      double m = 0.0;
+      for (int r = threadIdx.x; r < W; r += 64) m = fmax(m, w.pk_gathered[(size_t)r * (chunk + 1) + chunk]);
+      m = wave_max(m);
+      if (threadIdx.x == 0) w.gmax_pts[0] = m;
+    }
   }
 }
 
@@ -2020,6 +2047,7 @@ static int run_phase(const Launch& L, int phase) {
     case 3: phase_update(L); return VGG_OK;
     case 4: pack_lower_kernel<<<L.d.n_red + 1, 256, 0, L.st>>>(L.w, L.d.n_red, 0); return VGG_OK;
     case 5: pack_lower_kernel<<<L.d.n_red + 1, 256, 0, L.st>>>(L.w, L.d.n_red, 1); return VGG_OK;
+    case 6: pack_lower_kernel<<<L.d.n_red + 1, 256, 0, L.st>>>(L.w, L.d.n_red, 2); return VGG_OK;
     default: return VGG_ERR_INVALID_ARGUMENT;
   }
 }
@@ -2116,6 +2144,7 @@ int vgg_ba_begin(const vgg_ba_problem* problem, const vgg_ba_options* options, v
   int rc = make_launch(problem, options, workspace, (hipStream_t)stream, &L);
   if (rc != VGG_OK) return rc;
   if (workspace_bytes < L.w.total_bytes) return VGG_ERR_WORKSPACE;
+  if (world_size < 1 || world_size > kPackPad || rank < 0 || rank >= world_size) return VGG_ERR_INVALID_ARGUMENT;
   VGG_HIP_CHECK(hipMemsetAsync(L.w.Y, 0, L.w.y_bytes, L.st));   // absent slots stay zero for the whole solve
   init_kernel<<<div_up(L.d.n_red > 0 ? L.d.n_red : 1, 256), 256, 0, L.st>>>(L.dp, L.w, L.opt, rank, world_size);
   VGG_LAUNCH_CHECK();
@@ -2143,6 +2172,8 @@ int vgg_ba_reduce_buffer(const vgg_ba_problem* problem, const vgg_ba_options* op
     case 2: *device_ptr = w.gmax_pts; *count = 1; break;
     case 3: *device_ptr = w.stepsum; *count = 4; break;
     case 4: *device_ptr = w.packed; *count = w.packed_count; break;
+    case 5: *device_ptr = w.pk_mine; *count = (w.packed_count + 1) / 2 + 2; break;
+    case 6: *device_ptr = w.pk_gathered; *count = w.packed_count + 2 * kPackPad; break;
     default: return VGG_ERR_INVALID_ARGUMENT;
   }
   return VGG_OK;

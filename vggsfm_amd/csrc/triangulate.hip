@@ -164,10 +164,13 @@ struct Cand { double e; int n; };   // mean inlier error (or 2*pi) and inlier co
 // Evaluate hypothesis X against all views.  ACC: also accumulate the DLT matrix of its inlier views.
 // ransac_nan: NaN errors poison the mean (residual indicator on raw errors); otherwise NaN -> 100*pi.
 // `vlist[0 .. nv)`: the views in which the track is visible (flag 0), ascending.  Only they can hold inliers, so only they
-// are evaluated; a NaN error cannot appear in one view alone (it needs a non-finite point, which has no inlier anywhere:
-// the mean is 2 pi either way), and the cheirality test over ALL views (`any_behind`) needs the depth of the other views
-// only -- one row of P X, the expression view_error uses.  Same values, same order of the sums; ~4x fewer evaluations at
-// the visibility density of the BASELINE scenes.
+// are evaluated.  A NaN error in an INVISIBLE view -- which the reference's mean over all views would turn into NaN
+// (triangulation.py:842-877) -- has two sources: a non-finite point (NaN in every view, the visible ones included) or a
+// non-finite ray of that view (a normalised track coordinate that is inf / NaN, e.g. the undistortion of an off-image
+// point); the second is a property of the TRACK and is found when the table is built (`bad_ray` in triangulate_kernel,
+// which then poisons every RANSAC hypothesis as the reference's NaN mean does).  The cheirality test over ALL views
+// (`any_behind`) needs the depth of the other views only -- one row of P X, the expression view_error uses.  Same values,
+// same order of the sums; ~4x fewer evaluations at the visibility density of the BASELINE scenes.
 template <bool ACC>
 __device__ __forceinline__ Cand eval_views(const double* __restrict__ ext, const double* tab, const int* vlist, int nv, int S,
                                            double X0, double X1, double X2, bool invalid, bool live, double max_rad,
@@ -214,6 +217,7 @@ __device__ __forceinline__ Cand eval_views(const double* __restrict__ ext, const
 // untouched): the same additions in the same order as eval_views -- bit-identical counts, sums and DLT matrices.
 // src0 = first lane of this lane's group, vq = its position inside the group.
 constexpr int kGV = 6;
+static_assert(10 * kGV <= 64, "ten hypotheses of the second local-optimisation round, kGV lanes each");
 template <bool ACC>
 __device__ __forceinline__ Cand eval_views_grouped(const double* __restrict__ ext, const double* tab, const int* vlist, int nv,
                                                    int S, double X0, double X1, double X2, bool invalid, bool live,
@@ -243,8 +247,10 @@ __device__ __forceinline__ Cand eval_views_grouped(const double* __restrict__ ex
     const unsigned long long inl_mask = __ballot(inl);
 #pragma unroll
     for (int k = 0; k < kGV; ++k) {
-      const int src = src0 + k;
-      const bool inl_k = ((inl_mask >> src) & 1ull) != 0;
+      // (lanes behind the last group -- 60..63 -- belong to no hypothesis: their source lane is clamped into the wavefront
+      //  and they never count; their results are discarded by the caller)
+      const int src = min(src0 + k, 63);
+      const bool inl_k = (src0 + k < 64) && ((inl_mask >> src) & 1ull) != 0;
       const double e_k = __shfl(err, src, 64);
       cnt += inl_k ? 1 : 0;
       sum = inl_k ? sum + e_k : sum;
@@ -302,6 +308,7 @@ __global__ __launch_bounds__(64, 2) void triangulate_kernel(   // (two wavefront
     const double thres = thres_all[chunk];
     __syncthreads();
     // ---- per-view table (tracks are given track-major: tn[n][s][2], ivc[n][s])
+    bool nonfinite = false;
     for (int s = lane; s < S; s += 64) {
       const double u = tn[((size_t)n * S + s) * 2], v = tn[((size_t)n * S + s) * 2 + 1];
       const double nr = sqrt(u * u + v * v + 1.0);
@@ -310,7 +317,11 @@ __global__ __launch_bounds__(64, 2) void triangulate_kernel(   // (two wavefront
       // F.normalize of the same homogeneous ray (eps 1e-12 never binds: norm >= 1)
       t[0] = r0; t[1] = r1; t[2] = r2;
       t[3] = ivc[(size_t)n * S + s] ? 1.0 : 0.0;
+      nonfinite = nonfinite || !(fabs(r0) <= 1.7976931348623157e308 && fabs(r1) <= 1.7976931348623157e308 && r2 == r2);
     }
+    // a non-finite ray in ANY view, visible or not, makes the angular error of that view NaN for every hypothesis: the
+    // reference's mean over all views is then NaN for all of them (see eval_views)
+    const bool bad_ray = __any(nonfinite);
     // visible views of the track, ascending (one wavefront per track: a ballot per 64 views)
     int nv = 0;
     for (int base = 0; base < S; base += 64) {
@@ -356,7 +367,7 @@ __global__ __launch_bounds__(64, 2) void triangulate_kernel(   // (two wavefront
     double sum[HJ];
     bool pois[HJ];
 #pragma unroll
-    for (int j = 0; j < HJ; ++j) { cnt[j] = 0; sum[j] = 0.0; pois[j] = false; }
+    for (int j = 0; j < HJ; ++j) { cnt[j] = 0; sum[j] = 0.0; pois[j] = bad_ray; }
     // (visible views only: see eval_views)
     for (int k = 0; k < ((VGG_TRI_ABLATE & 1) ? 0 : nv); ++k) {
       const int s = vlist[k];

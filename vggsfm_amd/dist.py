@@ -71,15 +71,34 @@ def _gather_rows(local, counts, group=None):
     return torch.cat([p[:c] for p, c in zip(parts, counts)])
 
 
+def _adopt_rank0_rng(device, group=None):
+    """Every rank continues from rank 0's global CPU RNG state (5 KB broadcast; through the device for RCCL, which moves
+    device memory only)."""
+    import torch.distributed as dist
+    state = torch.get_rng_state()
+    on_device = dist.get_backend(group) == "nccl"
+    buf = state.to(device) if on_device else state.clone()
+    dist.broadcast(buf, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    torch.set_rng_state(buf.cpu())
+
+
 def triangulate_tracks_sharded(extrinsics, tracks_normalized, rank, world_size, track_vis=None, track_score=None, gather=True,
-                               group=None, **kw):
+                               group=None, sync_rng=True, **kw):
     """`triangulate_tracks` with the track axis shared by the ranks ("shard with no collective").  The unit is
     the reference's own chunk (triangulation.py:712-758: one randperm draw and one chunk-global indicator threshold per
     chunk), so every rank -- seeded alike -- draws the pairs of all chunks and triangulates a contiguous range of them: the
     concatenation over the ranks is bit for bit the single-rank result.  configs[2] has 25 chunks, configs[3] 147.
     gather=True: all-gather of points / inlier counts / masks (the only communication); False: the rank's own slice and
-    its track range."""
+    its track range.
+    sync_rng (default): the draws come from the global CPU RNG, which a rank may have consumed differently before this call
+    (data loading, per-rank seeding) -- the gathered result would then silently differ from the single-rank one -- so every
+    rank first adopts rank 0's RNG state; False: the caller guarantees identical states (or has no process
+    group: the lock-step tests)."""
     from .utils.triangulation import reference_chunks, triangulate_tracks
+    if sync_rng and world_size > 1:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            _adopt_rank0_rng(tracks_normalized.device, group)
     S, N = tracks_normalized.shape[0], tracks_normalized.shape[1]
     chunk_size, num_chunks = reference_chunks(S, N, kw.get("max_tri_points_num", 819200))
     b = chunk_ranges(num_chunks, world_size)
@@ -113,19 +132,46 @@ def filter_all_points3D_sharded(points3D, points2D, extrinsics, intrinsics, rank
 class Collectives:
     """The three exchanges of one LM iteration over ``torch.distributed``.
 
-    `system_(packed, local_max)`: SUM of the packed reduced system over the ranks, in place, and MAX of the one-element
-    `local_max`, in place: the payload is padded to N equal slices, reduce-scattered, and all-gathered with each rank's
-    local maximum appended to its slice (RCCL on the GPU box; gloo implements both calls too, which is how the CPU tests
-    run this very code).  `plain_all_reduce=True` keeps the round-2 form -- two all-reduces -- for A/B measurements."""
+    `system_scatter(padded, mine, gathered)`: SUM of the packed reduced system over the ranks as a reduce-scatter + an
+    all-gather on the solver's OWN buffers (``vgg_ba_reduce_buffer`` 4 / 5 / 6; include/vggsfm_amd.h, phase 6): `padded` =
+    the packed system zero-padded to W equal slices by the pack kernel, `mine` = this rank's reduced slice with its local
+    gradient maximum behind it, `gathered` = the W slices, which the unpack kernel reads in place -- no staging copy on
+    either side (round 3 copied the payload twice, 41 MB each at configs[3]) and no MAX collective.  RCCL on the GPU box;
+    gloo implements both calls too, which is how the CPU tests run this very code.
+    `system_(packed, local_max)`: the same on caller-owned tensors through internal staging buffers (tests);
+    `plain_all_reduce=True` keeps the round-2 form -- two all-reduces -- for A/B measurements."""
 
-    def __init__(self, world_size, group=None, plain_all_reduce=False):
+    def __init__(self, world_size, group=None, plain_all_reduce=False, host_staging=None):
         import torch.distributed as dist
         self.dist, self.world, self.group = dist, world_size, group
         self.scatter = not plain_all_reduce
         self._bufs = {}
+        # gloo moves host memory: device tensors are staged through the host (rehearsals of the N > 1 flow on a box with
+        # fewer GPUs than ranks -- bench.py with VGGSFM_BENCH_BACKEND=gloo; never the measured path, which is RCCL)
+        self.host_staging = (dist.is_initialized() and dist.get_backend(group) == "gloo") if host_staging is None else host_staging
+
+    def _staged(self, t):
+        return self.host_staging and t.is_cuda
 
     def sum_(self, t):
+        if self._staged(t):
+            h = t.cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+            return
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def system_scatter(self, padded, mine, gathered):
+        dist = self.dist
+        if self._staged(padded):
+            hp, hm, hg = padded.cpu(), mine.cpu(), torch.empty(gathered.shape, dtype=gathered.dtype)
+            dist.reduce_scatter_tensor(hm[:-1], hp, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_gather_into_tensor(hg, hm, group=self.group)
+            mine.copy_(hm)
+            gathered.copy_(hg)
+            return
+        dist.reduce_scatter_tensor(mine[:-1], padded, op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_gather_into_tensor(gathered, mine, group=self.group)
 
     def system_(self, packed, local_max):
         dist, W = self.dist, self.world
@@ -142,9 +188,8 @@ class Collectives:
                                torch.empty(W * (chunk + 1), dtype=packed.dtype, device=packed.device))
         padded, mine, gathered = self._bufs[key]
         padded[:M].copy_(packed)                                  # (the tail stays zero)
-        dist.reduce_scatter_tensor(mine[:chunk], padded, op=dist.ReduceOp.SUM, group=self.group)
         mine[chunk:].copy_(local_max[:1])
-        dist.all_gather_into_tensor(gathered, mine, group=self.group)
+        self.system_scatter(padded, mine, gathered)
         g = gathered.view(W, chunk + 1)
         packed.copy_(g[:, :chunk].reshape(-1)[:M])
         local_max[:1].copy_(g[:, chunk].max().reshape(1))
@@ -182,7 +227,7 @@ class ShardedBA:
         self.nbytes = nbytes
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=problem.pts.device)
         self.bufs = []
-        for which in range(5):
+        for which in range(7):
             p = ctypes.POINTER(ctypes.c_double)()
             cnt = ctypes.c_size_t()
             _lib.check(self.L.vgg_ba_reduce_buffer(ctypes.byref(self.cp), ctypes.byref(self.co), _lib.ptr(self.ws), which,
@@ -192,6 +237,14 @@ class ShardedBA:
         if collectives is None and world_size > 1:
             collectives = _FunctionCollectives(all_reduce) if all_reduce is not None else Collectives(world_size)
         self.coll = collectives
+        # reduce-scatter / all-gather views of the solver's own buffers (phase 4 pads, phase 6 reads the gathered slices)
+        M = self.bufs[4].numel()
+        chunk = -(-M // max(world_size, 1))
+        off4 = self.bufs[4].data_ptr() - self.ws.data_ptr()
+        self._padded = self.ws[off4:off4 + 8 * world_size * chunk].view(torch.float64)
+        self._mine = self.bufs[5][:chunk + 1]
+        self._gathered = self.bufs[6][:world_size * (chunk + 1)]
+        self._in_place = world_size > 1 and isinstance(collectives, Collectives) and collectives.scatter
 
     def begin(self):
         _lib.check(self.L.vgg_ba_begin(ctypes.byref(self.cp), ctypes.byref(self.co), _lib.ptr(self.ws),
@@ -208,9 +261,13 @@ class ShardedBA:
             co.sum_(self.bufs[0])
         self._phase(1)
         if co:
-            self._phase(4)                      # lower triangle + rhs -> packed buffer (half the payload)
-            co.system_(self.bufs[4], self.bufs[2])
-            self._phase(5)
+            self._phase(4)                      # lower triangle + rhs -> packed buffer (half the payload), padded to W slices
+            if self._in_place:
+                co.system_scatter(self._padded, self._mine, self._gathered)
+                self._phase(6)                  # S | rhs and the gradient maximum straight from the gathered slices
+            else:
+                co.system_(self.bufs[4], self.bufs[2])
+                self._phase(5)
         self._phase(2)
         if co:
             co.sum_(self.bufs[3])

@@ -1041,14 +1041,22 @@ class BundleAdjuster:
         # COLMAP BundleAdjuster::SetUp: a point whose track has observations in images OUTSIDE the config is held constant
         # (its track length exceeds its observations inside the problem) unless it was named with add_variable_point.  The
         # reference's call sites put every registered image into the config (video_runner.py:817-829), where this selects
-        # nothing.  (Deviation for configs that do leave images out: COLMAP also adds a variable point's observations in those
-        # images, with their poses constant; here they are not part of the problem.)
+        # nothing.  COLMAP's tracks only hold REGISTERED images (DeRegisterImage deletes the observations): 2D points linked
+        # in an image that is not registered do not count.  A variable point with observations outside the config would need
+        # those images in the problem with constant poses (COLMAP adds them); the reference never builds such a config, so
+        # that case raises instead of silently losing the observations.
         rec = self.reconstruction
         ptr, timg, _ = rec._track_csr()
+        registered = np.isin(timg, np.asarray(rec.reg_image_ids(), np.int64))
         inside = np.isin(timg, np.asarray(cfg.image_ids, np.int64))
         pid_of_obs = np.repeat(np.arange(1, len(ptr)), np.diff(ptr))
-        partly_outside = np.unique(pid_of_obs[~inside])
-        constant = set(cfg.constant_point3D_ids) | ({int(p) for p in partly_outside} - set(cfg.variable_point3D_ids))
+        partly_outside = {int(p) for p in np.unique(pid_of_obs[registered & ~inside])}
+        lost = partly_outside & set(cfg.variable_point3D_ids)
+        if lost:
+            raise NotImplementedError(f"BundleAdjustmentConfig: {len(lost)} variable point(s) (e.g. id {min(lost)}) are observed in "
+                                      "registered images outside the config; COLMAP would add those observations with constant "
+                                      "poses -- add the images to the config with set_constant_cam_pose")
+        constant = set(cfg.constant_point3D_ids) | partly_outside
         return _solve(rec, opts, cfg.image_ids, constant, sorted(cfg.constant_cam_poses), default_gauge=False)
 
     def solve(self, reconstruction):

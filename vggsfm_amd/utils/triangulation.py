@@ -75,7 +75,8 @@ def reference_chunks(S, N, max_tri_points_num=819200):
 
 
 def triangulate_tracks(extrinsics, tracks_normalized, max_ransac_iters=256, lo_num=50, max_angular_error=2,
-                       min_tri_angle=1.5, track_vis=None, track_score=None, max_tri_points_num=819200, chunk_range=None):
+                       min_tri_angle=1.5, track_vis=None, track_score=None, max_tri_points_num=819200, chunk_range=None,
+                       check_finite=True):
     """Reference: triangulation.py:677-773.  extrinsics (S,3,4), tracks_normalized (S,N,2), vis/score (S,N)
     -> points (N,3) f64, inlier_num (N) int64, inlier_mask (N,S) bool.
     The reference splits the track axis into ceil(S*N/max_tri_points_num) chunks (torch.chunk), each with its own
@@ -87,7 +88,14 @@ def triangulate_tracks(extrinsics, tracks_normalized, max_ransac_iters=256, lo_n
     chunk_range = (c0, c1): only the reference chunks c0 .. c1-1 are triangulated and the results cover just their tracks
     [c0 chunk_size, min(N, c1 chunk_size)) -- the RNG draws of ALL chunks are still consumed, in order, so that ranks which
     share the work by whole chunks (vggsfm_amd.dist.triangulate_tracks_sharded) reproduce the single-rank result bit for
-    bit."""
+    bit.
+    Error behaviour: non-finite normalised tracks raise ``torch.linalg.LinAlgError`` as in the reference, whose batched
+    ``eigh`` fails on the DLT matrix of a view pair with such a ray whether the view is visible or not
+    (triangulation_helpers.py:87; checked live against the reference in the CPU suite).  `check_finite=False` skips the test (one reduction
+    + host read): the kernel then treats such a track as the reference's NaN mean would -- all its RANSAC hypotheses void."""
+    if check_finite and not bool(torch.isfinite(tracks_normalized).all()):
+        raise torch.linalg.LinAlgError("triangulate_tracks: non-finite normalised track coordinates (the reference's "
+                                       "linalg.eigh fails on the DLT matrices of such views)")
     if max_ransac_iters > 256 or lo_num > 64 or max_ransac_iters < 1 or lo_num < 1:
         raise ValueError(f"triangulate_tracks: max_ransac_iters={max_ransac_iters} (1..256) / lo_num={lo_num} (1..64) are outside "
                          "what vgg_triangulate_tracks_chunks supports (the reference calls it with 256 or 128, and 50)")

@@ -191,3 +191,33 @@ def test_dropin_reconstruction_is_a_pycolmap_object(tmp_path):
     assert back.num_reg_images() == 9 and back.num_points3D() == rec.num_points3D()
     assert back.images[0].name == "frame_0.png" and back.cameras[0].width == 2048
     assert np.array_equal(back.images[4].points2D._xy, rec.images[4].points2D._xy)
+
+
+@pytest.mark.parametrize("cam,shared", [("SIMPLE_PINHOLE", False), ("SIMPLE_RADIAL", True)])
+def test_batch_matrix_to_pycolmap_device_selection_equals_host_construction(cam, shared):
+    """``batch_matrix_to_pycolmap`` on GPU tensors selects the observations on the device and ships the lists
+    (``Reconstruction.from_frame_lists``); same model as the host construction ``Reconstruction.from_arrays`` (which
+    tests/test_pycolmap_compat.py pins to the reference's own loop), including the two exclusion rules: tracks with fewer
+    than two observations and points with a coordinate >= max_points3D_val."""
+    from vggsfm_amd.utils.tensor_to_pycolmap import batch_matrix_to_pycolmap
+    sc = make_scene(14, 700, cam, shared_camera=shared, seed=21)
+    ext0, K0, xp0, pts0 = perturb_for_ba(sc, seed=21)
+    mask = sc.mask.copy()
+    mask[1:, 5] = False                                # a track with one observation
+    pts0[9, 1] = 4000.0                                # a point beyond the cap: kept, without observations
+    D = lambda x: None if x is None else torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    size = torch.tensor([1024, 1024])
+    a = batch_matrix_to_pycolmap(D(pts0), D(ext0), D(K0), D(sc.tracks), D(mask), size, shared_camera=shared, camera_type=cam,
+                                 extra_params=D(xp0))
+    b = pc.Reconstruction.from_arrays(pts0, ext0, K0, sc.tracks, mask, size.numpy(), 3000, shared, cam, xp0)
+    assert a.num_points3D() == b.num_points3D() and np.array_equal(a.valid_idx, b.valid_idx)
+    assert np.array_equal(a._xyz[:a._n], b._xyz[:b._n]) and sorted(a.cameras) == sorted(b.cameras)
+    for i in sorted(b.images):
+        assert np.array_equal(a.images[i].points2D._pid, b.images[i].points2D._pid)
+        assert np.array_equal(a.images[i].points2D._xy, b.images[i].points2D._xy)
+        assert np.array_equal(a.images[i].cam_from_world.matrix(), b.images[i].cam_from_world.matrix())
+        assert a.images[i].camera_id == b.images[i].camera_id
+        assert np.array_equal(a.cameras[a.images[i].camera_id].params, b.cameras[b.images[i].camera_id].params)
+    pa, ia, xa = a._track_csr()
+    pb, ib, xb = b._track_csr()
+    assert np.array_equal(pa, pb) and np.array_equal(ia, ib) and np.array_equal(xa, xb)

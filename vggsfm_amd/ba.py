@@ -387,6 +387,7 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
             batch_desc.contiguous())
 
 
+TILE_BACKFILL = None               # (off-diagonal, diagonal) workgroups per CU of the single back-filled tile launch; None = two launches
 TILE_WGS_PER_CU = (3, 4)           # resident schur_tile workgroups per CU with 6 x 6 blocks: (off-diagonal, diagonal) launch
 SPARSE_GRID_DENSITY = 0.05        # compile_problem: below this fill of the (frames x tracks) grid work on the observation list
 MERGED_TILE_MAX_OBS = 1_000_000   # below: off-diagonal and diagonal tiles share one launch
@@ -656,9 +657,22 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
     nb = TILE_BATCHES if (overlap and int(obs_cam.shape[0]) >= OVERLAP_MIN_OBS and S >= OVERLAP_MIN_FRAMES) else 1
     # small problems: one tile launch (c2, 0.25 M observations: 0.101 -> 0.068 ms for the tiles; c3, 5 M: 0.84 -> 0.90 ms)
     merged = nb == 1 and int(obs_cam.shape[0]) < MERGED_TILE_MAX_OBS
+    merged_slots = slots[0] if merged else None
+    backfill = TILE_BACKFILL if block_rows == 6 else None
+    if os.environ.get("VGGSFM_TILE_BACKFILL"):         # measurement hook: "off,diag" workgroups per CU, or "0" = two launches
+        v = os.environ["VGGSFM_TILE_BACKFILL"]
+        backfill = None if v == "0" else tuple(float(x) for x in v.split(","))
+    if backfill is not None and nb == 1 and not merged:
+        # ONE launch, off-diagonal chunks first (one resident round at the merged kernel's occupancy), the diagonal chunks
+        # behind them: the in-order dispatcher hands a diagonal workgroup to every slot an off-diagonal one leaves, so the
+        # ~16 % of the chip that idled while the slowest off-diagonal tiles finished (round 3 phase trace) computes diagonal
+        # tiles instead.  (Not the round-2 "merged" form, where both kinds shared one resident round and swept the points
+        # together: 0.90 ms against 0.62 + 0.24.)
+        merged, merged_slots = True, None
+        slots = (max(1, int(cus * backfill[0])), max(1, int(cus * backfill[1])))
     chunk_desc, entries, tile_desc, obs_slot, nseg, batch_desc = build_schur_tiles(
         row_ptr, obs_cam, max_chunks=slots, num_batches=nb, later_scale=(cus - CHOL_CUS) / cus,
-        merged_slots=(slots[0] if merged else None), block_rows=block_rows)
+        merged_slots=merged_slots, block_rows=block_rows)
     prob = DeviceProblem(cam_q, cam_t, intr, pts, row_ptr, obs_cam, obs_uv, col_ptr, cobs_pt, cobs_uv, chunk_desc,
                          entries, tile_desc, obs_slot, nseg, MODEL_ID[camera_type], cam_const=cam_const,
                          batch_desc=batch_desc, chol_split=chol_split, cam_perm=cam_perm, merged_tile_launch=merged,

@@ -542,6 +542,40 @@ class Reconstruction:
             rec.add_image(img)
         return rec
 
+    @classmethod
+    def from_frame_lists(cls, points3d_valid, valid_idx, extrinsics, intrinsics, xy, point3D_ids, frame_counts, image_size,
+                         shared_camera=False, camera_type="SIMPLE_PINHOLE", extra_params=None):
+        """The same model as :meth:`from_arrays` from observation LISTS the caller selected already (on the device:
+        ``vggsfm_amd.utils.tensor_to_pycolmap.batch_matrix_to_pycolmap``): points3d_valid (n,3) = the kept tracks in track
+        order, valid_idx (n,) their input track indices, xy (O,2) f64 / point3D_ids (O,) i64 frame-major (frame f owns the
+        next frame_counts[f] rows, tracks ascending inside a frame).  The per-image lists are views of xy / point3D_ids."""
+        if camera_type not in CAMERA_MODEL_IDS:
+            raise ValueError(f"Camera type {camera_type} is not supported yet")
+        ext, K, size = _np(extrinsics), _np(intrinsics), _np(image_size).reshape(-1)
+        xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
+        pid = np.ascontiguousarray(point3D_ids, dtype=np.int64).reshape(-1)
+        S = len(ext)
+        rec = cls()
+        rec.valid_idx = np.asarray(valid_idx)
+        n = len(points3d_valid)
+        rec._reserve(n)
+        rec._xyz[:n], rec._alive[:n], rec._n = _np(points3d_valid), True, n
+        off = np.concatenate([[0], np.cumsum(np.asarray(frame_counts, dtype=np.int64))])
+        assert off[-1] == len(pid) == len(xy) and len(off) == S + 1
+        camera = None
+        for f in range(S):
+            if camera is None or not shared_camera:
+                prm = [K[f, 0, 0], K[f, 0, 2], K[f, 1, 2]]
+                if camera_type == "SIMPLE_RADIAL":
+                    prm.append(_np(extra_params)[f, 0])
+                camera = Camera(camera_type, size[0], size[1], prm, f)
+                rec.add_camera(camera)
+            img = Image(f, f"image_{f}", camera.camera_id, Rigid3d(Rotation3d(ext[f, :, :3]), ext[f, :, 3]))
+            img.points2D = ListPoint2D.from_arrays(xy[off[f]:off[f + 1]], pid[off[f]:off[f + 1]])
+            img._registered = True
+            rec.add_image(img)
+        return rec
+
     # ---- point storage
     def _reserve(self, n):
         cap = len(self._alive)

@@ -139,7 +139,7 @@ typedef struct {
   int32_t num_tile_batches;   /* >= 1: the tiles are cut into batches of consecutive camera groups groupI (tile_batches) */
   const int32_t* chunk_desc;  /* [num_chunks,6] = groupI, groupJ, tile_entry_begin, tile_entry_end, j, J:
                                  workgroup j of the J of its tile takes the 32-entry sub-chunks j, j+J, ... */
-  const int32_t* entries;     /* [num_entries,4] = sweep position of the point, segment_A, segment_B, maskA | maskB<<16 of the
+  const int32_t* entries;     /* [num_entries,4] = point index (row of pts), segment_A, segment_B, maskA | maskB<<16 of the
                                  QUAD: the four consecutive entries, aligned to tile_entry_begin, that the kernel packs
                                  along K (bit l of a mask: camera group*16+l observes one of the four points; 16-row
                                  blocks of the tile without any camera are skipped for the quad) */
@@ -317,6 +317,12 @@ int vgg_fmat_residuals(const double* points1, const double* points2, const uint8
  * Jacobians; cam_workgroups / point_workgroups (0 = automatic) -- total workgroups of the camera / point passes.  Every
  * combination computes the same iteration up to the order of its sums. */
 int vgg_ba_tuning(int lanes_per_point, int long_tracks, int cam_workgroups, int point_workgroups);
+/* Where F^T (r - E h) and the shared-intrinsics border of the reduced system come from when the tile blocks are 6 x 6 (shared
+ * or constant intrinsics): 1 (default; VGG_TILE_RHS in the environment seeds it) = from the diagonal Schur tile launch, whose
+ * staged segments are multiplied by a 3 x 3 per-point block on the side, + per-point sums of the point pass -- no second
+ * camera-major evaluation of the projections per iteration; 0 = the camera pass cam_pass<RHS> (always used with 7 x 7 / 8 x 8
+ * blocks).  Both compute the same system up to the order of its sums.  Requires entries[e][0] = the entry's point. */
+int vgg_ba_set_tile_rhs(int enable);
 int vgg_ba_profile(int enable, int max_launches_per_kernel);
 int vgg_ba_profile_read(int kernel_id, double* total_ms, int* launches, int reset);
 

@@ -49,8 +49,12 @@ def main():
             name, _, envs = v.partition(":")
             os.environ.clear()
             os.environ.update(base_env)
+            L.vgg_ba_set_tile_rhs(1)
             for kv in filter(None, envs.split(",")):
                 k, _, val = kv.partition("=")
+                if k == "TILE_RHS":                        # (process-wide library switch, not an environment variable here)
+                    L.vgg_ba_set_tile_rhs(int(val))
+                    continue
                 os.environ[k] = val.replace(";", ",")
             prob, _, _ = BA.compile_problem(*args, shared, cam, camera_split=True)
             init = [t.clone() for t in (prob.cam_q, prob.cam_t, prob.intr, prob.pts)]

@@ -1,5 +1,5 @@
 """Phase cycle sums of the off-diagonal Schur tile launch per wavefront (library built with -DVGG_TILE_TRACE=1 as
-vggsfm_amd/_variants/lib_tile_trace.so):  VGGSFM_AMD_LIB=vggsfm_amd/_variants/lib_tile_trace.so python scripts/debug/tile_trace.py"""
+vggsfm_amd/_variants/lib_tile_trace.so):  VGGSFM_AMD_LIB=vggsfm_amd/_variants/lib_tile_trace.so python scripts/prof/tile_trace.py"""
 import ctypes
 import os
 import sys

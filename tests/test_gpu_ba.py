@@ -238,6 +238,42 @@ def test_ba_launch_variants_agree(S, N, cam, shared):
         L.vgg_ba_tuning(0, -1, 0, 0)
 
 
+@pytest.mark.parametrize("S,N,cam,shared,rf,rk", [(60, 3000, "SIMPLE_RADIAL", True, True, True), (40, 2500, "SIMPLE_PINHOLE", True, True, True),
+                                                  (24, 1500, "SIMPLE_RADIAL", True, True, False), (90, 2500, "SIMPLE_RADIAL", False, False, False),
+                                                  (200, 12000, "SIMPLE_RADIAL", True, True, True)])
+def test_ba_tile_rhs_matches_camera_pass(S, N, cam, shared, rf, rk):
+    """Round 4: with 6 x 6 tile blocks the reduced right-hand side F^T (r - E h) and the shared-intrinsics border come out
+    of the diagonal Schur tile launch (segments x a 3 x 3 per-point block, + per-point sums of the point pass) instead of
+    a second camera-major evaluation of every projection (cam_pass<RHS>).  Same system up to the order of its sums: same
+    LM trajectory as the camera pass (vgg_ba_set_tile_rhs(0)), whatever subset of the intrinsics is refined; the
+    trajectory tests against the oracle run with the default (1)."""
+    sc = make_scene(S, N, cam, shared_camera=shared, seed=41)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=41)
+    opt = BundleAdjustmentOptions()
+    opt.refine_focal_length, opt.refine_extra_params = rf, rk
+    opt.solver_options.max_num_iterations = 10
+    L = _lib.lib()
+
+    def solve():
+        return BA.bundle_adjustment(D(pts0), D(ext0), D(K0), D(sc.tracks), D(sc.mask), None, D(extra0), shared, cam, opt)
+    try:
+        assert L.vgg_ba_set_tile_rhs(0) == 0
+        ref = solve()
+        assert L.vgg_ba_set_tile_rhs(1) == 0
+        a, b = solve(), solve()
+    finally:
+        L.vgg_ba_set_tile_rhs(1)
+    for x, y in zip(a[:4], b[:4]):                       # bit-reproducible
+        assert x is None or torch.equal(x, y)
+    assert a[4]["num_iterations"] == ref[4]["num_iterations"]
+    for ia, ib in zip(a[4]["iterations"], ref[4]["iterations"]):
+        assert ia["successful"] == ib["successful"] and abs(ia["cost"] - ib["cost"]) <= 1e-10 * ib["cost"], (ia, ib)
+        assert abs(ia["radius"] - ib["radius"]) <= 1e-5 * ib["radius"]      # (the radius update amplifies the step quality's last bits)
+    for x, y in zip(a[:4], ref[:4]):
+        if x is not None:
+            np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-8, atol=1e-8)
+
+
 def test_cholesky_flags_indefinite():
     A = np.eye(40)
     A[17, 17] = -1.0

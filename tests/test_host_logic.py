@@ -93,6 +93,12 @@ def _check_views_and_work_list(prob, S, vi, row_ptr, obs_cam):
     seg_first = {int(sg): int(np.nonzero(seg_of == sg)[0][0]) for sg in np.unique(seg_of)}
     seg_mask = {int(sg): sum(1 << (int(c) % BA.GROUP) for c in obs_cam[seg_of == sg]) for sg in np.unique(seg_of)}
     pt_of_obs = np.repeat(np.arange(len(vi)), np.diff(row_ptr))
+    has = np.diff(row_ptr) > 0
+    ncam = int(obs_cam.max()) + 1
+    key = np.where(has, obs_cam[np.minimum(row_ptr[:-1], len(obs_cam) - 1)].astype(np.int64) * ncam
+                   + obs_cam[np.maximum(row_ptr[1:] - 1, 0)], 0)
+    sweep_rank = np.empty(len(vi), np.int64)
+    sweep_rank[np.argsort(key, kind="stable")] = np.arange(len(vi))
     covered = {}
     seen_entries = np.zeros(len(ent), bool)
     pos_of_point = {}
@@ -101,8 +107,11 @@ def _check_views_and_work_list(prob, S, vi, row_ptr, obs_cam):
         assert gI <= gJ and 0 <= j < J and J <= max(1, -(-(te - tb) // BA.MIN_CHUNK))
         # inside a tile: one entry per point; ascending sweep positions from window to window (QUAD_SORT_WINDOW entries), and
         # inside a window grouped by the pattern of 16-row blocks the tile kernel can skip, ascending inside a group
-        pos_t = ent[tb:te, 0].astype(np.int64)
-        assert len(np.unique(pos_t)) == len(pos_t)
+        # (field 0 of an entry = its point -- the diagonal tile launch looks the point's back-substitution block up by it;
+        #  the sweep position of a point = its rank by (first camera, last camera), ties in point order)
+        pt_t = ent[tb:te, 0].astype(np.int64)
+        assert len(np.unique(pt_t)) == len(pt_t)
+        pos_t = sweep_rank[pt_t]
         bd = 6 if prob.intr.shape[0] == 1 else 6 + (2 if prob.camera_model == BA.MODEL_ID["SIMPLE_RADIAL"] else 1)
         W = BA.QUAD_SORT_WINDOW if BA.QUAD_SORT_WINDOW > 0 else 1
         for w0 in range(0, te - tb, W):
@@ -131,7 +140,8 @@ def _check_views_and_work_list(prob, S, vi, row_ptr, obs_cam):
             B = obs_cam[ob:ob + cb]
             assert (A // BA.GROUP == gI).all() and (B // BA.GROUP == gJ).all()
             p = int(pt_of_obs[oa])
-            assert pos_of_point.setdefault(p, int(pos)) == int(pos)
+            assert int(pos) == p                                 # field 0 is the point of both segments
+            pos_of_point[p] = int(sweep_rank[p])
             assert row_ptr[p] <= oa and oa + ca <= row_ptr[p + 1] and row_ptr[p] <= ob and ob + cb <= row_ptr[p + 1]
             for a in A:
                 for bb in B:

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import ref_harness
-from vggsfm_amd.reconstruction import Reconstruction
+from vggsfm_amd.pycolmap_compat import Reconstruction
 from vggsfm_amd.scene import make_scene
 
 

@@ -208,7 +208,7 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     consecutive cameras; an *entry* pairs two segments (gI <= gJ) of the same point; entries are
     sorted by tile (gI, gJ) and, inside a tile, by the sweep position of the point (first camera, last camera); a tile with k entries gets J = ceil(k / `chunk`)
     workgroups ("chunks", off-diagonal tiles first), workgroup j taking the sub-chunks j, j+J, ... of SUB entries (kSub in ba.hip).
-    Returns (chunk_desc (n,6) int32 = gI,gJ,tile_begin,tile_end,j,J ; entries (E,4) int32 = sweep position of the point,
+    Returns (chunk_desc (n,6) int32 = gI,gJ,tile_begin,tile_end,j,J ; entries (E,4) int32 = point index,
     segA, segB, maskA|maskB<<16 of the QUAD (the union over the four consecutive entries, aligned to the tile's begin, that one
     MFMA K-step packs; bit l of a mask <=> camera group*16 + l observes one of the four points) ;
     tile_desc (T,4) int32 = gI,gJ,chunk_begin,chunk_end ; obs_slot (O,) int32 = segment*16 + camera%16 ;
@@ -305,7 +305,9 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     qm = torch.zeros((int(nquad.sum().item()), 4), dtype=torch.long, device=dev)
     qm[quad, upos % 4] = emask
     qm = qm[:, 0] | qm[:, 1] | qm[:, 2] | qm[:, 3]
-    entries = torch.stack([epos, A, B, qm[quad]], 1).to(torch.int32)
+    # (field 0 = the entry's POINT, row of `pts`: the diagonal tile launch fetches the point's back-substitution block by it --
+    #  vgg_ba_set_tile_rhs; the sweep position only orders the list)
+    entries = torch.stack([seg_pt[A], A, B, qm[quad]], 1).to(torch.int32)
     tbatch = ukeys // (2 * nn)
     is_diag = (ukeys % (2 * nn)) >= nn
     ukeys = ukeys % nn

@@ -42,6 +42,9 @@ constexpr int kGroup = 16;       // cameras per Schur tile side
 #ifndef VGG_OFFDIAG_OCC
 #define VGG_OFFDIAG_OCC 3   // wavefronts per SIMD of the off-diagonal Schur kernel (BD = 6): see DESIGN.md section 6
 #endif
+#ifndef VGG_DIAG_OCC
+#define VGG_DIAG_OCC 4      // wavefronts per SIMD of the diagonal Schur kernel (BD = 6)
+#endif
 #ifndef VGG_PP_OCC_SPLIT
 #define VGG_PP_OCC_SPLIT 3   // point_pass without the Y sweep: 158 VGPRs
 #endif
@@ -120,6 +123,11 @@ struct Ws {  // device workspace carve-up (pointers into the caller's buffer)
   double* chol_inv;           // inverse diagonal blocks of the Cholesky factor
   double* tile_part;          // [num_chunks][R][R] partial Schur tiles, R = 16*BDt
   int32_t* batch_flags;       // [8] overlap mode: tile batch b >= 1 has been summed into S2 (raised by a kernel behind it)
+  // reduced right-hand side from the diagonal tiles (tile_rhs, see schur_tile_body): per point Z = [z | y_0 | y_1] (3 x 3,
+  // column-major) with E hs = E G z, E Ms_m = E G y_m; per diagonal chunk the sums over its entries of Y_seg Z (96 x 3);
+  // per point-pass workgroup the shared-intrinsics terms sum_p Wa_p hs_p (KD) and sum_p Wa_p Ms_p^T (KD x KD)
+  double *Zp, *rz_part, *part_Q;
+  int tile_rhs;               // 1: cam_pass<RHS> is not launched, its sums come from the diagonal tile launch + point_pass
   size_t lin_count, sys_count, total_bytes;
 };
 
@@ -182,6 +190,10 @@ static Ws carve(const Dims& d, int max_iters, int num_chunks, int num_segments, 
     w.tile_part = (double*)take(8ull * (size_t)(num_chunks > 0 ? num_chunks : 1) * bdt * bdt * 256);   // R*R, R = 16*bdt
   }
   w.batch_flags = (int32_t*)take(64);
+  w.Zp = (double*)take(8ull * 9 * (d.P > 0 ? d.P : 1));
+  w.rz_part = (double*)take(8ull * (size_t)(num_chunks > 0 ? num_chunks : 1) * kGroup * 6 * 3);
+  w.part_Q = (double*)take(8ull * kMaxWG * 8);
+  w.tile_rhs = 0;
   w.total_bytes = off;
   return w;
 }
@@ -582,10 +594,10 @@ __global__ __launch_bounds__(256) void prep_kernel(DevProblem pb, Ws w, vgg_ba_o
 // measured per LM iteration, point_pass + point_step -- c2 (mean 12.5 observations) 64: 0.112, 32: 0.075, 16: 0.065,
 // 8: 0.059 ms; c3 (mean 50) 64: 0.674, 32: 0.549, 16: 0.499, 8: 0.535 ms; one c4 shard (mean 100) 32: 0.509, 16: 0.544 ms.
 // overrides of the automatic launch choices (vgg_ba_tuning; the environment variables seed them): 0 / -1 = automatic
-struct Tuning { int lpp, longt, cam_wgs, point_wgs; };
+struct Tuning { int lpp, longt, cam_wgs, point_wgs, tile_rhs; };
 static Tuning g_tuning = [] {
   auto env = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
-  return Tuning{env("VGG_LPP", 0), env("VGG_PP_LONGT", -1), env("VGG_CAM_WGS", 0), env("VGG_POINT_WGS", 0)};
+  return Tuning{env("VGG_LPP", 0), env("VGG_PP_LONGT", -1), env("VGG_CAM_WGS", 0), env("VGG_POINT_WGS", 0), env("VGG_TILE_RHS", 1)};
 }();
 static int lanes_per_point(int P, int O) {
   const int forced = g_tuning.lpp;
@@ -622,6 +634,25 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
   const double radius = ctl->radius;
   const int kdsh = d.kdsh;
   double gmax = 0.0;
+  const bool trhs = w.tile_rhs != 0;
+  if (trhs) {
+    // (cam_pass<RHS> is not launched: its other job -- zeroing the reduced system S | rhs for the tile sums and
+    //  assemble_kernel that follow -- is done here, a few 16-byte stores per thread)
+    const size_t me = (size_t)blockIdx.x * 256 + threadIdx.x, nth = (size_t)gridDim.x * 256;
+    double2* z = reinterpret_cast<double2*>(w.sys);
+    for (size_t i = me; i < w.sys_count / 2; i += nth) z[i] = make_double2(0.0, 0.0);
+    if (me == 0 && (w.sys_count & 1)) w.sys[w.sys_count - 1] = 0.0;
+  }
+  // shared-intrinsics terms of the reduced system that cam_pass<RHS> summed per observation (tile_rhs): they are per-POINT
+  // quantities -- sum_i Ji^T E_i hs_p = Wa_p hs_p, sum_i Ji^T E_i Ms_p = Wa_p Ms_p -- added up here, one lane per point
+  // (accumulators in LDS, one row per (wavefront, point slot) owned by that point's first lane: the pass has no registers to
+  //  spare -- six more doubles per lane put the long-track variant on the stack)
+  constexpr int KQ = (KD > 0) ? KD + KD * KD : 1;
+  __shared__ double qs[4][64 / LPP][KQ];
+  if (trhs && KD > 0 && (lane % LPP) == 0) {
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) qs[wave][lane / LPP][i] = 0.0;
+  }
   // The per-observation camera gather is the second of three dependent memory round trips of a point; with the
   // cameras in LDS it is an LDS read.  (The wavefronts are latency bound: SQ_WAIT_ANY 60 %, 2 waves/SIMD.)
   const double* lq = cam_cache;                  // rotation matrices [9C]
@@ -761,6 +792,7 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
     double Ms[3 * (KD ? KD : 1)];
 #pragma unroll
     for (int i = 0; i < 3 * (KD ? KD : 1); ++i) Ms[i] = 0;
+    bool z_written = false;                           // tile_rhs: Z = [z | y_0 | y_1] with hs = G z, Ms_m = G y_m
     if (!pt_c && o1 > o0) {
       double dd[3];
 #pragma unroll
@@ -791,6 +823,13 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
       const double gs0 = s[0] * g[0], gs1 = s[1] * g[1], gs2 = s[2] * g[2];
       const double z0 = i00 * gs0, z1 = i10 * gs0 + i11 * gs1, z2 = i20 * gs0 + i21 * gs1 + i22 * gs2;
       hs[0] = Gm[0] * z0 + Gm[1] * z1 + Gm[2] * z2; hs[1] = Gm[3] * z1 + Gm[4] * z2; hs[2] = Gm[5] * z2;
+      if (trhs && sl == 0) {
+        double* Z = w.Zp + 9 * (size_t)p;
+        Z[0] = z0; Z[1] = z1; Z[2] = z2;
+        if (!(KD > 0 && kdsh)) { Z[3] = 0; Z[4] = 0; Z[5] = 0; Z[6] = 0; Z[7] = 0; Z[8] = 0; }
+        if (KD == 1 && kdsh) { Z[6] = 0; Z[7] = 0; Z[8] = 0; }
+      }
+      z_written = true;
       if (KD > 0 && kdsh) {
 #pragma unroll
         for (int m = 0; m < KD; ++m) {
@@ -799,6 +838,17 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
           const double w0 = sa * s[0] * Wa[m * 3], w1 = sa * s[1] * Wa[m * 3 + 1], w2 = sa * s[2] * Wa[m * 3 + 2];
           const double y0 = i00 * w0, y1 = i10 * w0 + i11 * w1, y2 = i20 * w0 + i21 * w1 + i22 * w2;
           Ms[m * 3] = Gm[0] * y0 + Gm[1] * y1 + Gm[2] * y2; Ms[m * 3 + 1] = Gm[3] * y1 + Gm[4] * y2; Ms[m * 3 + 2] = Gm[5] * y2;
+          if (trhs && sl == 0) { double* Z = w.Zp + 9 * (size_t)p + 3 + 3 * m; Z[0] = y0; Z[1] = y1; Z[2] = y2; }
+        }
+        if (trhs && sl == 0) {
+          double* q = qs[wave][sub];
+#pragma unroll
+          for (int i = 0; i < KD; ++i) {
+            q[i] += Wa[i * 3] * hs[0] + Wa[i * 3 + 1] * hs[1] + Wa[i * 3 + 2] * hs[2];
+#pragma unroll
+            for (int j = 0; j < KD; ++j)
+              q[KD + i * KD + j] += Wa[i * 3] * Ms[j * 3] + Wa[i * 3 + 1] * Ms[j * 3 + 1] + Wa[i * 3 + 2] * Ms[j * 3 + 2];
+          }
         }
       }
       gmax = fmax(gmax, fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2]))));
@@ -919,12 +969,25 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
 #pragma unroll
         for (int i = 0; i < 3 * KD; ++i) w.Ms[(size_t)p * 3 * kdsh + i] = Ms[i];
       }
+      if (trhs && !z_written) {                       // constant / unobserved point: no step, no contribution
+#pragma unroll
+        for (int i = 0; i < 9; ++i) w.Zp[9 * (size_t)p + i] = 0.0;
+      }
     }
   }
   gmax = wave_max(gmax);
   if (lane == 0) wmax[wave] = gmax;
   __syncthreads();
   if (threadIdx.x == 0) w.part_B[blockIdx.x] = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
+  if (trhs && KD > 0) {
+    __syncthreads();                                  // (every slot's owner lane has finished its points)
+    if (threadIdx.x < KQ) {
+      double v = 0.0;                                 // fixed order: wavefront, then point slot
+      for (int wv = 0; wv < 4; ++wv)
+        for (int sb = 0; sb < 64 / LPP; ++sb) v += qs[wv][sb][threadIdx.x];
+      w.part_Q[8 * blockIdx.x + threadIdx.x] = v;
+    }
+  }
 }
 
 // start-of-iteration checks (Ceres FinalizeIterationAndCheckIfMinimizerCanContinue)
@@ -1058,10 +1121,29 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
   const int sseg = tid / TPS, l32 = tid % TPS;
   const bool stager = !(CY && DIAG) || sseg < 4;  // (wave-uniform)
   const int se = DIAG ? (sseg & 3) : (sseg >> 1), sside = DIAG ? 0 : (sseg & 1);
+  // tile_rhs (compressed diagonal tiles): every observation sits in exactly one segment and every segment is exactly one
+  // diagonal entry, so  sum over the entries of a diagonal tile of  Y_seg (96 x 3) Z_p (3 x 3)  is, per camera, what
+  // cam_pass<RHS> summed per observation: F^T E hs (column 0: Z = [z | y_0 | y_1], E hs = E G z) and F^T E Ms_m (columns
+  // 1, 2) -- from operands that are in LDS anyway.  The wavefronts 2, 3 have no segment to stage here (four segments, 32
+  // lanes each): they are the HELPERS -- they fetch the Z of the batch's four points through the same two-stage prefetch
+  // (entry -> point index, point index -> Z: field 0 of an entry is the point) into a 96-double LDS image per buffer and,
+  // while the other two wavefronts write the next batch's segments to LDS, add the products of their row (a lane per tile
+  // row) for the four entries of the batch that has just been multiplied.  The two roles are two instantiations of the loop
+  // (`run` below): the stagers carry the staging registers, the helpers the three sums, both within the 128 registers of four
+  // wavefronts per SIMD.  Scales and constant-parameter masks are applied by assemble_kernel, like tile_reduce_kernel does
+  // for the tile sums.
+  constexpr bool TR = CY && DIAG;
+  const bool trhs = TR && w.tile_rhs != 0;
+  constexpr int ZS = 12;                              // doubles per entry of the Z image (9 used; 16-byte aligned rows)
+  double* zs = ops + 2 * (DIAG ? 1 : 2) * 4 * SEG;    // [buffer][entry][col][k]
+  auto run = [&](auto role) __attribute__((always_inline)) {
+  constexpr bool HELPER = decltype(role)::value;      // (only with TR: wavefronts 2, 3)
+  const bool zthread = HELPER && trhs && l32 < 9;
+  double racc[3] = {0.0, 0.0, 0.0};
   // The segment index of a batch is loaded unconditionally (clamped entry) and only CONSUMED one iteration later;
   // entries past the end of the list are redirected to the all-zero segment behind the last real one.  Nothing in
   // the current iteration depends on the loaded value, so no s_waitcnt sits between the prefetch and the MFMAs.
-  const int32_t* seg_field = entries + 1 + sside;               // entries[e] = (point, segA, segB, masks)
+  const int32_t* seg_field = entries + (HELPER ? 0 : 1 + sside);   // entries[e] = (point, segA, segB, masks)
   auto load_seg_index = [&](int eb) -> int { return seg_field[4 * (size_t)min(eb + se, e1 - 1)]; };
   auto seg_valid = [&](int eb) -> bool { return eb + se < e1; };
   // two staging register sets: the loads of batch b + 2 are issued while batch b is multiplied and batch b + 1 (loaded an
@@ -1074,10 +1156,14 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
   const int cy_row16 = (cy_top ? cy_r0 : cy_r0 + 4) ^ cy_sw, cy_row8 = (cy_top ? cy_r0 + 2 : cy_r0 + 3) ^ cy_sw;
   auto issue_loads = [&](double2 (&sv)[NV], int seg_index, bool valid) __attribute__((always_inline)) {
     if constexpr (CY) {
-      if (stager) {
-        const double2* src = reinterpret_cast<const double2*>(w.Y) + (size_t)(valid ? seg_index : zero_seg) * (CSEG / 2) + 3 * l32;
+      if constexpr (!HELPER) {
+        if (stager) {
+          const double2* src = reinterpret_cast<const double2*>(w.Y) + (size_t)(valid ? seg_index : zero_seg) * (CSEG / 2) + 3 * l32;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) sv[i] = src[i];
+          for (int i = 0; i < NV; ++i) sv[i] = src[i];
+        }
+      } else {
+        if (zthread) sv[0].x = valid ? w.Zp[9 * (size_t)seg_index + l32] : 0.0;   // (seg_index = the entry's point here)
       }
     } else {
       const double2* src = reinterpret_cast<const double2*>(w.Y) + (size_t)(valid ? seg_index : zero_seg) * V;
@@ -1086,7 +1172,9 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
     }
   };
   auto write_lds = [&](const double2 (&sv)[NV], int buf) __attribute__((always_inline)) {
-    if constexpr (CY) {
+    if constexpr (CY && HELPER) {
+      if (zthread) zs[(buf * 4 + se) * ZS + l32] = sv[0].x;
+    } else if constexpr (CY) {
       if (stager) {
         // odd lane:  mine = (N20 N21 N22, 2a0 2a1 2a2), other = (N00 N01 N02, N10 N11 N12) -> rows 0..2 = (2 a) x N[:, k]:
         //            16 bytes at row 0, 8 at row 2
@@ -1165,6 +1253,25 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
       __builtin_amdgcn_s_setprio(0);
 #endif
       mfma_batch(buf, qmask);
+      if constexpr (TR && HELPER) {
+        if (trhs) {
+          const int rrow = tid & 127;                 // (wavefront 2: tile rows 0..63, wavefront 3: 64..95)
+          if (rrow < R) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const double* zz = zs + (buf * 4 + e) * ZS;
+              const double2* z2 = reinterpret_cast<const double2*>(zz);
+              const double2 za = z2[0], zb = z2[1], zc = z2[2], zd = z2[3];   // z0 z1 | z2 y00 | y01 y02 | y10 y11
+              const double ze = zz[8];                                          // y12
+              const double* op = ops + (size_t)(buf * 4 + e) * SEG + (rrow ^ ((e & 1) * SWZ));
+              const double v0 = op[0], v1 = op[R], v2 = op[2 * R];
+              racc[0] += v0 * za.x + v1 * za.y + v2 * zb.x;
+              racc[1] += v0 * zb.y + v1 * zc.x + v2 * zc.y;
+              racc[2] += v0 * zd.x + v1 * zd.y + v2 * ze;
+            }
+          }
+        }
+      }
 #if VGG_TILE_PRIO == 1
       __builtin_amdgcn_s_setprio(0);
 #elif VGG_TILE_PRIO == 2
@@ -1324,14 +1431,29 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
 #pragma unroll
     for (int t = 0; t < PER; ++t)
       if (t < nmine) store_subtile(rbs[t], cbs[t], acc[t / NH][t % NH]);
+    if constexpr (TR && HELPER) {
+      if (trhs) {                                     // the chunk's 96 x 3 block, a lane per tile row
+        const int rrow = tid & 127;
+        if (rrow < R) {
+          double* dst = w.rz_part + ((size_t)chunk * R + rrow) * 3;
+          dst[0] = racc[0]; dst[1] = racc[1]; dst[2] = racc[2];
+        }
+      }
+    }
+  }
+  };   // run
+  if constexpr (TR) {
+    if (wave < 2) run(std::false_type{}); else run(std::true_type{});
+  } else {
+    run(std::false_type{});
   }
 }
 
 // the two launches of a tile batch (off-diagonal tiles, diagonal tiles) ...
 template <int BD, bool DIAG>
-__global__ __launch_bounds__(256, (BD == 6 ? (DIAG ? 4 : VGG_OFFDIAG_OCC) : 2)) void schur_tile_kernel(Ws w, const int32_t* __restrict__ chunk_desc,
+__global__ __launch_bounds__(256, (BD == 6 ? (DIAG ? VGG_DIAG_OCC : VGG_OFFDIAG_OCC) : 2)) void schur_tile_kernel(Ws w, const int32_t* __restrict__ chunk_desc,
                                                          const int32_t* __restrict__ entries, int chunk0, int zero_seg) {
-  __shared__ __attribute__((aligned(16))) double ops[2 * (DIAG ? 1 : 2) * 4 * kGroup * BD * 3];
+  __shared__ __attribute__((aligned(16))) double ops[2 * (DIAG ? 1 : 2) * 4 * kGroup * BD * 3 + ((DIAG && BD == 6) ? 96 : 0)];
   if (w.ctl->done) return;
   const int chunk = chunk0 + blockIdx.x;
   schur_tile_body<BD, DIAG>(w, chunk_desc, entries, chunk, zero_seg, ops);
@@ -1396,66 +1518,119 @@ __global__ __launch_bounds__(256) void tile_reduce_kernel(Ws w, int n_red, int C
 
 // diagonal blocks, camera/intrinsics coupling, damping, right-hand side.  One workgroup (64) per camera,
 // plus one extra for the shared-intrinsics block.  Only rank 0 adds the terms that were already summed
-// over ranks (U, damping); the per-rank systems are then all-reduced.
+// over ranks (U, g, damping); the per-rank systems are then all-reduced.
+// tile_rhs: the pose rows of T_c = F^T [r - E hs | -E Ms] are  [g_c | 0] - (sum over the chunks of the camera's diagonal
+// tile, in order, of rz_part)  -- g_c from the linearisation pass, rz_part from schur_tile_body -- and the intrinsics rows
+// of the shared block come from point_pass' per-workgroup sums part_Q; T and cam_pass<RHS> are not used.
 template <int KD>
-__global__ __launch_bounds__(64) void assemble_kernel(DevProblem pb, Ws w) {
+__global__ __launch_bounds__(64) void assemble_kernel(DevProblem pb, Ws w, const int32_t* __restrict__ tile_desc, int num_tiles,
+                                                      int point_parts) {
   constexpr int BD = 6 + KD;
+  __shared__ double rz[6][3];
   if (w.ctl->done) return;
   const int global_terms = (w.ctl->rank == 0);
   const Dims& d = pb.d;
   const int n = d.n_red, kdsh = d.kdsh, tw = 1 + kdsh;
   const int c = blockIdx.x, tid = threadIdx.x;
+  const bool trhs = w.tile_rhs != 0;
   if (c < d.C) {
     const double* U = w.U + (size_t)c * BD * BD;
     const double* T = w.T + (size_t)c * BD * tw;
     const int ia = 6 * d.C + (d.shared ? 0 : KD * c);
+    if (trhs) {
+      // chunks of the diagonal tile of this camera's group (tiles are few: every thread scans a stride of the table)
+      int c0 = 0, c1 = 0;
+      const int g = c / kGroup;
+      for (int t = tid; t < num_tiles; t += 64)
+        if (tile_desc[4 * t] == g && tile_desc[4 * t + 1] == g) { c0 = tile_desc[4 * t + 2]; c1 = tile_desc[4 * t + 3]; }
+      c0 = wave_sum_i(c0); c1 = wave_sum_i(c1);           // (one thread found the tile, the others hold 0)
+      if (tid < 18) {
+        const int i = tid / 3, col = tid - 3 * i;
+        const double* src = w.rz_part + ((size_t)(c % kGroup) * 6 + i) * 3 + col;
+        double s0 = 0.0, s1 = 0.0;                     // (fixed order: even chunks into s0, odd ones into s1)
+        int ch = c0;
+        for (; ch + 1 < c1; ch += 2) { s0 += src[(size_t)ch * kGroup * 18]; s1 += src[(size_t)(ch + 1) * kGroup * 18]; }
+        if (ch < c1) s0 += src[(size_t)ch * kGroup * 18];
+        rz[i][col] = s0 + s1;
+      }
+      __syncthreads();
+    }
+    // T_c as cam_pass<RHS> defines it, whichever way it was formed (pose rows; intrinsics rows only without tile_rhs)
+    // (the compressed factors behind rz carry no constant-parameter masks -- cam_pass<RHS> evaluated MASKED Jacobians, so a
+    //  constant pose / translation component contributed exact zeros: the mask acts on the row here, like in tile_reduce)
+    auto Tc = [&](int i, int m) -> double {
+      if (!trhs) return T[i * tw + m];
+      if (!w.active[6 * c + i]) return 0.0;
+      return (m == 0 ? (global_terms ? w.g[(size_t)c * BD + i] : 0.0) : 0.0) - rz[i][m];
+    };
     // BD x BD block (lower part), rows/cols mapped to reduced indices
     for (int e = tid; e < BD * BD; e += 64) {
       const int i = e / BD, j = e - i * BD;
       const int ri = (i < 6) ? 6 * c + i : ia + (i - 6), cj = (j < 6) ? 6 * c + j : ia + (j - 6);
       if (cj > ri) continue;
       if (d.shared && i >= 6 && j >= 6) continue;           // intr-intr of the shared block: extra workgroup
+      if (trhs && !d.shared && (i >= 6 || j >= 6)) continue;   // (tile_rhs without shared intrinsics: none are refined)
       double v = 0.0;
       if (global_terms) {
         v = w.scale_c[ri] * w.scale_c[cj] * U[i * BD + j];
         if (ri == cj) v += w.dsq_c[ri];
       }
-      if (d.shared && i >= 6) v += w.scale_c[cj] * T[j * tw + 1 + (i - 6)];   // -F_pose^T E M
+      if (d.shared && i >= 6) v += w.scale_c[cj] * Tc(j, 1 + (i - 6));   // -F_pose^T E M
       w.S[(size_t)ri * n + cj] += v;
     }
-    if (tid < 6) w.rhs[6 * c + tid] += w.scale_c[6 * c + tid] * T[tid * tw];
-    if (!d.shared && tid >= 6 && tid < BD) w.rhs[ia + tid - 6] += w.scale_c[ia + tid - 6] * T[tid * tw];
-  } else if (d.shared && KD > 0) {
-    // shared-intrinsics block: sum the per-camera parts (one wavefront, lanes stride over cameras)
-    const int ia = 6 * d.C;
-    constexpr int NS = (KD > 0) ? KD * KD + KD : 1;
-    double sums[NS];
-#pragma unroll
-    for (int i = 0; i < NS; ++i) sums[i] = 0.0;
-    for (int cc = tid; cc < d.C; cc += 64) {
-#pragma unroll
-      for (int i = 0; i < KD; ++i) {
-#pragma unroll
-        for (int j = 0; j <= i; ++j) {
-          double v = w.scale_c[ia + i] * w.T[((size_t)cc * BD + 6 + i) * tw + 1 + j];
-          if (global_terms) v += w.scale_c[ia + i] * w.scale_c[ia + j] * w.U[(size_t)cc * BD * BD + (6 + i) * BD + 6 + j];
-          sums[i * KD + j] += v;
-        }
-        sums[KD * KD + i] += w.T[((size_t)cc * BD + 6 + i) * tw];
-      }
+    if (tid < 6) w.rhs[6 * c + tid] += w.scale_c[6 * c + tid] * Tc(tid, 0);
+    if (!trhs && !d.shared && tid >= 6 && tid < BD) w.rhs[ia + tid - 6] += w.scale_c[ia + tid - 6] * T[tid * tw];
+  } else {
+    if (trhs) {                                    // (rides along: max of the point passes' per-workgroup gradient norms,
+      double m = 0;                                //  what cam_reduce_kernel<KD, 1> did)
+      for (int i = tid; i < point_parts; i += 64) m = fmax(m, w.part_B[i]);
+      m = wave_max(m);
+      if (tid == 0) w.gmax_pts[0] = m;
     }
+    if (d.shared && KD > 0) {
+      // shared-intrinsics block: sum the per-camera parts (one wavefront, lanes stride over cameras)
+      const int ia = 6 * d.C;
+      constexpr int NS = (KD > 0) ? KD * KD + KD : 1;
+      double sums[NS];
 #pragma unroll
-    for (int i = 0; i < NS; ++i) sums[i] = wave_sum(sums[i]);
-    if (tid == 0) {
+      for (int i = 0; i < NS; ++i) sums[i] = 0.0;
+      for (int cc = tid; cc < d.C; cc += 64) {
 #pragma unroll
-      for (int i = 0; i < KD; ++i) {
+        for (int i = 0; i < KD; ++i) {
 #pragma unroll
-        for (int j = 0; j <= i; ++j) {
-          double v = sums[i * KD + j];
-          if (global_terms && i == j) v += w.dsq_c[ia + i];
-          w.S[(size_t)(ia + i) * n + ia + j] += v;
+          for (int j = 0; j <= i; ++j) {
+            double v = trhs ? 0.0 : w.scale_c[ia + i] * w.T[((size_t)cc * BD + 6 + i) * tw + 1 + j];
+            if (global_terms) v += w.scale_c[ia + i] * w.scale_c[ia + j] * w.U[(size_t)cc * BD * BD + (6 + i) * BD + 6 + j];
+            sums[i * KD + j] += v;
+          }
+          sums[KD * KD + i] += trhs ? (global_terms ? w.g[(size_t)cc * BD + 6 + i] : 0.0) : w.T[((size_t)cc * BD + 6 + i) * tw];
         }
-        w.rhs[ia + i] += w.scale_c[ia + i] * sums[KD * KD + i];
+      }
+      if (trhs) {
+        // - sum_p Wa_p Ms_p^T (scaled like the T terms above) and - sum_p Wa_p hs_p, workgroup partials in launch order
+        for (int b = tid; b < point_parts; b += 64) {
+          const double* q = w.part_Q + 8 * (size_t)b;
+#pragma unroll
+          for (int i = 0; i < KD; ++i) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j) sums[i * KD + j] -= w.scale_c[ia + i] * q[KD + i * KD + j];
+            sums[KD * KD + i] -= q[i];
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NS; ++i) sums[i] = wave_sum(sums[i]);
+      if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < KD; ++i) {
+#pragma unroll
+          for (int j = 0; j <= i; ++j) {
+            double v = sums[i * KD + j];
+            if (global_terms && i == j) v += w.dsq_c[ia + i];
+            w.S[(size_t)(ia + i) * n + ia + j] += v;
+          }
+          w.rhs[ia + i] += w.scale_c[ia + i] * sums[KD * KD + i];
+        }
       }
     }
   }
@@ -1907,7 +2082,7 @@ static void phase_schur(const Launch& L) {
       else launch(std::integral_constant<int, 64>{});
     }
   }
-  {
+  if (!L.w.tile_rhs) {
     ProfScope ps(kProfCamRhs, L.st);
     const int split = cam_split_for(d.C, d.O);
     cam_pass_kernel<KD, 1><<<dim3(d.C, split), 256, 0, L.st>>>(L.dp, L.w);
@@ -1923,7 +2098,7 @@ static void phase_schur(const Launch& L) {
       launch_schur_batches<KD>(L, 0, L.num_batches, L.st, L.w.S, nullptr);
     }
   }
-  assemble_kernel<KD><<<d.C + 1, 64, 0, L.st>>>(L.dp, L.w);
+  assemble_kernel<KD><<<d.C + 1, 64, 0, L.st>>>(L.dp, L.w, L.tile_desc, L.num_tiles, L.wgB);
 }
 
 template <int KD>
@@ -2025,6 +2200,9 @@ static int make_launch(const vgg_ba_problem* pb, const vgg_ba_options* opt, void
     if (prev_c != pb->num_chunks || prev_t != pb->num_tiles) return VGG_ERR_INVALID_ARGUMENT;
   }
   L->tile_desc = pb->tile_desc; L->num_tiles = pb->num_tiles;
+  // reduced right-hand side from the diagonal tile launch instead of cam_pass<RHS>: compressed 6 x 6 tile blocks (shared or
+  // constant intrinsics), one tile batch (the overlap mode needs the right-hand side before its later batches have run)
+  L->w.tile_rhs = (g_tuning.tile_rhs && (L->d.shared || L->d.kd == 0) && pb->num_chunks > 0 && pb->num_tile_batches == 1) ? 1 : 0;
   L->cam_q = pb->cam_q; L->cam_t = pb->cam_t; L->intr = pb->intr; L->pts = pb->pts;
   return VGG_OK;
 }
@@ -2081,7 +2259,12 @@ int vgg_ba_tuning(int lanes_per_point, int long_tracks, int cam_workgroups, int 
   if (!(lanes_per_point == 0 || lanes_per_point == 8 || lanes_per_point == 16 || lanes_per_point == 32 || lanes_per_point == 64))
     return VGG_ERR_INVALID_ARGUMENT;
   vgg::g_tuning = vgg::Tuning{lanes_per_point, long_tracks < 0 ? -1 : (long_tracks ? 1 : 0), cam_workgroups > 0 ? cam_workgroups : 0,
-                              point_workgroups > 0 ? point_workgroups : 0};
+                              point_workgroups > 0 ? point_workgroups : 0, vgg::g_tuning.tile_rhs};
+  return VGG_OK;
+}
+
+int vgg_ba_set_tile_rhs(int enable) {
+  vgg::g_tuning.tile_rhs = enable ? 1 : 0;
   return VGG_OK;
 }
 

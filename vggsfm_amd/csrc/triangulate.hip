@@ -87,6 +87,115 @@ __device__ __forceinline__ void smallest_eigvec4(const Sym4& m, double* v) {
   for (int k = 0; k < 4; ++k) v[k] = (best == 0) ? V[k][0] : (best == 1) ? V[k][1] : (best == 2) ? V[k][2] : V[k][3];
 }
 
+#ifndef VGG_TRI_EIG
+#define VGG_TRI_EIG 1        // 1 = shifted inverse iteration (Jacobi only where it does not converge), 0 = cyclic Jacobi always
+#endif
+#ifndef VGG_TRI_FAST_ERR
+#define VGG_TRI_FAST_ERR 1   // 1 = one reciprocal per view instead of three divisions, series for acos next to 1
+#endif
+#ifndef VGG_TRI_OCC
+#define VGG_TRI_OCC 2        // wavefronts per SIMD the kernel is compiled for (register budget 512 / VGG_TRI_OCC)
+#endif
+
+// The DLT matrices are positive semi-definite with a well separated smallest eigenvalue whenever the hypothesis is worth
+// anything (two views: (parallax / noise)^2; more views: better), so the wanted eigenvector is what inverse iteration
+// converges to, at a rate of lambda_1 / lambda_2 per step, from a generic start.  A + mu I = L D L^T with mu = 2^-44 trace
+// (far below lambda_2, above the rounding errors of the factorisation: every pivot stays positive although lambda_1 may be
+// 0 -- two rays that meet exactly); one factorisation (four divisions), then ~50 instructions per step against ~4000 for
+// the twelve-sweep cyclic Jacobi, which stays as the last resort of the lanes that have not settled to 1e-14 (below:
+// shift refinement first; then near-degenerate hypotheses -- no parallax at all -- or non-finite input).
+// Same eigenvector to ~1e-15; the reference's LAPACK call and the Jacobi differ from each other by as much.
+// Lanes that have not settled after the first kInvIt steps (a few per thousand: pairs that involve an outlier or a view the
+// track is not visible in -- lambda_1 / lambda_2 of order one) move the shift up to just below lambda_1: with rho = x^T A x
+// and r = A x - rho x, an eigenvalue lies within |r| of rho (and it is the smallest once x is dominated by its eigenvector),
+// so A - (rho - 1.01 |r| - mu) I is still positive definite and the rate becomes ~2 |r| / (lambda_2 - lambda_1): superlinear.
+// Up to kInvRounds factorisations; what is still moving after that (lambda_1 = lambda_2 to rounding: no parallax at all)
+// goes to the Jacobi.  `live` = the lane's result is used (a dead lane must not send its wavefront into the fallback).
+constexpr int kInvIt = 6, kInvRounds = 6;
+__device__ __forceinline__ bool smallest_eigvec4_invit(const Sym4& m, double* v, bool live) {
+  const double tr = m.a[0] + m.a[4] + m.a[7] + m.a[9];
+  bool ok = (tr > 0.0) && (tr <= 1.7976931348623157e308);
+  const double mu = ok ? tr * 5.684341886080802e-14 : 1.0;
+  double sig = -mu;                                  // factor A - sig I
+  double x0 = 0.3, x1 = 0.4, x2 = 0.5, x3 = 0.7071067811865476;
+  bool conv = false;
+#pragma unroll 1
+  for (int round = 0; round < kInvRounds; ++round) {
+    // L D L^T of A - sig I (unit lower L: l10 l20 l30 l21 l31 l32; reciprocal pivots r0..r3)
+    const double d0 = m.a[0] - sig, r0 = 1.0 / d0;
+    const double l10 = m.a[1] * r0, l20 = m.a[2] * r0, l30 = m.a[3] * r0;
+    const double d1 = (m.a[4] - sig) - l10 * m.a[1], r1 = 1.0 / d1;
+    const double u21 = m.a[5] - l20 * m.a[1], u31 = m.a[6] - l30 * m.a[1];
+    const double l21 = u21 * r1, l31 = u31 * r1;
+    const double d2 = ((m.a[7] - sig) - l20 * m.a[2]) - l21 * u21, r2 = 1.0 / d2;
+    const double u32 = (m.a[8] - l30 * m.a[2]) - l31 * u21;
+    const double l32 = u32 * r2;
+    const double d3 = (((m.a[9] - sig) - l30 * m.a[3]) - l31 * u31) - l32 * u32, r3 = 1.0 / d3;
+    ok = ok && (d0 > 0.0) && (d1 > 0.0) && (d2 > 0.0) && (d3 > 0.0);
+#pragma unroll 1
+    for (int it = 0; it < kInvIt; ++it) {
+      // L w = x;  z = D^-1 w;  L^T y = z
+      const double w0 = x0, w1 = x1 - l10 * w0, w2 = (x2 - l20 * w0) - l21 * w1, w3 = ((x3 - l30 * w0) - l31 * w1) - l32 * w2;
+      const double y3 = w3 * r3, y2 = w2 * r2 - l32 * y3, y1 = (w1 * r1 - l21 * y2) - l31 * y3,
+                   y0 = ((w0 * r0 - l10 * y1) - l20 * y2) - l30 * y3;
+      const double n2 = (y0 * y0 + y1 * y1) + (y2 * y2 + y3 * y3);
+      double rn = 1.0 / sqrt(n2);
+      if (x0 * y0 + x1 * y1 + x2 * y2 + x3 * y3 < 0.0) rn = -rn;     // (successive iterates point the same way)
+      const double n0 = y0 * rn, n1 = y1 * rn, nn2 = y2 * rn, n3 = y3 * rn;
+      const double dlt = fmax(fmax(fabs(n0 - x0), fabs(n1 - x1)), fmax(fabs(nn2 - x2), fabs(n3 - x3)));
+      x0 = n0; x1 = n1; x2 = nn2; x3 = n3;
+      conv = dlt <= 1.0e-14;                          // (NaN compares false: such a lane ends in the fallback)
+      if (__all(conv || !ok || !live)) break;
+    }
+    if (__all(conv || !ok || !live)) break;
+    // shift of the next round for the lanes that are still moving (the others keep theirs: their factorisation is repeated
+    // with the same numbers and their iterate stays where it is)
+    const double a0 = m.a[0] * x0 + m.a[1] * x1 + m.a[2] * x2 + m.a[3] * x3, a1 = m.a[1] * x0 + m.a[4] * x1 + m.a[5] * x2 + m.a[6] * x3,
+                 a2 = m.a[2] * x0 + m.a[5] * x1 + m.a[7] * x2 + m.a[8] * x3, a3 = m.a[3] * x0 + m.a[6] * x1 + m.a[8] * x2 + m.a[9] * x3;
+    const double rho = (x0 * a0 + x1 * a1) + (x2 * a2 + x3 * a3);
+    const double q0 = a0 - rho * x0, q1 = a1 - rho * x1, q2 = a2 - rho * x2, q3 = a3 - rho * x3;
+    const double rnorm = sqrt((q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3));
+    const double cand = (rho - 1.01 * rnorm) - mu;
+    if (!conv && cand > sig) sig = cand;
+  }
+  v[0] = x0; v[1] = x1; v[2] = x2; v[3] = x3;
+  return (ok && conv) || !live;
+}
+
+#ifdef VGG_TRI_STATS
+__device__ unsigned long long g_tri_stats[4];       // measurement builds: eigen-solves, fallbacks, waves with a fallback
+#endif
+__device__ __forceinline__ void smallest_eigvec4_fast(const Sym4& m, double* v, bool live) {
+#if VGG_TRI_EIG
+  const bool done = smallest_eigvec4_invit(m, v, live);
+#ifdef VGG_TRI_STATS
+  atomicAdd(&g_tri_stats[0], 1ull);
+  if (!done) atomicAdd(&g_tri_stats[1], 1ull);
+  if (__any(!done) && (threadIdx.x & 63) == 0) atomicAdd(&g_tri_stats[2], 1ull);
+#endif
+  // (the last resort: ~5 lanes per million at configs[1] / [2] -- 96 of 23 M, 544 of 115 M solves with -DVGG_TRI_STATS -- whose
+  //  two smallest eigenvalues agree to rounding.  Dropping it is worth 0.2 ms of 18 at configs[2] and changed ONE mask bit in
+  //  4.9 million there (such a hypothesis can still pass the triangulation-angle test): kept, so that the masks are what the
+  //  Jacobi-only kernel of rounds 1-3 produced, bit for bit)
+  if (!done) smallest_eigvec4(m, v);
+#else
+  smallest_eigvec4(m, v);
+#endif
+}
+
+// acos for the candidate inliers, whose cosine is within ~1e-3 of 1: acos(1 - u) = sqrt(2u) (1 + u/12 + 3u^2/160 + 5u^3/896
+// + 35u^4/18432 + O(u^5)); u = 1 - c is exact there (Sterbenz), the truncation error at u = 1e-3 is 7e-19.
+__device__ __forceinline__ double acos_near_one(double c) {
+#if VGG_TRI_FAST_ERR
+  const double u = 1.0 - c;
+  if (u > 1.0e-3) return acos(c);
+  const double p = 1.0 + u * (1.0 / 12.0 + u * (3.0 / 160.0 + u * (5.0 / 896.0 + u * (35.0 / 18432.0))));
+  return sqrt(u + u) * p;
+#else
+  return acos(c);
+#endif
+}
+
 __device__ __forceinline__ double tri_angle_deg2(double r1, double r2, double b) {
   // triangulation_helpers.py:503-519: law of cosines on (norm)^2 values, min(theta, pi - theta), degrees
   double den = 2.0 * sqrt(r1 * r2);
@@ -127,11 +236,18 @@ __device__ __forceinline__ double view_error(const double* __restrict__ P, const
   const double y2 = P[8] * X0 + P[9] * X1 + P[10] * X2 + P[11];
   depth = y2;
   const double n = fmax(sqrt(y0 * y0 + y1 * y1 + y2 * y2), 1e-12);
+#if VGG_TRI_FAST_ERR
+  // one reciprocal instead of the reference's three divisions: the cosine moves by <= 1 ulp, the angle of a candidate inlier
+  // by ~3e-15 rad -- a decision changes only where |error - threshold| is below that (the goldens compare every mask bit)
+  const double rn = 1.0 / n;
+  double c = (tab[0] * (y0 * rn) + tab[1] * (y1 * rn)) + tab[2] * (y2 * rn);
+#else
   double c = (tab[0] * (y0 / n) + tab[1] * (y1 / n)) + tab[2] * (y2 / n);
+#endif
   is_nan = (c != c);
   c = fmin(fmax(c, -1.0), 1.0);
   if (!(c >= cos_gate)) return 4.0;             // cannot be an inlier (also NaN): skip acos
-  return acos(c);
+  return acos_near_one(c);
 }
 
 // "any pair of the S cameras subtends >= thr degrees at X" for the lanes with `live`; wave-uniform loop
@@ -179,6 +295,9 @@ __device__ __forceinline__ Cand eval_views(const double* __restrict__ ext, const
   double sum = 0.0;
   bool poisoned = false, behind = false;
   if (any_behind) {
+    // (four views per trip: their scalar loads go out together and are waited for once -- one view per trip is a chain of
+    //  load latencies, 200 of them per hypothesis at configs[2])
+#pragma unroll 4
     for (int s = 0; s < ((VGG_TRI_ABLATE & 2) ? 0 : S); ++s) {
       const double* P = ext + 12 * s;
       const double y2 = P[8] * X0 + P[9] * X1 + P[10] * X2 + P[11];
@@ -186,7 +305,11 @@ __device__ __forceinline__ Cand eval_views(const double* __restrict__ ext, const
     }
   }
   for (int k = 0; k < ((VGG_TRI_ABLATE & 2) ? 0 : nv); ++k) {
-    const int s = vlist[k];
+    // (the view index is the same in every lane -- it comes out of LDS, which the compiler cannot know: as a scalar the
+    //  projection matrix is fetched by scalar loads into scalar registers instead of 12 vector loads into 24 VGPRs.
+    //  A hand-written two-stage pipeline of this loop -- index two views ahead, matrix and ray one ahead -- was SLOWER,
+    //  21.9 against 19.2 ms at configs[2]: the copies between the stages cost more than the latency they hide)
+    const int s = __builtin_amdgcn_readfirstlane(vlist[k]);
     const double* t = tab + s * kTab;
     bool isn;
     double depth;
@@ -245,7 +368,9 @@ __device__ __forceinline__ Cand eval_views_grouped(const double* __restrict__ ex
     Sym4 mv;
     if (ACC) view_dlt_matrix_r(ext + 12 * sc, t[0], t[1], t[2], mv);
     const unsigned long long inl_mask = __ballot(inl);
-#pragma unroll
+    // (not unrolled: six copies of the eleven exchanges were the register peak of the whole kernel -- 189 VGPRs with one
+    //  hypothesis per lane, 168 without this block)
+#pragma unroll 1
     for (int k = 0; k < kGV; ++k) {
       // (lanes behind the last group -- 60..63 -- belong to no hypothesis: their source lane is clamped into the wavefront
       //  and they never count; their results are discarded by the caller)
@@ -274,16 +399,15 @@ __device__ __forceinline__ Cand eval_views_grouped(const double* __restrict__ ex
 }
 
 template <int HJ>
-__global__ __launch_bounds__(64, 2) void triangulate_kernel(   // (two wavefronts per SIMD: <= 256 registers)
-   
+__global__ __launch_bounds__(64, VGG_TRI_OCC) void triangulate_kernel(   // (round 4: the RANSAC points stay in registers and
+    // travel by shuffles -- ~10 KB of LDS per wavefront at 200 views instead of 18; the registers still allow two per SIMD)
     const double* __restrict__ ext, const double* __restrict__ tn, const uint8_t* __restrict__ ivc,
     const int32_t* __restrict__ pairs_all, int S, int N, int H, int lo1, int lo2, double max_rad, double min_tri_deg,
     const double* __restrict__ thres_all, int chunk_size, double* __restrict__ out_pts, int64_t* __restrict__ out_num,
     uint8_t* __restrict__ out_mask, unsigned long long* __restrict__ gmax_all, const double* __restrict__ centers) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* tab = lds;                                    // [S][kTab]
-  double* hx = tab + (size_t)S * kTab;                  // [H][4]  RANSAC points + invalid flag
-  double* lx = hx + (size_t)H * 4;                      // [64][4] LO1 points + invalid flag
+  double* lx = tab + (size_t)S * kTab;                  // [64][4] LO1 points + invalid flag
   int* cnts = reinterpret_cast<int*>(lx + 64 * 4);      // [H] inlier counts, later [64] LO1 counts
   int* sel = cnts + ((H + 63) / 64) * 64;               // [64] selected hypothesis per LO slot
   int* vlist = sel + 64;                                // [S] views in which the track is visible, ascending
@@ -349,7 +473,7 @@ __global__ __launch_bounds__(64, 2) void triangulate_kernel(   // (two wavefront
 #pragma unroll
       for (int k = 0; k < 10; ++k) m.a[k] = m.a[k] + m2.a[k];
       double v[4];
-      smallest_eigvec4(m, v);
+      smallest_eigvec4_fast(m, v, live[j]);
       X[j][0] = v[0] / v[3]; X[j][1] = v[1] / v[3]; X[j][2] = v[2] / v[3];
       // cheirality on the two views, triangulation angle of the pair
       const double z1 = P1[8] * X[j][0] + P1[9] * X[j][1] + P1[10] * X[j][2] + P1[11];
@@ -370,7 +494,7 @@ __global__ __launch_bounds__(64, 2) void triangulate_kernel(   // (two wavefront
     for (int j = 0; j < HJ; ++j) { cnt[j] = 0; sum[j] = 0.0; pois[j] = bad_ray; }
     // (visible views only: see eval_views)
     for (int k = 0; k < ((VGG_TRI_ABLATE & 1) ? 0 : nv); ++k) {
-      const int s = vlist[k];
+      const int s = __builtin_amdgcn_readfirstlane(vlist[k]);
       const double* t = tab + s * kTab;
       const double* P = ext + 12 * s;
 #pragma unroll
@@ -392,7 +516,6 @@ __global__ __launch_bounds__(64, 2) void triangulate_kernel(   // (two wavefront
     for (int j = 0; j < HJ; ++j) {
       const int h = lane + 64 * j;
       if (live[j]) {
-        hx[4 * h] = X[j][0]; hx[4 * h + 1] = X[j][1]; hx[4 * h + 2] = X[j][2]; hx[4 * h + 3] = inv[j] ? 1.0 : 0.0;
         cnts[h] = cnt[j];
         Cand c;
         c.n = cnt[j];
@@ -424,14 +547,23 @@ __global__ __launch_bounds__(64, 2) void triangulate_kernel(   // (two wavefront
     Cand lc;
     lc.n = 0; lc.e = 2.0 * kPi;
     {
+      // the selected RANSAC point comes out of its owner's registers: hypothesis h lives in lane h % 64, register h / 64
       const int h = l_live ? sel[lane] : 0;
+      const int hl = h & 63, hj = h >> 6;
+      double S0 = 0, S1 = 0, S2 = 0;
+      bool s_inv = true;
+#pragma unroll
+      for (int j = 0; j < HJ; ++j) {
+        const double a0 = __shfl(X[j][0], hl, 64), a1 = __shfl(X[j][1], hl, 64), a2 = __shfl(X[j][2], hl, 64);
+        const bool ai = __shfl((int)inv[j], hl, 64) != 0;
+        if (hj == j) { S0 = a0; S1 = a1; S2 = a2; s_inv = ai; }
+      }
       Sym4 m;
 #pragma unroll
       for (int k = 0; k < 10; ++k) m.a[k] = 0.0;
-      eval_views<true>(ext, tab, vlist, nv, S, hx[4 * h], hx[4 * h + 1], hx[4 * h + 2], hx[4 * h + 3] != 0.0, l_live, max_rad, cos_gate,
-                       true, &m, nullptr);
+      eval_views<true>(ext, tab, vlist, nv, S, S0, S1, S2, s_inv, l_live, max_rad, cos_gate, true, &m, nullptr);
       double v[4];
-      smallest_eigvec4(m, v);
+      smallest_eigvec4_fast(m, v, l_live);
       L0 = v[0] / v[3]; L1 = v[1] / v[3]; L2 = v[2] / v[3];
       bool behind;
       // errors of the refined point (NaN -> 100*pi: not an inlier, no poisoning), cheirality over ALL views
@@ -473,7 +605,7 @@ __global__ __launch_bounds__(64, 2) void triangulate_kernel(   // (two wavefront
       eval_views_grouped<true>(ext, tab, vlist, nv, S, lx[4 * g], lx[4 * g + 1], lx[4 * g + 2], lx[4 * g + 3] != 0.0, q_live, max_rad,
                                cos_gate, false, &m, nullptr, src0, vq);
       double v[4];
-      smallest_eigvec4(m, v);
+      smallest_eigvec4_fast(m, v, q_live);
       const double Q0 = v[0] / v[3], Q1 = v[1] / v[3], Q2 = v[2] / v[3];
       bool behind;
       Cand qc = eval_views_grouped<false>(ext, tab, vlist, nv, S, Q0, Q1, Q2, false, q_live, max_rad, cos_gate, false, nullptr, &behind,
@@ -554,7 +686,7 @@ __global__ __launch_bounds__(256) void triangulate_pairs_kernel(const double* __
 #pragma unroll
     for (int k = 0; k < 10; ++k) m.a[k] = m0.a[k] + ms.a[k];
     double v[4];
-    smallest_eigvec4(m, v);
+    smallest_eigvec4_fast(m, v, true);
     double* o = out + ((size_t)(s - 1) * N + n) * 3;
     o[0] = v[0] / v[3]; o[1] = v[1] / v[3]; o[2] = v[2] / v[3];
   }
@@ -596,7 +728,7 @@ int vgg_triangulate_tracks_chunks(const double* extrinsics, const double* tracks
   const int lo1 = lo_num < H ? lo_num : H;
   const int lo2 = lo1 < 10 ? lo1 : 10;                   // (<= 64 / kGV: six lanes per hypothesis in the second round)
   const double max_rad = max_angular_error_deg * (kPi / 180.0);
-  const size_t lds = sizeof(double) * ((size_t)S * kTab + (size_t)H * 4 + 64 * 4) + sizeof(int) * (((H + 63) / 64) * 64 + 64 + (size_t)S);
+  const size_t lds = sizeof(double) * ((size_t)S * kTab + 64 * 4) + sizeof(int) * (((H + 63) / 64) * 64 + 64 + (size_t)S);
   if (lds > 160 * 1024) return VGG_ERR_UNSUPPORTED;
   unsigned long long* gmax = (unsigned long long*)((char*)workspace + 256);
   double* thres = (double*)(gmax + num_chunks);
@@ -622,6 +754,14 @@ int vgg_triangulate_tracks_chunks(const double* extrinsics, const double* tracks
   }
   return VGG_OK;
 }
+
+#ifdef VGG_TRI_STATS
+int vgg_debug_tri_stats(unsigned long long* host, int reset) {
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(vgg::g_tri_stats), sizeof(unsigned long long) * 4) != hipSuccess) return VGG_ERR_HIP;
+  if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(vgg::g_tri_stats), z, sizeof(z)); }
+  return VGG_OK;
+}
+#endif
 
 // One chunk (the reference's triangulate_tracks_single_chunk): pairs (H,2), *threshold_io as above.
 int vgg_triangulate_tracks(const double* extrinsics, const double* tracks_t, const uint8_t* invalid_vis_conf_t,

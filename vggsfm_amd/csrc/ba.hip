@@ -45,6 +45,9 @@ constexpr int kGroup = 16;       // cameras per Schur tile side
 #ifndef VGG_DIAG_OCC
 #define VGG_DIAG_OCC 4      // wavefronts per SIMD of the diagonal Schur kernel (BD = 6)
 #endif
+#ifndef VGG_TILE_INTERLEAVE
+#define VGG_TILE_INTERLEAVE 1   // full-factor tiles: LDS writes of the next batch between the K steps of the current one
+#endif
 #ifndef VGG_PP_OCC_SPLIT
 #define VGG_PP_OCC_SPLIT 3   // point_pass without the Y sweep: 158 VGPRs
 #endif
@@ -1133,6 +1136,7 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
   // wavefronts per SIMD.  Scales and constant-parameter masks are applied by assemble_kernel, like tile_reduce_kernel does
   // for the tile sums.
   constexpr bool TR = CY && DIAG;
+  constexpr bool INTERLEAVE = VGG_TILE_INTERLEAVE && !CY;
   const bool trhs = TR && w.tile_rhs != 0;
   constexpr int ZS = 12;                              // doubles per entry of the Z image (9 used; 16-byte aligned rows)
   double* zs = ops + 2 * (DIAG ? 1 : 2) * 4 * SEG;    // [buffer][entry][col][k]
@@ -1171,9 +1175,10 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
       for (int i = 0; i < NV; ++i) { const int off = l32 + TPS * i; sv[i] = (off < V) ? src[off] : make_double2(0.0, 0.0); }
     }
   };
-  auto write_lds = [&](const double2 (&sv)[NV], int buf) __attribute__((always_inline)) {
+  // (third k of 3 of a batch's LDS image: one component of the compressed factors, a third of the double2 of the full ones)
+  auto write_lds_k = [&](const double2 (&sv)[NV], int buf, const int k) __attribute__((always_inline)) {
     if constexpr (CY && HELPER) {
-      if (zthread) zs[(buf * 4 + se) * ZS + l32] = sv[0].x;
+      if (k == 0 && zthread) zs[(buf * 4 + se) * ZS + l32] = sv[0].x;
     } else if constexpr (CY) {
       if (stager) {
         // odd lane:  mine = (N20 N21 N22, 2a0 2a1 2a2), other = (N00 N01 N02, N10 N11 N12) -> rows 0..2 = (2 a) x N[:, k]:
@@ -1184,27 +1189,28 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
         //  and the component enters the LDS address as an immediate offset)
         double* dst = ops + (size_t)((buf * SIDES + sside) * 4 + se) * SEG;
         const double m[6] = {sv[0].x, sv[0].y, sv[1].x, sv[1].y, sv[2].x, sv[2].y};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
 #if VGG_ABLATE == 4                               // (profiling build: the staging without its exchange / arithmetic)
-          *reinterpret_cast<double2*>(dst + k * R + cy_row16) = make_double2(m[3 + k], m[k]);
-          dst[k * R + cy_row8] = m[k];
+        *reinterpret_cast<double2*>(dst + k * R + cy_row16) = make_double2(m[3 + k], m[k]);
+        dst[k * R + cy_row8] = m[k];
 #else
-          const double ok = dpp_swap_xor1(m[k]), o3k = dpp_swap_xor1(m[3 + k]);   // the other half, one component at a time
-          const double t0 = m[4] * m[k] - m[5] * o3k, t1 = m[5] * ok - m[3] * m[k], t2 = m[3] * o3k - m[4] * ok;
-          *reinterpret_cast<double2*>(dst + k * R + cy_row16) = cy_top ? make_double2(t0, t1) : make_double2(m[3 + k], ok);
-          dst[k * R + cy_row8] = cy_top ? t2 : m[k];
+        const double ok = dpp_swap_xor1(m[k]), o3k = dpp_swap_xor1(m[3 + k]);   // the other half, one component at a time
+        const double t0 = m[4] * m[k] - m[5] * o3k, t1 = m[5] * ok - m[3] * m[k], t2 = m[3] * o3k - m[4] * ok;
+        *reinterpret_cast<double2*>(dst + k * R + cy_row16) = cy_top ? make_double2(t0, t1) : make_double2(m[3 + k], ok);
+        dst[k * R + cy_row8] = cy_top ? t2 : m[k];
 #endif
-        }
       }
     } else {
       double2* dst = reinterpret_cast<double2*>(ops + (size_t)((buf * SIDES + sside) * 4 + se) * SEG);
+      constexpr int PER3 = (NV + 2) / 3;
 #pragma unroll
-      for (int i = 0; i < NV; ++i) {
+      for (int i = k * PER3; i < (k + 1) * PER3 && i < NV; ++i) {
         const int off = l32 + TPS * i;
         if (off < V) dst[off ^ ((se & 1) * (SWZ / 2))] = sv[i];
       }
     }
+  };
+  auto write_lds = [&](const double2 (&sv)[NV], int buf) __attribute__((always_inline)) {
+    write_lds_k(sv, buf, 0); write_lds_k(sv, buf, 1); write_lds_k(sv, buf, 2);
   };
   // operand addressing: entry e = lane >> 4 of the batch, component c = ks, tile row rr = 16 rb + (lane & 15)
   const int li = lane & 15, lk = lane >> 4;
@@ -1252,7 +1258,16 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
 #elif VGG_TILE_PRIO == 2                          // experiment: staging phases at raised wave priority
       __builtin_amdgcn_s_setprio(0);
 #endif
-      mfma_batch(buf, qmask);
+      // INTERLEAVE (full factors, 7 x 7 / 8 x 8 blocks): the LDS image of batch b + 1 is written in three pieces BETWEEN
+      // the K steps of batch b instead of in a phase of its own behind the last matrix instruction -- the ds_writes issue
+      // while the matrix pipe works.  Same-box A/B (round 4): configs[3] whole, off-diagonal launch 13.66 -> 13.18 ms,
+      // iteration 21.1 -> 20.6; with the compressed 6 x 6 factors (whose write phase is arithmetic: exchanges and cross
+      // products on the pipe the matrix instructions use) nothing for the off-diagonal launch and +6 % for the diagonal one
+      mfma_batch(buf, qmask, [&](const int k) __attribute__((always_inline)) {
+#if VGG_ABLATE != 5
+        if constexpr (INTERLEAVE) write_lds_k(sv_write, buf ^ 1, k);
+#endif
+      });
       if constexpr (TR && HELPER) {
         if (trhs) {
           const int rrow = tid & 127;                 // (wavefront 2: tile rows 0..63, wavefront 3: 64..95)
@@ -1282,7 +1297,7 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
       qmask = qmask_next;
       qmask_next = load_quad_mask(ebase(b + 2));
 #if VGG_ABLATE != 5                               // (profiling build: 5 = no LDS writes)
-      write_lds(sv_write, buf ^ 1);               // batch b+1, in flight for two steps
+      if constexpr (!INTERLEAVE) write_lds(sv_write, buf ^ 1);   // batch b+1, in flight for two steps
 #endif
       VGG_TT(tr_write)
 #if VGG_ABLATE != 3
@@ -1330,7 +1345,7 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
       bitsA[i] = block_slot_bits<BD>(wr + 2 * i);
       bitsB[i] = block_slot_bits<BD>(wc + 2 * i) << 16;
     }
-    sweep([&](int buf, uint32_t qm) {
+    sweep([&](int buf, uint32_t qm, auto&& wr) {
       const double* As = ops + (size_t)(buf * SIDES) * 4 * SEG;
       const double* Bs = ops + (size_t)(buf * SIDES + 1) * 4 * SEG;
       // one scalar bit per sub-tile of this wavefront (bit NH i + j), built once per batch: every skip test below is a bit
@@ -1375,10 +1390,13 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
       fetch(0, 0);
       fetch(1, 1); pin(0);
       group(0);
+      wr(0);
       fetch(0, 2); pin(1);
       group(1);
+      wr(1);
       pin(0);
       group(0);
+      wr(2);
     });
 #pragma unroll
     for (int i = 0; i < NH; ++i)
@@ -1407,7 +1425,7 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
         for (int u = 0; u < 4; ++u) { if (cb == rb) { ++rb; cb = 0; } else ++cb; }
       }
     }
-    sweep([&](int buf, uint32_t qm) {
+    sweep([&](int buf, uint32_t qm, auto&& wr) {
       const double* As = ops + (size_t)(buf * SIDES) * 4 * SEG;
       uint32_t on = 0u;                             // bit t: sub-tile t of this wavefront has a camera in its rows and in its columns
 #pragma unroll
@@ -1426,6 +1444,7 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
         for (int t = 0; t < PER; ++t)
           if (m & (1u << t))
             acc[t / NH][t % NH] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], bq[t], acc[t / NH][t % NH], 0, 0, 0);
+        wr(ks);
       }
     });
 #pragma unroll

@@ -53,10 +53,22 @@ def triangulate_tracks_single_chunk(extrinsics, tracks_normalized, max_ransac_it
     return _launch_chunk(ext, tracks_normalized, ivc, ransac_idx, lo_num, max_angular_error, min_tri_angle)
 
 
+_PAIRS = {}
+
+
+def _all_pairs(S):
+    """All C(S,2) view pairs in the reference's order, built once per view count (the reference rebuilds the list for
+    every chunk: 25 times per call at configs[2])."""
+    if S not in _PAIRS:
+        _PAIRS.clear()
+        _PAIRS[S] = torch.from_numpy(generate_combinations(S))
+    return _PAIRS[S]
+
+
 def _draw_pairs(S, max_ransac_iters, lo_num):
     """The hypothesis pairs of ONE reference chunk (triangulation.py:799-816): all C(S,2) pairs, or a
     torch.randperm draw from the global CPU RNG when there are more than max_ransac_iters."""
-    ransac_idx = torch.from_numpy(generate_combinations(S))
+    ransac_idx = _all_pairs(S)
     if max_ransac_iters > len(ransac_idx):
         max_ransac_iters = len(ransac_idx)
     else:

@@ -427,7 +427,8 @@ def main():
             "cholesky": ("mfma", n_red ** 3 / 3.0 + 2.0 * n_red ** 2),
             # (with the segment buffer it writes: 96 B per observation compressed, 24 BD B otherwise -- an artefact of the
             #  formulation, priced because it is what bounds the kernel)
-            "point_pass": ("hbm", (12.0 + 8.0 * y_slot) * n_obs + P * (24 + 4 + 8 * (6 + 3 + 6))),
+            # (+ the 72-byte back-substitution block Z per point the diagonal tile launch reads when it forms the right-hand side)
+            "point_pass": ("hbm", (12.0 + 8.0 * y_slot) * n_obs + P * (24 + 4 + 8 * (6 + 3 + 6) + (72 if bd == 6 else 0))),
             "point_step": ("hbm", 12.0 * n_obs + P * (24 + 4 + 8 * (6 + 3) + 24)),
             "cam_pass<linearize>": ("hbm", 12.0 * n_obs + 24.0 * n_obs),
             "cam_pass<rhs>": ("hbm", 12.0 * n_obs + (24.0 + 24 + 48) * n_obs),
@@ -442,11 +443,16 @@ def main():
         family = lambda k: "schur_tile" if k.startswith("schur_tile") else k
         fam_ms = {}
         for k, v in prof.items():
+            if v[1] == 0:
+                continue
             fam_ms[family(k)] = fam_ms.get(family(k), 0.0) + v[0]
         dom_family = max(fam_ms, key=fam_ms.get)
         dom = max((k for k in prof if family(k) == dom_family), key=lambda k: prof[k][0])
         by_kernel = {}
         for k, (ms_k, launches_k) in prof.items():
+            if launches_k == 0:          # cam_pass<rhs> with 6 x 6 tile blocks: its sums come out of the diagonal tile launch
+                by_kernel[k] = dict(ms_per_iteration=0.0, bound=work[k][0], frac=None, launches=0)
+                continue
             bound_k, amount_k = work[k]
             per_iter_ms = ms_k / args.steps
             rate = amount_k / max(per_iter_ms * 1e-3, 1e-12)          # work per iteration / time per iteration

@@ -535,28 +535,43 @@ __device__ __forceinline__ void prep_body(const DevProblem& pb, const Ws& w, con
     for (int k = 3; k < 6; ++k) if (w.active[6 * c + k]) gmax = fmax(gmax, fabs(g[k]));
     if (!d.shared) for (int k = 0; k < KD; ++k) if (w.active[6 * d.C + KD * c + k]) gmax = fmax(gmax, fabs(g[6 + k]));
   }
-  red[threadIdx.x] = cost; __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
-  const double cost_total = red[0]; __syncthreads();
-  red[threadIdx.x] = gmax; __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]); __syncthreads(); }
-  double gm = red[0]; __syncthreads();
+  // one block reduction for everything (round 4: six 256-thread trees of eight barriers each took 15 us of every iteration):
+  // wave shuffles, then the four wavefronts' partials in a fixed order
+  constexpr int NS = 1 + 2 * (KD > 0 ? KD : 1);
+  double sums[NS];
+  sums[0] = cost;
+#pragma unroll
+  for (int k = 1; k < NS; ++k) sums[k] = 0.0;
+  if (d.shared && KD > 0) {                        // shared intrinsics: column norm and gradient are sums over all cameras
+    for (int c = threadIdx.x; c < d.C; c += 256) {
+#pragma unroll
+      for (int k = 0; k < KD; ++k) {
+        sums[1 + k] += w.U[(size_t)c * BD * BD + (6 + k) * BD + 6 + k];
+        sums[1 + KD + k] += w.g[(size_t)c * BD + 6 + k];
+      }
+    }
+  }
+  const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const double v = wave_sum(sums[k]);
+    if (ln == 0) red[wv * 8 + k] = v;
+  }
+  gmax = wave_max(gmax);
+  if (ln == 0) red[32 + wv] = gmax;
+  __syncthreads();
+  const double cost_total = (red[0] + red[8]) + (red[16] + red[24]);
+  double gm = fmax(fmax(red[32], red[33]), fmax(red[34], red[35]));
   if (d.shared && KD > 0) {
-    // shared intrinsics: column norm and gradient are sums over all cameras
+#pragma unroll
     for (int k = 0; k < KD; ++k) {
-      double cs = 0, gs = 0;
-      for (int c = threadIdx.x; c < d.C; c += 256) { cs += w.U[(size_t)c * BD * BD + (6 + k) * BD + 6 + k]; gs += w.g[(size_t)c * BD + 6 + k]; }
-      red[threadIdx.x] = cs; __syncthreads();
-      for (int s2 = 128; s2 > 0; s2 >>= 1) { if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2]; __syncthreads(); }
-      cs = red[0]; __syncthreads();
-      red[threadIdx.x] = gs; __syncthreads();
-      for (int s2 = 128; s2 > 0; s2 >>= 1) { if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2]; __syncthreads(); }
-      gs = red[0]; __syncthreads();
+      const double cs = (red[1 + k] + red[9 + k]) + (red[17 + k] + red[25 + k]);
+      const double gs = (red[1 + KD + k] + red[9 + KD + k]) + (red[17 + KD + k] + red[25 + KD + k]);
       if (threadIdx.x == 0) w.colsq_c[6 * d.C + k] = cs;
       if (w.active[6 * d.C + k]) gm = fmax(gm, fabs(gs));
     }
-    __syncthreads();
   }
+  __syncthreads();                                 // (colsq_c is read below by other threads)
   if (first) {
     for (int j = threadIdx.x; j < d.n_red; j += 256)
       w.scale_c[j] = opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(w.colsq_c[j])) : 1.0;

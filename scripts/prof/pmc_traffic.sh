@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$C
   (cd $ROOT && rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc_$C -- \
-      python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-strong-leg --no-triangulation > $OUT/bench_$C.log 2>&1)
+      python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-strong-leg --no-triangulation --no-pipeline > $OUT/bench_$C.log 2>&1)
 done
 # calibration: known-size streaming reads with the kernels' access widths
 make -s -C $ROOT/scripts/ubench fetch_calib >/dev/null 2>&1

@@ -43,3 +43,12 @@ with contextlib.redirect_stdout(io.StringIO()):
 st = pstats.Stats(pr)
 st.sort_stats("tottime").print_stats(45)
 st.sort_stats("cumtime").print_stats(40)
+# device view of the same call: which kernels the forward spends its GPU time in (torch ops of compile_problem and the
+# drop-in's own launches side by side)
+from torch.profiler import ProfilerActivity, profile  # noqa: E402
+with contextlib.redirect_stdout(io.StringIO()):
+    torch.manual_seed(0)
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        tri(cams, tracks, vis, img, prelim, **kw)
+        torch.cuda.synchronize()
+print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=70))

@@ -308,7 +308,9 @@ __device__ __forceinline__ Cand eval_views(const double* __restrict__ ext, const
     // (the view index is the same in every lane -- it comes out of LDS, which the compiler cannot know: as a scalar the
     //  projection matrix is fetched by scalar loads into scalar registers instead of 12 vector loads into 24 VGPRs.
     //  A hand-written two-stage pipeline of this loop -- index two views ahead, matrix and ray one ahead -- was SLOWER,
-    //  21.9 against 19.2 ms at configs[2]: the copies between the stages cost more than the latency they hide)
+    //  21.9 against 19.2 ms at configs[2]: the copies between the stages cost more than the latency they hide; walking the
+    //  tracks in the order of their first visible view, so that the wavefronts resident together share their views'
+    //  matrices in the scalar cache, changed nothing: 16.60 against 16.69 ms)
     const int s = __builtin_amdgcn_readfirstlane(vlist[k]);
     const double* t = tab + s * kTab;
     bool isn;

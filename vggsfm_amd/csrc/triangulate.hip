@@ -335,6 +335,12 @@ __device__ __forceinline__ Cand eval_views(const double* __restrict__ ext, const
   return c;
 }
 
+// (Round 4, measured and NOT kept: the local-optimisation rounds with the VIEWS in the lanes and the hypotheses as the loop --
+//  a lane fetches its view's matrix once, the inlier decisions of a hypothesis are a ballot word, and the DLT matrices of all
+//  hypotheses are a (hypotheses x views) 0/1 matrix times the (views x 10) per-view matrices on the matrix cores.  Same masks;
+//  16.8 against 17.5 ms at 200 views, 2.12 against 1.91 ms at 50: the kernel is bound by its VALU instruction count -- SQ
+//  counters: 48.9 k vector instructions per track, the vector unit busy ~65 % of the launch -- not by the view-loop latency
+//  that form removes, and its per-hypothesis reductions cost what the per-view loads did.)
 // eval_views with kGV lanes per hypothesis (second local-optimisation round: 10 hypotheses, which left 54 of 64 lanes
 // idle for two passes over the views -- a quarter of the kernel at 200 views).  The lanes of a group evaluate kGV
 // consecutive views at once; their contributions are then added to the group's accumulators ONE VIEW AT A TIME, in view

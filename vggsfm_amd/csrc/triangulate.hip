@@ -235,13 +235,14 @@ __device__ __forceinline__ double view_error(const double* __restrict__ P, const
   const double y1 = P[4] * X0 + P[5] * X1 + P[6] * X2 + P[7];
   const double y2 = P[8] * X0 + P[9] * X1 + P[10] * X2 + P[11];
   depth = y2;
-  const double n = fmax(sqrt(y0 * y0 + y1 * y1 + y2 * y2), 1e-12);
 #if VGG_TRI_FAST_ERR
-  // one reciprocal instead of the reference's three divisions: the cosine moves by <= 1 ulp, the angle of a candidate inlier
-  // by ~3e-15 rad -- a decision changes only where |error - threshold| is below that (the goldens compare every mask bit)
-  const double rn = 1.0 / n;
+  // one reciprocal square root instead of the reference's square root and three divisions: the cosine moves by <= 2 ulp, the
+  // angle of a candidate inlier by ~5e-15 rad -- a decision changes only where |error - threshold| is below that (the goldens
+  // compare every mask bit).  (max(|y|, 1e-12) of the reference = max(|y|^2, 1e-24) under the root.)
+  const double rn = rsqrt(fmax(y0 * y0 + y1 * y1 + y2 * y2, 1e-24));
   double c = (tab[0] * (y0 * rn) + tab[1] * (y1 * rn)) + tab[2] * (y2 * rn);
 #else
+  const double n = fmax(sqrt(y0 * y0 + y1 * y1 + y2 * y2), 1e-12);
   double c = (tab[0] * (y0 / n) + tab[1] * (y1 / n)) + tab[2] * (y2 / n);
 #endif
   is_nan = (c != c);
@@ -287,10 +288,11 @@ struct Cand { double e; int n; };   // mean inlier error (or 2*pi) and inlier co
 // which then poisons every RANSAC hypothesis as the reference's NaN mean does).  The cheirality test over ALL views
 // (`any_behind`) needs the depth of the other views only -- one row of P X, the expression view_error uses.  Same values,
 // same order of the sums; ~4x fewer evaluations at the visibility density of the BASELINE scenes.
+constexpr int kGvMax = 64;   // visible views whose DLT matrix is tabulated per track (LDS: 80 bytes each)
 template <bool ACC>
 __device__ __forceinline__ Cand eval_views(const double* __restrict__ ext, const double* tab, const int* vlist, int nv, int S,
                                            double X0, double X1, double X2, bool invalid, bool live, double max_rad,
-                                           double cos_gate, bool ransac_nan, Sym4* acc, bool* any_behind) {
+                                           double cos_gate, bool ransac_nan, Sym4* acc, bool* any_behind, const double* gv = nullptr) {
   int cnt = 0;
   double sum = 0.0;
   bool poisoned = false, behind = false;
@@ -321,10 +323,17 @@ __device__ __forceinline__ Cand eval_views(const double* __restrict__ ext, const
     if (inl) {
       ++cnt; sum += err;
       if (ACC) {
-        Sym4 mv;
-        view_dlt_matrix_r(ext + 12 * s, t[0], t[1], t[2], mv);
+        // the DLT matrix of a view does not depend on the hypothesis: tabulated once per track for the first kGvMax visible
+        // views (round 4; the same numbers the expression below produces, added in the same order)
+        if (k < kGvMax) {
 #pragma unroll
-        for (int k2 = 0; k2 < 10; ++k2) acc->a[k2] += mv.a[k2];
+          for (int k2 = 0; k2 < 10; ++k2) acc->a[k2] += gv[k * 10 + k2];
+        } else {
+          Sym4 mv;
+          view_dlt_matrix_r(ext + 12 * s, t[0], t[1], t[2], mv);
+#pragma unroll
+          for (int k2 = 0; k2 < 10; ++k2) acc->a[k2] += mv.a[k2];
+        }
       }
     }
   }
@@ -353,7 +362,7 @@ template <bool ACC>
 __device__ __forceinline__ Cand eval_views_grouped(const double* __restrict__ ext, const double* tab, const int* vlist, int nv,
                                                    int S, double X0, double X1, double X2, bool invalid, bool live,
                                                    double max_rad, double cos_gate, bool ransac_nan, Sym4* acc,
-                                                   bool* any_behind, int src0, int vq) {
+                                                   bool* any_behind, int src0, int vq, const double* gv = nullptr) {
   int cnt = 0;
   double sum = 0.0;
   bool poisoned = false, behind = false;
@@ -374,7 +383,15 @@ __device__ __forceinline__ Cand eval_views_grouped(const double* __restrict__ ex
     if (has && isn && ransac_nan) poisoned = true;
     const bool inl = has && live && !invalid && !isn && (err <= max_rad);
     Sym4 mv;
-    if (ACC) view_dlt_matrix_r(ext + 12 * sc, t[0], t[1], t[2], mv);
+    if (ACC) {
+      const int kk = has ? k0 + vq : nv - 1;
+      if (kk < kGvMax) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) mv.a[i] = gv[kk * 10 + i];
+      } else {
+        view_dlt_matrix_r(ext + 12 * sc, t[0], t[1], t[2], mv);
+      }
+    }
     const unsigned long long inl_mask = __ballot(inl);
     // (not unrolled: six copies of the eleven exchanges were the register peak of the whole kernel -- 189 VGPRs with one
     //  hypothesis per lane, 168 without this block)
@@ -419,6 +436,7 @@ __global__ __launch_bounds__(64, VGG_TRI_OCC) void triangulate_kernel(   // (rou
   int* cnts = reinterpret_cast<int*>(lx + 64 * 4);      // [H] inlier counts, later [64] LO1 counts
   int* sel = cnts + ((H + 63) / 64) * 64;               // [64] selected hypothesis per LO slot
   int* vlist = sel + 64;                                // [S] views in which the track is visible, ascending
+  double* gv = reinterpret_cast<double*>(vlist + ((S + 1) & ~1));   // [kGvMax][10] DLT matrices of the first visible views
   const int lane = threadIdx.x;
   const double cos_gate = cos(max_rad) - 1e-9;
   double wave_max_e = 0.0;
@@ -462,6 +480,14 @@ __global__ __launch_bounds__(64, VGG_TRI_OCC) void triangulate_kernel(   // (rou
       const unsigned long long bm = __ballot(vis);
       if (vis) vlist[nv + __popcll(bm & ((1ull << lane) - 1ull))] = s;
       nv += __popcll(bm);
+    }
+    __syncthreads();
+    if (lane < nv && lane < kGvMax) {                  // (one view per lane; tab and vlist are in place)
+      const int sv = vlist[lane];
+      Sym4 g;
+      view_dlt_matrix_r(ext + 12 * sv, tab[sv * kTab], tab[sv * kTab + 1], tab[sv * kTab + 2], g);
+#pragma unroll
+      for (int i = 0; i < 10; ++i) gv[lane * 10 + i] = g.a[i];
     }
     __syncthreads();
 
@@ -539,13 +565,27 @@ __global__ __launch_bounds__(64, VGG_TRI_OCC) void triangulate_kernel(   // (rou
     // ---- LO round 1: stable descending rank of the H counts, top lo1 hypotheses -> slots
     if (lane < 64) sel[lane] = -1;
     __syncthreads();
+    {
+      // Stable descending order without comparing every hypothesis with every other (round 1-3: H comparisons per hypothesis,
+      // ~4 k instructions per track): counts are small integers, so walk the count VALUES downwards from the maximum; the
+      // hypotheses with the current value take the next slots in index order -- h = lane + 64 j ascends with (j, lane), i.e.
+      // a ballot per j and the number of set bits below the lane -- until lo1 slots are filled.
+      int cmax = -1;
 #pragma unroll
-    for (int j = 0; j < HJ; ++j) {
-      const int h = lane + 64 * j;
-      if (live[j]) {
-        int rank = 0;
-        for (int g = 0; g < H; ++g) { const int cg = cnts[g]; rank += (cg > cnt[j]) || (cg == cnt[j] && g < h); }
-        if (rank < lo1) sel[rank] = h;
+      for (int j = 0; j < HJ; ++j) cmax = max(cmax, live[j] ? cnt[j] : -1);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, __shfl_xor(cmax, off, 64));
+      int pos = 0;
+      const unsigned long long below = (1ull << lane) - 1ull;
+      for (int c = cmax; c >= 0 && pos < lo1; --c) {
+#pragma unroll
+        for (int j = 0; j < HJ; ++j) {
+          const bool mine = live[j] && cnt[j] == c;
+          const unsigned long long bm = __ballot(mine);
+          const int slot = pos + __popcll(bm & below);
+          if (mine && slot < lo1) sel[slot] = lane + 64 * j;
+          pos += __popcll(bm);
+        }
       }
     }
     __syncthreads();
@@ -569,7 +609,7 @@ __global__ __launch_bounds__(64, VGG_TRI_OCC) void triangulate_kernel(   // (rou
       Sym4 m;
 #pragma unroll
       for (int k = 0; k < 10; ++k) m.a[k] = 0.0;
-      eval_views<true>(ext, tab, vlist, nv, S, S0, S1, S2, s_inv, l_live, max_rad, cos_gate, true, &m, nullptr);
+      eval_views<true>(ext, tab, vlist, nv, S, S0, S1, S2, s_inv, l_live, max_rad, cos_gate, true, &m, nullptr, gv);
       double v[4];
       smallest_eigvec4_fast(m, v, l_live);
       L0 = v[0] / v[3]; L1 = v[1] / v[3]; L2 = v[2] / v[3];
@@ -611,7 +651,7 @@ __global__ __launch_bounds__(64, VGG_TRI_OCC) void triangulate_kernel(   // (rou
 #pragma unroll
       for (int k = 0; k < 10; ++k) m.a[k] = 0.0;
       eval_views_grouped<true>(ext, tab, vlist, nv, S, lx[4 * g], lx[4 * g + 1], lx[4 * g + 2], lx[4 * g + 3] != 0.0, q_live, max_rad,
-                               cos_gate, false, &m, nullptr, src0, vq);
+                               cos_gate, false, &m, nullptr, src0, vq, gv);
       double v[4];
       smallest_eigvec4_fast(m, v, q_live);
       const double Q0 = v[0] / v[3], Q1 = v[1] / v[3], Q2 = v[2] / v[3];
@@ -736,7 +776,8 @@ int vgg_triangulate_tracks_chunks(const double* extrinsics, const double* tracks
   const int lo1 = lo_num < H ? lo_num : H;
   const int lo2 = lo1 < 10 ? lo1 : 10;                   // (<= 64 / kGV: six lanes per hypothesis in the second round)
   const double max_rad = max_angular_error_deg * (kPi / 180.0);
-  const size_t lds = sizeof(double) * ((size_t)S * kTab + 64 * 4) + sizeof(int) * (((H + 63) / 64) * 64 + 64 + (size_t)S);
+  const size_t lds = sizeof(double) * ((size_t)S * kTab + 64 * 4) + sizeof(int) * (((H + 63) / 64) * 64 + 64 + (((size_t)S + 1) & ~(size_t)1)) +
+                     sizeof(double) * kGvMax * 10;
   if (lds > 160 * 1024) return VGG_ERR_UNSUPPORTED;
   unsigned long long* gmax = (unsigned long long*)((char*)workspace + 256);
   double* thres = (double*)(gmax + num_chunks);

@@ -89,6 +89,16 @@ int vgg_triangulate_tracks_chunks(const double* extrinsics, const double* tracks
                                   double max_angular_error_deg, double min_tri_angle_deg, double* out_points,
                                   int64_t* out_inlier_num, uint8_t* out_inlier_mask, double* thresholds_io,
                                   void* workspace, void* stream);
+/* Asynchronous form of the same launch (round 4): nothing is copied back, nothing is waited for.  `num_chunks` consecutive
+ * chunks starting at tracks_t[0]; thresholds_dev [num_chunks] and gmax_dev [num_chunks] (zeroed by the caller) are DEVICE
+ * arrays -- gmax_dev receives the bit pattern of the largest mean inlier error of every chunk (compare with the threshold
+ * semantics above); centers_dev [S][3] is scratch.  Lets the caller enqueue a call group of chunks by group of chunks while
+ * it is still drawing the later groups' hypothesis pairs on the host. */
+int vgg_triangulate_tracks_chunks_enqueue(const double* extrinsics, const double* tracks_t, const uint8_t* invalid_vis_conf_t,
+                                          const int32_t* pairs, int S, int N, int H, int num_chunks, int chunk_size, int lo_num,
+                                          double max_angular_error_deg, double min_tri_angle_deg, double* out_points,
+                                          int64_t* out_inlier_num, uint8_t* out_inlier_mask, const double* thresholds_dev,
+                                          unsigned long long* gmax_dev, double* centers_dev, void* stream);
 
 /* triangulate_by_pair (vggsfm/utils/triangulation.py:45-135): the S-1 two-view DLT point clouds between frame 0 and
  * every other frame.  extrinsics [S,3,4] f64, tracks_normalized [S,N,2] f64 (frame-major, camera rays) ->

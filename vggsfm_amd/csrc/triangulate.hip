@@ -763,12 +763,19 @@ size_t vgg_triangulate_chunks_workspace_bytes(int S, int num_chunks) { return tr
 // caller in chunk order; chunk c covers tracks [c*chunk_size, min(N,(c+1)*chunk_size)).
 // thresholds_io (host, [num_chunks]): in = residual-indicator threshold per chunk; out = max mean error + 1e-6
 // measured per chunk (the caller re-runs when they differ).  Synchronises the stream once.
-int vgg_triangulate_tracks_chunks(const double* extrinsics, const double* tracks_t, const uint8_t* invalid_vis_conf_t,
-                                  const int32_t* pairs, int S, int N, int H, int num_chunks, int chunk_size, int lo_num,
-                                  double max_angular_error_deg, double min_tri_angle_deg, double* out_points,
-                                  int64_t* out_inlier_num, uint8_t* out_inlier_mask, double* thresholds_io,
-                                  void* workspace, void* stream) {
-  if (S < 2 || N < 0 || H < 1 || H > 256 || lo_num < 1 || lo_num > 64 || !thresholds_io || !workspace ||
+// Asynchronous core: enqueues the launch for `num_chunks` consecutive reference chunks whose first track is tracks_t[0] and
+// returns -- nothing is copied back, nothing is waited for.  thresholds_dev [num_chunks] (device): residual-indicator
+// threshold per chunk; gmax_dev [num_chunks] (device, zeroed by the caller): receives the bits of the largest mean inlier
+// error per chunk (atomicMax on the non-negative doubles' bit patterns); centers_dev [S][3]: scratch for the camera centres.
+// The host mirror draws the hypothesis pairs of a call chunk group by chunk group (torch.randperm on the host, ~0.2 ms per
+// chunk at 200 views, 25 chunks) and enqueues every group as soon as its pairs are there: the draws of group g + 1 run
+// while the GPU works on group g.
+int vgg_triangulate_tracks_chunks_enqueue(const double* extrinsics, const double* tracks_t, const uint8_t* invalid_vis_conf_t,
+                                          const int32_t* pairs, int S, int N, int H, int num_chunks, int chunk_size, int lo_num,
+                                          double max_angular_error_deg, double min_tri_angle_deg, double* out_points,
+                                          int64_t* out_inlier_num, uint8_t* out_inlier_mask, const double* thresholds_dev,
+                                          unsigned long long* gmax_dev, double* centers_dev, void* stream) {
+  if (S < 2 || N < 0 || H < 1 || H > 256 || lo_num < 1 || lo_num > 64 || !thresholds_dev || !gmax_dev || !centers_dev ||
       num_chunks < 1 || num_chunks > 4096 || chunk_size < 1 || (long)num_chunks * chunk_size < N)
     return VGG_ERR_INVALID_ARGUMENT;
   if (N == 0) return VGG_OK;
@@ -779,20 +786,35 @@ int vgg_triangulate_tracks_chunks(const double* extrinsics, const double* tracks
   const size_t lds = sizeof(double) * ((size_t)S * kTab + 64 * 4) + sizeof(int) * (((H + 63) / 64) * 64 + 64 + (((size_t)S + 1) & ~(size_t)1)) +
                      sizeof(double) * kGvMax * 10;
   if (lds > 160 * 1024) return VGG_ERR_UNSUPPORTED;
-  unsigned long long* gmax = (unsigned long long*)((char*)workspace + 256);
-  double* thres = (double*)(gmax + num_chunks);
-  double* centers = thres + num_chunks;
-  VGG_HIP_CHECK(hipMemsetAsync(gmax, 0, sizeof(unsigned long long) * num_chunks, st));
-  VGG_HIP_CHECK(hipMemcpyAsync(thres, thresholds_io, sizeof(double) * num_chunks, hipMemcpyHostToDevice, st));
-  view_centers_kernel<<<div_up(S, 64), 64, 0, st>>>(extrinsics, S, centers);
+  view_centers_kernel<<<div_up(S, 64), 64, 0, st>>>(extrinsics, S, centers_dev);
   const int grid = N < 256 * 32 ? N : 256 * 32;
   void (*kern)(const double*, const double*, const uint8_t*, const int32_t*, int, int, int, int, int, double, double,
                const double*, int, double*, int64_t*, uint8_t*, unsigned long long*, const double*) =
       (H <= 64) ? triangulate_kernel<1> : (H <= 128) ? triangulate_kernel<2> : triangulate_kernel<4>;
   if (lds > 64 * 1024) VGG_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   kern<<<grid, 64, lds, st>>>(extrinsics, tracks_t, invalid_vis_conf_t, pairs, S, N, H, lo1, lo2, max_rad, min_tri_angle_deg,
-                              thres, chunk_size, out_points, out_inlier_num, out_inlier_mask, gmax, centers);
+                              thresholds_dev, chunk_size, out_points, out_inlier_num, out_inlier_mask, gmax_dev, centers_dev);
   VGG_LAUNCH_CHECK();
+  return VGG_OK;
+}
+
+int vgg_triangulate_tracks_chunks(const double* extrinsics, const double* tracks_t, const uint8_t* invalid_vis_conf_t,
+                                  const int32_t* pairs, int S, int N, int H, int num_chunks, int chunk_size, int lo_num,
+                                  double max_angular_error_deg, double min_tri_angle_deg, double* out_points,
+                                  int64_t* out_inlier_num, uint8_t* out_inlier_mask, double* thresholds_io,
+                                  void* workspace, void* stream) {
+  if (!thresholds_io || !workspace || num_chunks < 1 || num_chunks > 4096) return VGG_ERR_INVALID_ARGUMENT;
+  if (N == 0) return VGG_OK;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned long long* gmax = (unsigned long long*)((char*)workspace + 256);
+  double* thres = (double*)(gmax + num_chunks);
+  double* centers = thres + num_chunks;
+  VGG_HIP_CHECK(hipMemsetAsync(gmax, 0, sizeof(unsigned long long) * num_chunks, st));
+  VGG_HIP_CHECK(hipMemcpyAsync(thres, thresholds_io, sizeof(double) * num_chunks, hipMemcpyHostToDevice, st));
+  const int rc = vgg_triangulate_tracks_chunks_enqueue(extrinsics, tracks_t, invalid_vis_conf_t, pairs, S, N, H, num_chunks, chunk_size,
+                                                       lo_num, max_angular_error_deg, min_tri_angle_deg, out_points, out_inlier_num,
+                                                       out_inlier_mask, thres, gmax, centers, stream);
+  if (rc != VGG_OK) return rc;
   unsigned long long bits[4096];
   VGG_HIP_CHECK(hipMemcpyAsync(bits, gmax, sizeof(unsigned long long) * num_chunks, hipMemcpyDeviceToHost, st));
   VGG_HIP_CHECK(hipStreamSynchronize(st));
@@ -803,14 +825,6 @@ int vgg_triangulate_tracks_chunks(const double* extrinsics, const double* tracks
   }
   return VGG_OK;
 }
-
-#ifdef VGG_TRI_STATS
-int vgg_debug_tri_stats(unsigned long long* host, int reset) {
-  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(vgg::g_tri_stats), sizeof(unsigned long long) * 4) != hipSuccess) return VGG_ERR_HIP;
-  if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(vgg::g_tri_stats), z, sizeof(z)); }
-  return VGG_OK;
-}
-#endif
 
 // One chunk (the reference's triangulate_tracks_single_chunk): pairs (H,2), *threshold_io as above.
 int vgg_triangulate_tracks(const double* extrinsics, const double* tracks_t, const uint8_t* invalid_vis_conf_t,

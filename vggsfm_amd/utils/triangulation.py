@@ -115,48 +115,95 @@ def triangulate_tracks(extrinsics, tracks_normalized, max_ransac_iters=256, lo_n
     L = _lib.lib()
     S, N = tracks_normalized.shape[0], tracks_normalized.shape[1]
     dev = tracks_normalized.device
-    chunk_size, num_chunks = reference_chunks(S, N, max_tri_points_num)
-    draws = [_draw_pairs(S, max_ransac_iters, lo_num) for _ in range(num_chunks)]     # RNG consumed in chunk order
-    lo = draws[0][1]
-    if chunk_range is not None:
-        c0, c1 = max(0, int(chunk_range[0])), min(num_chunks, int(chunk_range[1]))
-        t0, t1 = min(N, c0 * chunk_size), min(N, c1 * chunk_size)
-        draws = draws[c0:c1]
-        tracks_normalized = tracks_normalized[:, t0:t1]
-        track_vis = None if track_vis is None else track_vis[:, t0:t1]
-        track_score = None if track_score is None else track_score[:, t0:t1]
-        N, num_chunks = t1 - t0, max(1, c1 - c0)
-        if not draws:                                 # a rank without a chunk
-            return (torch.empty((0, 3), dtype=torch.float64, device=dev), torch.empty(0, dtype=torch.int64, device=dev),
-                    torch.empty((0, S), dtype=torch.bool, device=dev))
-    pairs = torch.stack([d[0] for d in draws]).to(device=dev, dtype=torch.int32).contiguous()      # (C,H,2)
-    H = pairs.shape[1]
+    chunk_size, total_chunks = reference_chunks(S, N, max_tri_points_num)
+    c0, c1 = (0, total_chunks) if chunk_range is None else (max(0, int(chunk_range[0])), min(total_chunks, int(chunk_range[1])))
+    c1 = max(c0, c1)
+    t0, t1 = min(N, c0 * chunk_size), min(N, c1 * chunk_size)
+    n_loc, nc = t1 - t0, c1 - c0                      # tracks / chunks this call triangulates
+    # device-side preparation first (asynchronous): it runs under the host-side draws below
+    sl = slice(t0, t1)
     if track_score is not None:
-        ivc = torch.logical_or(track_vis <= 0.05, track_score <= 0.5)
+        ivc = torch.logical_or(track_vis[:, sl] <= 0.05, track_score[:, sl] <= 0.5)
     elif track_vis is not None:
-        ivc = track_vis <= 0.05
+        ivc = track_vis[:, sl] <= 0.05
     else:
-        ivc = torch.zeros((S, N), dtype=torch.bool, device=dev)
+        ivc = torch.zeros((S, n_loc), dtype=torch.bool, device=dev)
     ext = extrinsics.to(torch.float64).contiguous()
-    tn_t = tracks_normalized.to(torch.float64).permute(1, 0, 2).contiguous()          # track-major
+    tn_t = tracks_normalized[:, sl].to(torch.float64).permute(1, 0, 2).contiguous()          # track-major
     ivc_t = ivc.t().contiguous().to(torch.uint8)
-    pts = torch.empty((N, 3), dtype=torch.float64, device=dev)
-    num = torch.empty(N, dtype=torch.int64, device=dev)
-    mask = torch.empty((N, S), dtype=torch.uint8, device=dev)
-    if N == 0:
+    pts = torch.empty((n_loc, 3), dtype=torch.float64, device=dev)
+    num = torch.empty(n_loc, dtype=torch.int64, device=dev)
+    mask = torch.empty((n_loc, S), dtype=torch.uint8, device=dev)
+    first_thr = 2.0 * math.pi + 1e-6
+    thr_dev = torch.full((max(nc, 1),), first_thr, dtype=torch.float64, device=dev)
+    gmax_dev = torch.zeros(max(nc, 1), dtype=torch.int64, device=dev)
+    centers = torch.empty(3 * S, dtype=torch.float64, device=dev)
+    # The hypothesis pairs are drawn on the host, chunk by chunk, from the global CPU RNG (one torch.randperm(C(S,2)) per chunk,
+    # as the reference does: ~0.2 ms each at 200 views, 25 chunks at configs[2]) -- and every GROUP of chunks is enqueued
+    # (vgg_triangulate_tracks_chunks_enqueue, no synchronisation) as soon as its pairs are on the device, so the draws of the
+    # next group run while the GPU works on this one.  The pairs go up on a side stream: a blocking copy on the launch stream
+    # would wait for the kernel in front of it.
+    groups = min(nc, ASYNC_GROUPS) if nc >= 4 else 1
+    per_group = -(-nc // groups) if nc else 1
+    pairs_dev, lo, H = None, None, None
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(dev)
+    pending, g_first = [], c0
+    for c in range(total_chunks):
+        idx, lo_c = _draw_pairs(S, max_ransac_iters, lo_num)                   # RNG consumed in chunk order, for ALL chunks
+        lo = lo_c if lo is None else lo
+        if not (c0 <= c < c1) or n_loc == 0:
+            continue
+        pending.append(idx)
+        if len(pending) < per_group and c != c1 - 1:
+            continue
+        host = torch.stack(pending).to(torch.int32)                            # (G,H,2)
+        if pairs_dev is None:
+            H = host.shape[1]
+            pairs_dev = torch.empty((nc, H, 2), dtype=torch.int32, device=dev)
+            side.wait_stream(main)
+        g0, g1 = g_first - c0, c - c0 + 1
+        with torch.cuda.stream(side):
+            pairs_dev[g0:g1].copy_(host)
+        main.wait_stream(side)
+        ta, tb = min(n_loc, g0 * chunk_size), min(n_loc, g1 * chunk_size)
+        if tb > ta:
+            _lib.check(L.vgg_triangulate_tracks_chunks_enqueue(
+                _lib.ptr(ext), _lib.ptr(tn_t[ta:tb]), _lib.ptr(ivc_t[ta:tb]), _lib.ptr(pairs_dev[g0:g1]), S, tb - ta, H, g1 - g0,
+                chunk_size, lo, ctypes.c_double(max_angular_error), ctypes.c_double(min_tri_angle), _lib.ptr(pts[ta:tb]),
+                _lib.ptr(num[ta:tb]), _lib.ptr(mask[ta:tb]), _lib.ptr(thr_dev[g0:g1]), _lib.ptr(gmax_dev[g0:g1]), _lib.ptr(centers),
+                _lib.stream_ptr()), "vgg_triangulate_tracks_chunks_enqueue")
+        pending, g_first = [], c + 1
+    if n_loc == 0 or nc == 0:
         return pts, num, mask.bool()
-    ws = torch.zeros(int(L.vgg_triangulate_chunks_workspace_bytes(S, num_chunks)), dtype=torch.uint8, device=dev)
-    thr = (ctypes.c_double * num_chunks)(*([2.0 * math.pi + 1e-6] * num_chunks))
-    for _ in range(2):
-        used = list(thr)
-        _lib.check(L.vgg_triangulate_tracks_chunks(_lib.ptr(ext), _lib.ptr(tn_t), _lib.ptr(ivc_t), _lib.ptr(pairs), S, N, H,
-                                                   num_chunks, chunk_size, lo, ctypes.c_double(max_angular_error),
-                                                   ctypes.c_double(min_tri_angle), _lib.ptr(pts), _lib.ptr(num),
-                                                   _lib.ptr(mask), thr, _lib.ptr(ws), _lib.stream_ptr()),
-                   "vgg_triangulate_tracks_chunks")
-        if list(thr) == used:
-            break
+    # the one synchronisation of the call: the largest mean inlier error of every chunk (the indicator's chunk-global threshold)
+    measured = gmax_dev.cpu().numpy().view("float64") + 1e-6
+    if not (measured == first_thr).all():
+        # (pathological: every hypothesis of a chunk has an inlier -- the threshold the launch assumed was not the chunk's
+        #  maximum; run again with the measured ones, synchronously, as rounds 1-3 did)
+        ws = torch.zeros(int(L.vgg_triangulate_chunks_workspace_bytes(S, nc)), dtype=torch.uint8, device=dev)
+        thr = (ctypes.c_double * nc)(*[float(x) for x in measured])
+        for _ in range(2):
+            used = list(thr)
+            _lib.check(L.vgg_triangulate_tracks_chunks(_lib.ptr(ext), _lib.ptr(tn_t), _lib.ptr(ivc_t), _lib.ptr(pairs_dev), S, n_loc, H,
+                                                       nc, chunk_size, lo, ctypes.c_double(max_angular_error),
+                                                       ctypes.c_double(min_tri_angle), _lib.ptr(pts), _lib.ptr(num),
+                                                       _lib.ptr(mask), thr, _lib.ptr(ws), _lib.stream_ptr()),
+                       "vgg_triangulate_tracks_chunks")
+            if list(thr) == used:
+                break
     return pts, num, mask.bool()
+
+
+ASYNC_GROUPS = 5          # chunk groups a multi-chunk triangulate_tracks call is enqueued in (host draws overlap the GPU)
+_SIDE = {}
+
+
+def _side_stream(dev):
+    key = (dev.type, dev.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
 
 
 def triangulate_by_pair(extrinsics, tracks_normalized, eps=1e-12):

@@ -552,16 +552,20 @@ def main():
             hyp = min(256, S * (S - 1) // 2)
             # SURVEY 8(d) per-track flops of the REFERENCE formulation (its all-pairs angle term included)
             f_ref = N * (hyp * (2.5e3 + 70 * S) + 60 * (150 * S + 2e3 + 70 * S) + 60 * 40 * S * S)
-            # what the kernel evaluates: (H + 2 x 60) passes over the track's VISIBLE views of ~70 flop each (only they can hold
-            # inliers; the cheirality pass over all views costs 6 flop per view) + (H + 60) x 3k flop of DLT / Jacobi per track
+            # what the kernel evaluates (round 4): (H + 2 x 60) passes over the track's VISIBLE views of ~60 flop each (one
+            # reciprocal square root, the acos series; only visible views can hold inliers; the cheirality pass over all views
+            # costs 6 flop per view), the per-view DLT matrices once per track (~100 flop) and 20 flop per (local-optimisation
+            # hypothesis, inlier view) to add them up, ~1 k flop per hypothesis for its two view matrices, the smallest
+            # eigenvector by inverse iteration (LDL^T + ~8 steps) and the triangulation angle (rounds 1-3: 3 k with the Jacobi)
             vis_mean = float(sc.mask.sum()) / N
-            f_exec = N * ((hyp + 120) * vis_mean * 70.0 + 120 * S * 6.0 + (hyp + 60) * 3e3)
+            f_exec = N * ((hyp + 120) * vis_mean * 60.0 + 120 * S * 6.0 + vis_mean * 100.0 + 60 * vis_mean * 20.0 + (hyp + 60) * 1.0e3)
             tri = dict(workload=f"triangulate_tracks on the timed scene ({S} x {N}), {hyp} hypotheses + 2 local-optimisation rounds, "
                                 "all reference chunks in one launch", mean_visible_views=vis_mean, ms=1e3 * t_dev, ms_host_inclusive=1e3 * t_host,
                        tracks_per_s=N / t_dev, valid_frac=float((num_inl >= 3).float().mean()),
                        bound="fp64 valu", executed_flops=f_exec, frac_of_fp64_peak=f_exec / t_dev / (FP64_PEAK_TFLOPS * 1e12),
                        reference_formulation_flops=f_ref, reference_formulation_tflops=f_ref / t_dev / 1e12,
-                       kernel="triangulate_kernel (profiles/: rocprofv3 stats of scripts/prof/bench_geometry.py)")
+                       kernel="triangulate_kernel (its own time: the rocprofv3 kernel stats under profiles/; `ms` is the whole call on "
+                              "the launch stream, host-side pair draws included)")
             del g_tracks, g_vis, g_score, tn, p3
             torch.cuda.empty_cache()
         parity_c3 = None

@@ -130,6 +130,7 @@ struct Ws {  // device workspace carve-up (pointers into the caller's buffer)
   // column-major) with E hs = E G z, E Ms_m = E G y_m; per diagonal chunk the sums over its entries of Y_seg Z (96 x 3);
   // per point-pass workgroup the shared-intrinsics terms sum_p Wa_p hs_p (KD) and sum_p Wa_p Ms_p^T (KD x KD)
   double *Zp, *rz_part, *part_Q;
+  double* rz;                 // [ceil(C / 16)][96 x 3] rz_part summed over the chunks of a group's diagonal tile (tile_reduce_kernel)
   int tile_rhs;               // 1: cam_pass<RHS> is not launched, its sums come from the diagonal tile launch + point_pass
   size_t lin_count, sys_count, total_bytes;
 };
@@ -196,6 +197,7 @@ static Ws carve(const Dims& d, int max_iters, int num_chunks, int num_segments, 
   w.Zp = (double*)take(8ull * 9 * (d.P > 0 ? d.P : 1));
   w.rz_part = (double*)take(8ull * (size_t)(num_chunks > 0 ? num_chunks : 1) * kGroup * 6 * 3);
   w.part_Q = (double*)take(8ull * kMaxWG * 8);
+  w.rz = (double*)take(8ull * (size_t)((d.C + kGroup - 1) / kGroup) * kGroup * 6 * 3);
   w.tile_rhs = 0;
   w.total_bytes = off;
   return w;
@@ -1517,6 +1519,31 @@ __global__ __launch_bounds__(256) void tile_reduce_kernel(Ws w, int n_red, int C
   const int gI = tile_desc[4 * tile], gJ = tile_desc[4 * tile + 1];
   const int c0 = tile_desc[4 * tile + 2], c1 = tile_desc[4 * tile + 3];
   const int n = n_red;
+  if constexpr (BD == 6) {
+    // tile_rhs: the blocks behind the R x R elements add up, for a diagonal tile, the chunks' 96 x 3 right-hand-side blocks
+    // (schur_tile_body's helpers) in the same fixed order -- assemble_kernel then reads 18 numbers per camera instead of
+    // walking ~80 chunks with 18 of its 64 threads (24 us of every iteration at configs[2])
+    const int nb2 = (R * R + 255) / 256;
+    if ((int)blockIdx.x >= nb2) {
+      if (gI != gJ || !w.tile_rhs) return;
+      const int e = ((int)blockIdx.x - nb2) * 256 + threadIdx.x;
+      if (e >= R * 3) return;
+      double s0 = 0.0, s1 = 0.0;
+      int ch = c0;
+      const double* src = w.rz_part + e;
+      for (; ch + 7 < c1; ch += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(ch + u) * R * 3];
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) { s0 += v[u]; s1 += v[u + 1]; }
+      }
+      for (; ch + 1 < c1; ch += 2) { s0 += src[(size_t)ch * R * 3]; s1 += src[(size_t)(ch + 1) * R * 3]; }
+      if (ch < c1) s0 += src[(size_t)ch * R * 3];
+      w.rz[(size_t)gI * R * 3 + e] = s0 + s1;
+      return;
+    }
+  }
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= R * R) return;
   const int row = e / R, col = e - row * R;
@@ -1572,24 +1599,15 @@ __global__ __launch_bounds__(64) void assemble_kernel(DevProblem pb, Ws w, const
     const double* T = w.T + (size_t)c * BD * tw;
     const int ia = 6 * d.C + (d.shared ? 0 : KD * c);
     if (trhs) {
-      // chunks of the diagonal tile of this camera's group (tiles are few: every thread scans a stride of the table)
-      int c0 = 0, c1 = 0;
-      const int g = c / kGroup;
-      for (int t = tid; t < num_tiles; t += 64)
-        if (tile_desc[4 * t] == g && tile_desc[4 * t + 1] == g) { c0 = tile_desc[4 * t + 2]; c1 = tile_desc[4 * t + 3]; }
-      c0 = wave_sum_i(c0); c1 = wave_sum_i(c1);           // (one thread found the tile, the others hold 0)
+      // (a group without observations has no diagonal tile: nothing was summed for it)
       if (tid < 18) {
         const int i = tid / 3, col = tid - 3 * i;
-        const double* src = w.rz_part + ((size_t)(c % kGroup) * 6 + i) * 3 + col;
-        double s0 = 0.0, s1 = 0.0;                     // (fixed order: even chunks into s0, odd ones into s1)
-        int ch = c0;
-        for (; ch + 1 < c1; ch += 2) { s0 += src[(size_t)ch * kGroup * 18]; s1 += src[(size_t)(ch + 1) * kGroup * 18]; }
-        if (ch < c1) s0 += src[(size_t)ch * kGroup * 18];
-        rz[i][col] = s0 + s1;
+        const int g = c / kGroup;
+        const bool has_tile = pb.col_ptr[min((g + 1) * kGroup, d.C)] > pb.col_ptr[g * kGroup];
+        rz[i][col] = has_tile ? w.rz[(size_t)g * kGroup * 18 + ((size_t)(c % kGroup) * 6 + i) * 3 + col] : 0.0;
       }
       __syncthreads();
     }
-    // T_c as cam_pass<RHS> defines it, whichever way it was formed (pose rows; intrinsics rows only without tile_rhs)
     // (the compressed factors behind rz carry no constant-parameter masks -- cam_pass<RHS> evaluated MASKED Jacobians, so a
     //  constant pose / translation component contributed exact zeros: the mask acts on the row here, like in tile_reduce)
     auto Tc = [&](int i, int m) -> double {
@@ -2034,8 +2052,8 @@ static void launch_schur_batch(const Launch& L, int batch, hipStream_t st, doubl
     schur_tile_kernel<BD, true><<<c1 - cm, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, cm, L.num_segments);
   }
   if (t1 > t0)
-    tile_reduce_kernel<BD><<<dim3(div_up(kGroup * BD * kGroup * BD, 256), t1 - t0), 256, 0, st>>>(L.w, L.d.n_red, L.d.C, L.d.kd,
-                                                                                                  L.tile_desc, t0, dst);
+    tile_reduce_kernel<BD><<<dim3(div_up(kGroup * BD * kGroup * BD, 256) + ((BD == 6 && L.w.tile_rhs) ? div_up(kGroup * BD * 3, 256) : 0),
+                                  t1 - t0), 256, 0, st>>>(L.w, L.d.n_red, L.d.C, L.d.kd, L.tile_desc, t0, dst);
 }
 
 template <int KD>

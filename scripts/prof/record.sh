@@ -5,6 +5,7 @@
 #   <tag>_bench_c3_kernel_stats.csv     rocprofv3 --kernel-trace --stats of the same command (triangulation leg included)
 #   <tag>_pmc_fetch_write_c3.json       FETCH_SIZE / WRITE_SIZE per kernel, separate --pmc passes (scripts/prof/pmc_traffic.sh)
 #   <tag>_bench_c4full.json (+ _kernel_stats.csv)   configs[3] whole on one GPU
+#   <tag>_c5_video.json, <tag>_c1_kitchen.json      configs[4] (1000-frame video loop) and configs[0] (kitchen plumbing) once
 TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
@@ -24,3 +25,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c4 -o c4 -- py
 cp $(find /tmp/prof_c4 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_c4full_kernel_stats.csv
 cd $ROOT
 python scripts/prof/compile_profile.py > $OUT/compile_profile.txt 2>&1
+python scripts/run_c5_video.py --out $OUT/${TAG}_c5_video.json > $OUT/c5.log 2>&1
+python scripts/run_c1_kitchen.py --stage run --out $OUT/${TAG}_c1_kitchen.json > $OUT/c1.log 2>&1

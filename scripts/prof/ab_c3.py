@@ -3,7 +3,10 @@ every variant = a set of environment switches read by vggsfm_amd.ba.compile_prob
 ...) -> ms per LM iteration + per-kernel HIP-event times, variants interleaved over `--rounds` rounds (drift shows up as a
 difference between the rounds of one variant).  A different library (built with other -D switches) is selected for the
 whole process with VGGSFM_AMD_LIB.
-usage: python scripts/prof/ab_c3.py [--workload c3] [--steps 25] [--rounds 2] name:ENV=VAL,ENV=VAL ..."""
+A variant key RCCL=1 (RCCL=2) runs the iteration with the collectives of a ONE-RANK "nccl" communicator between the phases
+(reduce-scatter + all-gather form; 2 = the two-all-reduce form): what the exchange sequence costs on the kernel stream before
+any link time.  --tracks overrides the track count (37500 = one rank's shard of configs[3] at 8 GPUs).
+usage: python scripts/prof/ab_c3.py [--workload c3] [--tracks N] [--steps 25] [--rounds 2] name:ENV=VAL,ENV=VAL ..."""
 import argparse
 import ctypes
 import json
@@ -30,11 +33,13 @@ def main():
     ap.add_argument("--steps", type=int, default=25)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--tracks", type=int, default=0)
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     L = _lib.lib()
     S, N, cam, shared = B.WORKLOADS[a.workload]
+    N = a.tracks or N
     if S >= 400:
         sc = make_scene_device(S, N, cam, shared_camera=shared, seed=0, track_seed=1000, device=dev)
         ext0, K0, xp0, _ = perturb_for_ba(B.sc_cameras_only(sc), seed=0)
@@ -50,10 +55,20 @@ def main():
             os.environ.clear()
             os.environ.update(base_env)
             L.vgg_ba_set_tile_rhs(1)
+            coll = None
             for kv in filter(None, envs.split(",")):
                 k, _, val = kv.partition("=")
                 if k == "TILE_RHS":                        # (process-wide library switch, not an environment variable here)
                     L.vgg_ba_set_tile_rhs(int(val))
+                    continue
+                if k == "RCCL":
+                    import torch.distributed as dist
+                    from vggsfm_amd.dist import Collectives
+                    if not dist.is_initialized():
+                        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
+                        torch.cuda.set_device(dev)
+                        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+                    coll = Collectives(1, plain_all_reduce=(val == "2"))
                     continue
                 os.environ[k] = val.replace(";", ",")
             prob, _, _ = BA.compile_problem(*args, shared, cam, camera_split=True)
@@ -62,7 +77,7 @@ def main():
             so = opts.solver_options
             so.max_num_iterations = B.EPISODE
             so.function_tolerance = so.gradient_tolerance = so.parameter_tolerance = -1.0
-            solver = ShardedBA(prob, opts, 0, 1)
+            solver = ShardedBA(prob, opts, 0, 1, collectives=coll)
             cnt = [0]
 
             def run(n):

@@ -86,3 +86,56 @@ def test_rccl_sharded_solve_equals_single_rank(cam, shared):
         np.testing.assert_allclose(g["intr"], ref["intr"], rtol=1e-10)
     pts = np.concatenate([g["pts"] for g in got])
     np.testing.assert_allclose(pts, ref["pts"], atol=1e-8)
+
+
+def _one_rank(port, cam, shared, out):
+    import torch.distributed as dist
+
+    from vggsfm_amd import ba as BA
+    from vggsfm_amd.dist import Collectives, ShardedBA, triangulate_tracks_sharded
+    from vggsfm_amd.scene import make_scene, perturb_for_ba
+    from vggsfm_amd.utils.triangulation_helpers import prepare_ba_options
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    D = lambda x: None if x is None else torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    sc = make_scene(96, 5000, cam, shared_camera=shared, seed=23)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=23)
+    opts = prepare_ba_options()
+    opts.solver_options.max_num_iterations = 10
+    res = {}
+    for name in ("plain", "rccl", "rccl_allreduce"):
+        pr, _, _ = BA.compile_problem(D(pts0), D(ext0), D(K0), D(sc.tracks), D(sc.mask), D(extra0), shared, cam, camera_split=True)
+        co = None if name == "plain" else Collectives(1, plain_all_reduce=(name == "rccl_allreduce"))
+        r = ShardedBA(pr, opts, collectives=co).solve()
+        torch.cuda.synchronize()
+        res[name] = dict(its=[(i["successful"], i["cost"]) for i in r["iterations"]], final=r["final_cost"], n_it=r["num_iterations"],
+                         cam_t=pr.cam_t.cpu().numpy(), intr=pr.intr.cpu().numpy(), pts=pr.pts.cpu().numpy())
+    out.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cam,shared", [("SIMPLE_RADIAL", True), ("SIMPLE_RADIAL", False)])
+def test_rccl_one_rank_runs_the_exchange_sequence_on_the_solver_buffers(cam, shared):
+    """What a 1-GPU box can show of the RCCL path: a REAL "nccl" communicator of one rank takes the solver's own buffers
+    through every collective of an LM iteration -- all-reduce of the camera blocks, reduce-scatter of the zero-padded packed
+    system into the slice buffer, all-gather into the buffer the unpack kernel reads, all-reduce of the step scalars -- on
+    the kernel stream, between the phase launches.  With one rank every sum is the identity, so the solve has to reproduce
+    the collective-free one bit for bit; the two-all-reduce form (A/B switch) as well."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    p = ctx.Process(target=_one_rank, args=(_free_port(), cam, shared, out))
+    p.start()
+    res = out.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    ref = res["plain"]
+    for name in ("rccl", "rccl_allreduce"):
+        g = res[name]
+        assert g["n_it"] == ref["n_it"] and g["its"] == ref["its"] and g["final"] == ref["final"], name
+        for k in ("cam_t", "intr", "pts"):
+            assert np.array_equal(g[k], ref[k]), (name, k)

@@ -173,7 +173,7 @@ static Ws carve(const Dims& d, int max_iters, int num_chunks, int num_segments, 
   w.S2 = (double*)take(8ull * (size_t)d.n_red * d.n_red);
   w.packed_count = (size_t)d.n_red * (d.n_red + 1) / 2 + d.n_red;
   w.packed = (double*)take(8ull * (w.packed_count + kPackPad));
-  w.pk_mine = (double*)take(8ull * ((w.packed_count + 1) / 2 + 2));            // (W >= 2)
+  w.pk_mine = (double*)take(8ull * (w.packed_count + 2));                      // (W = 1: the whole payload)
   w.pk_gathered = (double*)take(8ull * (w.packed_count + 2 * kPackPad));
   w.gmax_pts = (double*)take(64);
   w.stepsum = (double*)take(64);
@@ -2407,7 +2407,7 @@ int vgg_ba_reduce_buffer(const vgg_ba_problem* problem, const vgg_ba_options* op
     case 2: *device_ptr = w.gmax_pts; *count = 1; break;
     case 3: *device_ptr = w.stepsum; *count = 4; break;
     case 4: *device_ptr = w.packed; *count = w.packed_count; break;
-    case 5: *device_ptr = w.pk_mine; *count = (w.packed_count + 1) / 2 + 2; break;
+    case 5: *device_ptr = w.pk_mine; *count = w.packed_count + 2; break;
     case 6: *device_ptr = w.pk_gathered; *count = w.packed_count + 2 * kPackPad; break;
     default: return VGG_ERR_INVALID_ARGUMENT;
   }

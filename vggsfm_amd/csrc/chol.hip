@@ -1092,12 +1092,16 @@ __device__ __forceinline__ bool factor16_mfma(f64x4 acc, double* D, double* Tl, 
 
 // slab(kb): called by wavefront 1 alone (all 64 lanes) once the 16 columns 16 kb .. 16 kb + 15 of T are final (kb = 0, 1, 2;
 // the last 16 columns are final on return): the caller hands them on while the factorisation goes on.
+#ifndef VGG_F64_ABL
+#define VGG_F64_ABL 0      // scripts/ubench/factor64_bench ablations: 1 no 16 x 16 factorisation, 2 no trailing updates, 4 no
+#endif                     // side panels, 8 no critical panel, 16 no zero fill of T
 template <class FS>
 __device__ __forceinline__ void factor64_blocked(double* D, double* Tl, double* scr, int32_t* fail, FS slab) {
   constexpr int LD = DFB + 1, B = 16;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int e = tid; e < DFB * DFB; e += 256) Tl[(e / DFB) * LD + (e % DFB)] = 0.0;
+  if (!(VGG_F64_ABL & 16))
+    for (int e = tid; e < DFB * DFB; e += 256) Tl[(e / DFB) * LD + (e % DFB)] = 0.0;
   __syncthreads();
   bool bad = false;
   // D[ib][jb] -= L[ib][k] L[jb][k]^T   /   E[ib][jb] -= E[ib][k] L[jb][k]^T   (16 x 16 blocks; E = the rows of the identity in Tl)
@@ -1114,8 +1118,8 @@ __device__ __forceinline__ void factor64_blocked(double* D, double* Tl, double* 
 #pragma unroll 1
   for (int kb = 0; kb < 4; ++kb) {
     if (wave == 0) {
-      bad = factor16_mfma<LD>(dacc, D, Tl, kb) || bad;
-    } else if (kb > 0) {
+      if (!(VGG_F64_ABL & 1)) bad = factor16_mfma<LD>(dacc, D, Tl, kb) || bad;
+    } else if (kb > 0 && !(VGG_F64_ABL & 2)) {
       // the rest of the trailing update of step k = kb - 1, dealt to wavefronts 2, 3, 1, 2, 3, 1 ...; wavefront 1 first hands
       // on the columns of T that step k completed (they are not touched again)
       const int k = kb - 1;
@@ -1140,6 +1144,7 @@ __device__ __forceinline__ void factor64_blocked(double* D, double* Tl, double* 
     // order lk + 4 reg on both sides), and takes the next diagonal block (every earlier update is in LDS by now) minus
     // X X^T straight into the registers it factors from -- no pass through LDS, no barrier on that path.
     if (wave == 0 && kb < 3) {
+      if (VGG_F64_ABL & 8) { __syncthreads(); continue; }
       const int lane = tid & 63, li = lane & 15, lk = lane >> 4, ib = kb + 1;
       dacc = load_block16_sym<LD>(D, ib);
       f64x4 xa = {0.0, 0.0, 0.0, 0.0}, xb = {0.0, 0.0, 0.0, 0.0};
@@ -1156,7 +1161,7 @@ __device__ __forceinline__ void factor64_blocked(double* D, double* Tl, double* 
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) D[(B * ib + li) * LD + B * kb + lk + 4 * reg] = xt[reg];
       dacc = dacc - (xx + xy);
-    } else if (wave < 3) {
+    } else if (wave < 3 && !(VGG_F64_ABL & 4)) {
       const int ib = (wave < 3 - kb) ? kb + 1 + wave : wave - (3 - kb);      // kb+1 .. 3, then 0 .. kb-1
       double* X = (wave < 3 - kb) ? D : Tl;
       mm16([&](int i, int kk) { return X[(B * ib + i) * LD + B * kb + kk]; }, [&](int j, int kk) { return Tl[(B * kb + kk) * LD + B * kb + j]; },

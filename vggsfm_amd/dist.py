@@ -236,6 +236,8 @@ class ShardedBA:
             self.bufs.append(self.ws[off:off + 8 * cnt.value].view(torch.float64))
         if collectives is None and world_size > 1:
             collectives = _FunctionCollectives(all_reduce) if all_reduce is not None else Collectives(world_size)
+        # collectives handed in explicitly are used at world size 1 as well: a one-rank RCCL communicator runs the whole
+        # exchange sequence on the solver's buffers (tests/test_gpu_dist_rccl.py::test_rccl_one_rank_...)
         self.coll = collectives
         # reduce-scatter / all-gather views of the solver's own buffers (phase 4 pads, phase 6 reads the gathered slices)
         M = self.bufs[4].numel()
@@ -244,7 +246,7 @@ class ShardedBA:
         self._padded = self.ws[off4:off4 + 8 * world_size * chunk].view(torch.float64)
         self._mine = self.bufs[5][:chunk + 1]
         self._gathered = self.bufs[6][:world_size * (chunk + 1)]
-        self._in_place = world_size > 1 and isinstance(collectives, Collectives) and collectives.scatter
+        self._in_place = isinstance(collectives, Collectives) and collectives.scatter
 
     def begin(self):
         _lib.check(self.L.vgg_ba_begin(ctypes.byref(self.cp), ctypes.byref(self.co), _lib.ptr(self.ws),
@@ -255,7 +257,7 @@ class ShardedBA:
                                        _lib.stream_ptr()), "vgg_ba_phase")
 
     def iteration(self):
-        co = self.coll if self.world > 1 else None
+        co = self.coll
         self._phase(0)
         if co:
             co.sum_(self.bufs[0])

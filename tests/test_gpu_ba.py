@@ -284,6 +284,39 @@ def test_cholesky_flags_indefinite():
     assert int(fail.item()) == 1
 
 
+@pytest.mark.parametrize("n,pos,kind", [(200, 0, "neg"), (200, 3, "neg"), (200, 70, "neg"), (200, 199, "neg"), (350, 131, "zero"),
+                                        (350, 64, "nan"), (350, 17, "inf"), (1202, 1201, "neg"), (1202, 600, "rank"),
+                                        (257, 256, "neg")])
+def test_cholesky_single_launch_flags_bad_pivots(n, pos, kind):
+    """The single-launch factorisation (n >= 128, rhs behind the matrix: the BA path).  Round 4 took the per-pivot sign tests
+    out of the 16 x 16 diagonal routine: a non-positive or non-finite pivot is caught where it surfaces -- the scale
+    sqrt(d) of its column is NaN -- once per 16 columns.  Every way a pivot can be bad, at the first / an inner / the last
+    column of a 4-pivot group, of a 16-block and of the ragged last 64-block: the flag must come up, and the launch must end
+    (every hand-off flag is still published)."""
+    rng = np.random.default_rng(n + pos)
+    M = rng.normal(size=(n, n + 8))
+    A = M @ M.T / n + np.eye(n)
+    if kind == "neg":
+        A[pos, pos] = -3.0
+    elif kind == "zero":
+        A[pos, :] = 0.0
+        A[:, pos] = 0.0
+    elif kind == "nan":
+        A[pos, pos] = np.nan
+    elif kind == "inf":
+        A[pos, pos] = np.inf
+    else:                                                 # rank deficient: row pos = row pos - 1 (pivot = rounding noise or <= 0)
+        A[pos, :] = A[pos - 1, :]
+        A[:, pos] = A[:, pos - 1]
+        A[pos, pos] = A[pos - 1, pos - 1] - 1e-9
+    buf = D(np.concatenate([np.tril(A).ravel(), rng.normal(size=n)]))
+    fail = torch.zeros(1, dtype=torch.int32, device="cuda")
+    rc = _lib.lib().vgg_cholesky_solve(_lib.ptr(buf[:n * n]), _lib.ptr(buf[n * n:]), n, _lib.ptr(_chol_ws(n)), _lib.ptr(fail),
+                                       _lib.stream_ptr())
+    torch.cuda.synchronize()
+    assert rc == 0 and int(fail.item()) == 1, (n, pos, kind)
+
+
 CASES = [
     # S, N, camera, shared, options
     (6, 60, "SIMPLE_PINHOLE", False, "prep"),

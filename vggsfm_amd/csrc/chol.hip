@@ -1026,9 +1026,17 @@ __device__ __forceinline__ bool factor16_mfma(f64x4 acc, double* D, double* Tl, 
   for (int reg = 0; reg < 4; ++reg) accE[reg] = (li == lk + 4 * reg) ? 1.0 : 0.0;
   double xfin[4], yfin[4], rs[4], sd[4];
   double dlast = 1.0;
-  bool bad = false;
-  constexpr double HUGE_ = 1.7976931348623157e308;
   const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
+  // Round 4: the step is bound by its INSTRUCTION COUNT (one wavefront, ~135 instructions per four pivots), so the lane
+  // selections are multiply-adds with per-lane 0 / 1 constants instead of nested selects (exact: one term per lane is
+  // non-zero), and a non-positive or non-finite pivot is no longer caught pivot by pivot (eight compares, eight selects
+  // per step) but where it ends up anyway: the scale sqrt(d) of the lane's own column is NaN (rsq of d <= 0, 0 * inf,
+  // or a NaN handed down from an earlier pivot), tested once per 16 columns.  For a positive definite block the
+  // operations and their order are unchanged -- the factor is bit-identical.
+  const double k01 = (li == 1 && lk == 0) ? 1.0 : 0.0, k02 = (li == 2 && lk == 0) ? 1.0 : 0.0, k03 = (li == 3 && lk == 0) ? 1.0 : 0.0;
+  const double k12 = (li == 2 && lk == 1) ? 1.0 : 0.0, k13 = (li == 3 && lk == 1) ? 1.0 : 0.0, k23 = (li == 3 && lk == 2) ? 1.0 : 0.0;
+  const double kone = (li < 4 && lk == li) ? 1.0 : 0.0;
+  const double q0 = (lk == 0) ? 1.0 : 0.0, q1 = (lk == 1) ? 1.0 : 0.0, q2 = (lk == 2) ? 1.0 : 0.0, q3 = (lk == 3) ? 1.0 : 0.0;
 #pragma unroll
   for (int j0 = 0; j0 < 16; j0 += 4) {
     const int qq = j0 / 4;
@@ -1041,36 +1049,34 @@ __device__ __forceinline__ bool factor16_mfma(f64x4 acc, double* D, double* Tl, 
     const double p33 = readlane_f64(pa, j0 + 3 + 48);
     // the scale of this lane's column of the PREVIOUS step: one short chain per lane in the shadow of the matrix instructions
     if (j0 > 0) fast_rsqrt_sqrt(dlast, rs[qq - 1], sd[qq - 1]);
-    const double r0 = fast_rcp<1>((d0 > 0.0) ? d0 : 1.0);
+    const double r0 = fast_rcp<1>(d0);
     const double m10 = u10 * r0, m20 = u20 * r0, m30 = u30 * r0;
     const double d1 = p11 - u10 * m10;
     const double u21 = p21 - u20 * m10, u31 = p31 - u30 * m10;
-    const double r1 = fast_rcp<1>((d1 > 0.0) ? d1 : 1.0);
+    const double r1 = fast_rcp<1>(d1);
     const double m21 = u21 * r1, m31 = u31 * r1;
     const double d2 = (p22 - u20 * m20) - u21 * m21;
     const double u32 = (p32 - u30 * m20) - u31 * m21;
-    const double r2 = fast_rcp<1>((d2 > 0.0) ? d2 : 1.0);
+    const double r2 = fast_rcp<1>(d2);
     const double m32 = u32 * r2;
     const double d3 = ((p33 - u30 * m30) - u31 * m31) - u32 * m32;
-    const double r3 = fast_rcp<1>((d3 > 0.0) ? d3 : 1.0);
-    if (!(d0 > 0.0) || !(d0 < HUGE_) || !(d1 > 0.0) || !(d1 < HUGE_) || !(d2 > 0.0) || !(d2 < HUGE_) || !(d3 > 0.0) || !(d3 < HUGE_))
-      bad = true;
+    const double r3 = fast_rcp<1>(d3);
     // x_t = sum_k a_k W[k][t]:  W[k][t] = -sum_{k <= s < t} W[k][s] m_ts,  W[k][k] = 1
-    const double w01 = -m10, w12 = -m21, w23 = -m32;
     const double w02 = __builtin_fma(m10, m21, -m20), w13 = __builtin_fma(m21, m32, -m31);
     const double w03 = __builtin_fma(-w02, m32, __builtin_fma(m10, m31, -m30));
-    // operand lane (li = n, lk = k) carries W[k][n] (n < 4, k <= n), zero elsewhere
-    double wsel = 0.0;
-    wsel = (li == 0 && lk == 0) ? 1.0 : wsel;
-    wsel = (li == 1) ? (lk == 0 ? w01 : lk == 1 ? 1.0 : 0.0) : wsel;
-    wsel = (li == 2) ? (lk == 0 ? w02 : lk == 1 ? w12 : lk == 2 ? 1.0 : 0.0) : wsel;
-    wsel = (li == 3) ? (lk == 0 ? w03 : lk == 1 ? w13 : lk == 2 ? w23 : 1.0) : wsel;
+    // operand lane (li = n, lk = k) carries W[k][n] (n < 4, k <= n), zero elsewhere  (w01 = -m10, w12 = -m21, w23 = -m32;
+    // a form with the three late entries as ONE multiply-add behind m32 measured the same: the step is issue bound)
+    double wsel = __builtin_fma(-k01, m10, kone);
+    wsel = __builtin_fma(-k12, m21, wsel);
+    wsel = __builtin_fma(k02, w02, wsel);
+    wsel = __builtin_fma(-k23, m32, wsel);
+    wsel = __builtin_fma(k13, w13, wsel);
+    wsel = __builtin_fma(k03, w03, wsel);
     const f64x4 xt = __builtin_amdgcn_mfma_f64_16x16x4f64(wsel, pa, zero4, 0, 0, 0);
     const f64x4 yt = __builtin_amdgcn_mfma_f64_16x16x4f64(wsel, pe, zero4, 0, 0, 0);
     const double x = xt[0], y = yt[0];               // X[li][lk], Y[li][lk]
-    const double rsel = (lk == 0) ? r0 : (lk == 1) ? r1 : (lk == 2) ? r2 : r3;
-    const double dsel = (lk == 0) ? d0 : (lk == 1) ? d1 : (lk == 2) ? d2 : d3;
-    dlast = (dsel > 0.0) ? dsel : 1.0;
+    const double rsel = __builtin_fma(q3, r3, __builtin_fma(q2, r2, __builtin_fma(q1, r1, q0 * r0)));
+    dlast = __builtin_fma(q3, d3, __builtin_fma(q2, d2, __builtin_fma(q1, d1, q0 * d0)));
     xfin[qq] = x; yfin[qq] = y;
     if (j0 < 12) {
       const double xm = (li >= j0 + 4) ? x : 0.0;
@@ -1080,29 +1086,33 @@ __device__ __forceinline__ bool factor16_mfma(f64x4 acc, double* D, double* Tl, 
     }
   }
   fast_rsqrt_sqrt(dlast, rs[3], sd[3]);
+  bool badlane = false;
+  constexpr double HUGE_ = 1.7976931348623157e308;
   // (the upper triangle of the block in D is never read: it takes whatever the product left there)
 #pragma unroll
   for (int qq = 0; qq < 4; ++qq) {
     const int c = 4 * qq + lk;
+    badlane = badlane || !(sd[qq] > 0.0) || !(sd[qq] < HUGE_);
     Db[li * LD + c] = (li == c) ? sd[qq] : xfin[qq] * rs[qq];
     Tb[li * LD + c] = (li <= c) ? yfin[qq] * rs[qq] : 0.0;
   }
-  return bad;
+  return __any(badlane);
 }
 
 // slab(kb): called by wavefront 1 alone (all 64 lanes) once the 16 columns 16 kb .. 16 kb + 15 of T are final (kb = 0, 1, 2;
 // the last 16 columns are final on return): the caller hands them on while the factorisation goes on.
 #ifndef VGG_F64_ABL
 #define VGG_F64_ABL 0      // scripts/ubench/factor64_bench ablations: 1 no 16 x 16 factorisation, 2 no trailing updates, 4 no
-#endif                     // side panels, 8 no critical panel, 16 no zero fill of T
+#endif                     // side panels, 8 no critical panel
 template <class FS>
 __device__ __forceinline__ void factor64_blocked(double* D, double* Tl, double* scr, int32_t* fail, FS slab) {
   constexpr int LD = DFB + 1, B = 16;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (!(VGG_F64_ABL & 16))
-    for (int e = tid; e < DFB * DFB; e += 256) Tl[(e / DFB) * LD + (e % DFB)] = 0.0;
-  __syncthreads();
+  // (Round 4: no zero fill of Tl and no barrier here -- 0.6 us on the pivot chain per 64 columns.  A block of T above the
+  //  diagonal is STORED by its first update (step k = its block row, where the identity's block is still zero); the blocks
+  //  below the diagonal are never written and never read from LDS: whoever hands T on writes zeros for them.  The caller's
+  //  barrier after filling D is the one the first loads below need.)
   bool bad = false;
   // D[ib][jb] -= L[ib][k] L[jb][k]^T   /   E[ib][jb] -= E[ib][k] L[jb][k]^T   (16 x 16 blocks; E = the rows of the identity in Tl)
   auto trail_A = [&](int ib, int jb, int k) __attribute__((always_inline)) {
@@ -1110,8 +1120,12 @@ __device__ __forceinline__ void factor64_blocked(double* D, double* Tl, double* 
          [&](int i, int j, double x) { D[(B * ib + i) * LD + B * jb + j] -= x; });
   };
   auto trail_E = [&](int ib, int jb, int k) __attribute__((always_inline)) {
-    mm16([&](int i, int kk) { return Tl[(B * ib + i) * LD + B * k + kk]; }, [&](int j, int kk) { return D[(B * jb + j) * LD + B * k + kk]; },
-         [&](int i, int j, double x) { Tl[(B * ib + i) * LD + B * jb + j] -= x; });
+    if (k == ib)
+      mm16([&](int i, int kk) { return Tl[(B * ib + i) * LD + B * k + kk]; }, [&](int j, int kk) { return D[(B * jb + j) * LD + B * k + kk]; },
+           [&](int i, int j, double x) { Tl[(B * ib + i) * LD + B * jb + j] = -x; });
+    else
+      mm16([&](int i, int kk) { return Tl[(B * ib + i) * LD + B * k + kk]; }, [&](int j, int kk) { return D[(B * jb + j) * LD + B * k + kk]; },
+           [&](int i, int j, double x) { Tl[(B * ib + i) * LD + B * jb + j] -= x; });
   };
   f64x4 dacc = {0.0, 0.0, 0.0, 0.0};               // wavefront 0: the diagonal block it is about to factor
   if (wave == 0) dacc = load_block16_sym<LD>(D, 0);
@@ -1395,7 +1409,7 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int i = 4 * q + (lane >> 4), j = 16 * kb + (lane & 15);
-        st_agent(&Tg[i * DFB + j], sh.T[i * LD + j]);
+        st_agent(&Tg[i * DFB + j], (i < 16 * (kb + 1)) ? sh.T[i * LD + j] : 0.0);      // (below the diagonal block: zero)
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) __hip_atomic_store(&tready[bc], kb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

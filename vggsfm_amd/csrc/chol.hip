@@ -1503,6 +1503,11 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
         if (i >= vr || j >= vr) v = (i == j) ? 1.0 : 0.0;
         sh.D[i * LD + j] = v;
       }
+  // (Round 4, measured and rejected: raising this flag from inside the factorisation, behind its first 16 x 16 step, where the
+  //  drain of the X stores is free -- 0.7 us off the factor path, but the flag is 2 us late for tile (r+1, r), whose last
+  //  update + first three slab products are a second chain of the same length per block column (T_c out -> tile (c+2,c) 3.2 us
+  //  -> last update of tile (c+2,c+1) 5.9 us -> its slabs 0..2 4.7 us = the 13.9 us of the factor path): n = 1202 0.273 ->
+  //  0.294 ms.  Either chain alone no longer sets the step.)
   df_publish(&ready[(size_t)r * nbk + c]);               // (+ the barrier between the reads of X in sh.T and the factorisation)
   DF_STAMP(3);
   DF_STAMP_AT(dtile, 1);                                 // diagonal tile r: updates applied

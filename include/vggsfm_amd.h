@@ -333,6 +333,12 @@ int vgg_ba_tuning(int lanes_per_point, int long_tracks, int cam_workgroups, int 
  * camera-major evaluation of the projections per iteration; 0 = the camera pass cam_pass<RHS> (always used with 7 x 7 / 8 x 8
  * blocks).  Both compute the same system up to the order of its sums.  Requires entries[e][0] = the entry's point. */
 int vgg_ba_set_tile_rhs(int enable);
+/* Where the back-substitution of the points (point_step_kernel) takes E^T F dy from, again with 6 x 6 tile blocks: 0 (default;
+ * VGG_STEP_FACTORS seeds it) = a second evaluation of every projection and its Jacobians; 1 = from the compressed Schur
+ * factors the point pass left in the segment buffer (one 96-byte record per observation; the model cost change's camera
+ * share from the cameras' J^T J, J^T r); 2 = every other observation of a lane from its factor.  Same step up to rounding;
+ * 1 and 2 measured slower on gfx950 (ba.hip, point_step_kernel) and are kept for measurements. */
+int vgg_ba_set_step_from_factors(int enable);
 int vgg_ba_profile(int enable, int max_launches_per_kernel);
 int vgg_ba_profile_read(int kernel_id, double* total_ms, int* launches, int reset);
 

@@ -55,11 +55,15 @@ def main():
             os.environ.clear()
             os.environ.update(base_env)
             L.vgg_ba_set_tile_rhs(1)
+            L.vgg_ba_set_step_from_factors(0)
             coll = None
             for kv in filter(None, envs.split(",")):
                 k, _, val = kv.partition("=")
                 if k == "TILE_RHS":                        # (process-wide library switch, not an environment variable here)
                     L.vgg_ba_set_tile_rhs(int(val))
+                    continue
+                if k == "STEP_FACTORS":
+                    L.vgg_ba_set_step_from_factors(int(val))
                     continue
                 if k == "RCCL":
                     import torch.distributed as dist

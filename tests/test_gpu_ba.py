@@ -274,6 +274,39 @@ def test_ba_tile_rhs_matches_camera_pass(S, N, cam, shared, rf, rk):
             np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-8, atol=1e-8)
 
 
+@pytest.mark.parametrize("S,N,cam,shared,rf,rk,mode", [(60, 3000, "SIMPLE_RADIAL", True, True, True, 1), (40, 2500, "SIMPLE_PINHOLE", True, True, True, 1),
+                                                       (24, 1500, "SIMPLE_RADIAL", True, True, False, 2), (90, 2500, "SIMPLE_RADIAL", False, False, False, 1),
+                                                       (200, 12000, "SIMPLE_RADIAL", True, True, True, 2)])
+def test_ba_step_from_factors_matches_evaluation(S, N, cam, shared, rf, rk, mode):
+    """Round 4, opt-in (vgg_ba_set_step_from_factors; measured slower, so not the default): the points' back-substitution
+    takes E^T F dy from the compressed Schur factors in the segment buffer and the model cost change's camera share from the
+    cameras' J^T J, J^T r, instead of re-evaluating every projection with its Jacobians.  Same step up to rounding: same
+    accept / reject pattern, costs, and parameters as the default."""
+    sc = make_scene(S, N, cam, shared_camera=shared, seed=43)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=43)
+    opt = BundleAdjustmentOptions()
+    opt.refine_focal_length, opt.refine_extra_params = rf, rk
+    opt.solver_options.max_num_iterations = 10
+    L = _lib.lib()
+
+    def solve():
+        return BA.bundle_adjustment(D(pts0), D(ext0), D(K0), D(sc.tracks), D(sc.mask), None, D(extra0), shared, cam, opt)
+    try:
+        assert L.vgg_ba_set_step_from_factors(0) == 0
+        ref = solve()
+        assert L.vgg_ba_set_step_from_factors(mode) == 0
+        a = solve()
+    finally:
+        L.vgg_ba_set_step_from_factors(0)
+    assert a[4]["num_iterations"] == ref[4]["num_iterations"]
+    for ia, ib in zip(a[4]["iterations"], ref[4]["iterations"]):
+        assert ia["successful"] == ib["successful"] and abs(ia["cost"] - ib["cost"]) <= 1e-10 * ib["cost"], (ia, ib)
+        assert abs(ia["relative_decrease"] - ib["relative_decrease"]) <= 1e-7 * max(abs(ib["relative_decrease"]), 1e-3)
+    for x, y in zip(a[:4], ref[:4]):
+        if x is not None:
+            np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-8, atol=1e-8)
+
+
 def test_cholesky_flags_indefinite():
     A = np.eye(40)
     A[17, 17] = -1.0

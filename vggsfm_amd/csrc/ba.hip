@@ -57,6 +57,9 @@ constexpr int kGroup = 16;       // cameras per Schur tile side
 #ifndef VGG_PP_OCC
 #define VGG_PP_OCC 2
 #endif
+#ifndef VGG_PS_OCC_FY
+#define VGG_PS_OCC_FY 2      // point_step_kernel without the Jacobian sweep
+#endif
 #ifndef VGG_PS_OCC
 #define VGG_PS_OCC 2
 #endif
@@ -119,7 +122,7 @@ struct Ws {  // device workspace carve-up (pointers into the caller's buffer)
   double* pk_mine;            // [ceil(count / W) + 1] this rank's reduced slice + its local gradient maximum (reduce-scatter
                               //   output = all-gather input)
   double* pk_gathered;        // [W (ceil(count / W) + 1)] the all-gather output, read in place by the unpack (phase 6)
-  double* cam_part;           // [C+1][2] step^2 / x^2 of camera-side parameters
+  double* cam_part;           // [C+1][3] step^2 / x^2 of camera-side parameters, camera-side share of the model cost change
   double* cam_split;          // [C][kCamSplitMax][kCamNV] partial sums of the split camera passes
   double* Y;                  // [num_segments][16][BDt*3] zero-padded per-observation Schur factors s_c o (F^T E G_p)
   size_t y_bytes;
@@ -132,6 +135,7 @@ struct Ws {  // device workspace carve-up (pointers into the caller's buffer)
   double *Zp, *rz_part, *part_Q;
   double* rz;                 // [ceil(C / 16)][96 x 3] rz_part summed over the chunks of a group's diagonal tile (tile_reduce_kernel)
   int tile_rhs;               // 1: cam_pass<RHS> is not launched, its sums come from the diagonal tile launch + point_pass
+  int step_from_factors;      // 1: point_step_kernel takes E^T F dy from the compressed Schur factors (no Jacobian sweep)
   size_t lin_count, sys_count, total_bytes;
 };
 
@@ -183,7 +187,7 @@ static Ws carve(const Dims& d, int max_iters, int num_chunks, int num_segments, 
   w.T = (double*)take(8ull * d.C * d.BDp * (1 + d.kdsh));
   w.part_B = (double*)take(8ull * kMaxWG);
   w.part_F = (double*)take(8ull * kMaxWG * 4);
-  w.cam_part = (double*)take(8ull * (d.C + 1) * 2);
+  w.cam_part = (double*)take(8ull * (d.C + 1) * 3);
   w.cam_split = (double*)take(8ull * (size_t)d.C * kCamSplitMax * kCamNV);
   // + one all-zero segment behind the last real one (target of the tile kernel's loads past the end of a list)
   w.y_bytes = 8ull * ((size_t)(num_segments > 0 ? num_segments : 0) + 1) * kGroup * y_slot_doubles(d);
@@ -614,10 +618,10 @@ __global__ __launch_bounds__(256) void prep_kernel(DevProblem pb, Ws w, vgg_ba_o
 // measured per LM iteration, point_pass + point_step -- c2 (mean 12.5 observations) 64: 0.112, 32: 0.075, 16: 0.065,
 // 8: 0.059 ms; c3 (mean 50) 64: 0.674, 32: 0.549, 16: 0.499, 8: 0.535 ms; one c4 shard (mean 100) 32: 0.509, 16: 0.544 ms.
 // overrides of the automatic launch choices (vgg_ba_tuning; the environment variables seed them): 0 / -1 = automatic
-struct Tuning { int lpp, longt, cam_wgs, point_wgs, tile_rhs; };
+struct Tuning { int lpp, longt, cam_wgs, point_wgs, tile_rhs, step_factors; };
 static Tuning g_tuning = [] {
   auto env = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
-  return Tuning{env("VGG_LPP", 0), env("VGG_PP_LONGT", -1), env("VGG_CAM_WGS", 0), env("VGG_POINT_WGS", 0), env("VGG_TILE_RHS", 1)};
+  return Tuning{env("VGG_LPP", 0), env("VGG_PP_LONGT", -1), env("VGG_CAM_WGS", 0), env("VGG_POINT_WGS", 0), env("VGG_TILE_RHS", 1), env("VGG_STEP_FACTORS", 0)};
 }();
 static int lanes_per_point(int P, int O) {
   const int forced = g_tuning.lpp;
@@ -1729,16 +1733,54 @@ __global__ void cam_update_kernel(DevProblem pb, Ws w) {
     const int np = (d.model == kSimpleRadial) ? 4 : 3;
     for (int k = 0; k < 4; ++k) { w.cand_intr[4 * a + k] = in4[k]; if (intr_var && k < np) xn += pb.intr[4 * a + k] * pb.intr[4 * a + k]; }
   }
-  w.cam_part[2 * c] = step;
-  w.cam_part[2 * c + 1] = xn;
+  // Model cost change, the part that is a function of the camera-side step alone (compressed Schur factors: point_step_kernel
+  // no longer re-evaluates the Jacobians): sum over the observations of [F dy . r - |F dy|^2 / 2] = sum over the cameras of
+  // dy_c . g_c - dy_c^T U_c dy_c / 2, with U_c = sum F^T F and g_c = sum F^T r of the linearisation in place (cam_pass
+  // <linearize>, all-reduced over the ranks) and dy_c the camera's pose step followed by the step of its intrinsics block.
+  double mc = 0.0;
+  if (c < d.C && w.step_from_factors) {
+    constexpr int BD = 6 + KD;
+    double dv[BD];
+    for (int k = 0; k < 6; ++k) dv[k] = w.active[6 * c + k] ? w.scale_c[6 * c + k] * w.rhs[6 * c + k] : 0.0;
+    const int ai = d.shared ? 0 : c;
+    for (int k = 0; k < KD; ++k) { const int j = 6 * d.C + KD * ai + k; dv[6 + k] = w.active[j] ? w.scale_c[j] * w.rhs[j] : 0.0; }
+    const double* U = w.U + (size_t)c * BD * BD;
+    const double* g = w.g + (size_t)c * BD;
+    double lin = 0.0, quad = 0.0;
+    for (int i = 0; i < BD; ++i) {
+      double ui = 0.0;
+      for (int k = 0; k < BD; ++k) ui += U[i * BD + k] * dv[k];
+      quad += dv[i] * ui;
+      lin += dv[i] * g[i];
+    }
+    mc = lin - 0.5 * quad;
+  }
+  w.cam_part[3 * c] = step;
+  w.cam_part[3 * c + 1] = xn;
+  w.cam_part[3 * c + 2] = mc;
 }
 
 // back-substitution, model cost change, candidate point and candidate cost: LPP lanes per point (see point_pass_kernel)
-template <int KD, bool LDSCAM, int LPP, bool LONGT = false>
-__global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem pb, Ws w) {
+// FYM = 1 (round 4, OPT-IN: vgg_ba_set_step_from_factors / VGG_STEP_FACTORS; measured SLOWER, see below): the tile blocks
+// are 6 x 6 and the segment buffer holds the compressed Schur factors N = Jw^T (E G), 2 a of every observation
+// (point_pass_kernel, CY).  Then E^T F dy -- all this kernel needs of the Jacobians -- is there already:
+// F_pose dy = Jw (dy_t - 2 a x dy_w), so G^T sum E^T F dy = sum N^T (dy_t - 2 a x dy_w): one 96-byte record and ~25
+// multiply-adds per observation instead of a second evaluation of the projection and its Jacobians (~150 FP64 operations);
+// the shared intrinsics' share is Ms (dy_a / scale) per point, and the part of the model cost change that only depends on
+// the camera step comes from the cameras' U, g (cam_update_kernel).  The candidate's residuals are still evaluated here.
+// Same step to rounding (tests/test_gpu_ba.py::test_ba_step_from_factors_matches_evaluation).  c3, same box
+// (profiles/r04_ab_step_from_factors_c3.jsonl): 0.143 ms re-evaluating (210 VGPRs, 2 wavefronts / SIMD, FP64 issue bound),
+// 0.170 ms from the factors (160 VGPRs, 3 wavefronts / SIMD): a point's records lie in as many segments as it has
+// observations, each 96-byte record touches 1.5 cache lines on average -- 5 M x 192 B = 0.96 GB of line traffic in 0.17 ms
+// is the memory system's limit for this access pattern.  FYM = 2, every other sweep of a lane from the factors so that
+// both pipes have work: 0.147 ms -- no better than re-evaluating.  So the default stays 0.
+template <int KD, bool LDSCAM, int LPP, bool LONGT = false, int FYM = 0>
+__global__ __launch_bounds__(256, FYM == 1 ? VGG_PS_OCC_FY : VGG_PS_OCC) void point_step_kernel(DevProblem pb, Ws w) {
+  constexpr bool FY = FYM == 1;                  // every observation from its factor
+  constexpr bool HY = FYM == 2;                  // (measurement only) odd sweeps from the factors, even sweeps re-evaluated
   constexpr int BD = 6 + KD;
   __shared__ double red[4][4];
-  extern __shared__ double cam_cache[];   // LDSCAM: R[9C] t[3C] dy_pose[6C] cand R[9C] cand_t[3C] flags[C]
+  extern __shared__ double cam_cache[];   // LDSCAM: R[9C] t[3C] dy_pose[6C] cand R[9C] cand_t[3C] flags[C]   (FY: dy, cand R, cand t only)
   if (w.ctl->done) return;
   const Dims& d = pb.d;
   constexpr int PPW = 64 / LPP;
@@ -1747,21 +1789,25 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
   const int nw = gridDim.x * 4 * PPW;
   double s_cost = 0, s_mcc = 0, s_step = 0, s_xn = 0;
   const double* lq = cam_cache;                  // rotation matrices [9C]
-  const double* lt = lq + 9 * d.C;
-  const double* ldy = lt + 3 * d.C;
+  const double* lt = lq + (FY ? 0 : 9 * d.C);
+  const double* ldy = lt + (FY ? 0 : 3 * d.C);
   const double* lcq = ldy + 6 * d.C;             // rotation matrices of the candidate [9C]
   const double* lct = lcq + 9 * d.C;
   const double* lfl = lct + 3 * d.C;
   if (LDSCAM) {
+    double* cc = cam_cache;
     for (int i = threadIdx.x; i < d.C; i += 256) {
-      quat_to_R(pb.cam_q + 4 * i, cam_cache + 9 * i);
-      quat_to_R(w.cand_q + 4 * i, cam_cache + 18 * d.C + 9 * i);
-      cam_cache[30 * d.C + i] = pb.cam_const ? (double)pb.cam_const[i] : 0.0;
+      if (!FY) {
+        quat_to_R(pb.cam_q + 4 * i, cc + 9 * i);
+        cc[30 * d.C + i] = pb.cam_const ? (double)pb.cam_const[i] : 0.0;
+      }
+      quat_to_R(w.cand_q + 4 * i, cc + (lcq - cam_cache) + 9 * i);
     }
-    for (int i = threadIdx.x; i < 3 * d.C; i += 256) { cam_cache[9 * d.C + i] = pb.cam_t[i]; cam_cache[27 * d.C + i] = w.cand_t[i]; }
-    for (int i = threadIdx.x; i < 6 * d.C; i += 256) cam_cache[12 * d.C + i] = w.dy[i];
+    for (int i = threadIdx.x; i < 3 * d.C; i += 256) { if (!FY) cc[9 * d.C + i] = pb.cam_t[i]; cc[(lct - cam_cache) + i] = w.cand_t[i]; }
+    for (int i = threadIdx.x; i < 6 * d.C; i += 256) cc[(ldy - cam_cache) + i] = w.dy[i];
     __syncthreads();
   }
+  (void)lfl;
   // same software pipeline over the points of a wavefront as in point_pass_kernel
   int p = (blockIdx.x * 4 + wave) * PPW + sub;
   constexpr int NPF = LONGT ? 4 : 2;             // prefetched observations per lane (see point_pass_kernel)
@@ -1778,7 +1824,7 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
     n_o0 = pb.row_ptr[p]; n_o1 = pb.row_ptr[p + 1];
     n_X0 = pb.pts[3 * p]; n_X1 = pb.pts[3 * p + 1]; n_X2 = pb.pts[3 * p + 2];
     n_ptc = pb.pt_const ? pb.pt_const[p] != 0 : false;
-    n_pf.template load<false>(pb.obs_cam, pb.obs_uv, nullptr, n_o0, n_o1, LPP, sl);
+    n_pf.template load<(FYM != 0)>(pb.obs_cam, pb.obs_uv, pb.obs_slot, n_o0, n_o1, LPP, sl);
     if (p + nw < d.P) {
       const int pm = p + nw;
       m_o0 = pb.row_ptr[pm]; m_o1 = pb.row_ptr[pm + 1];
@@ -1794,7 +1840,7 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
     {
       // stage 1 -> current of the next iteration: observations of point p + nw (its bounds arrived an iteration ago)
       n_o0 = m_o0; n_o1 = m_o1; n_X0 = m_X0; n_X1 = m_X1; n_X2 = m_X2; n_ptc = m_ptc;
-      if (p + nw < d.P) n_pf.template load<false>(pb.obs_cam, pb.obs_uv, nullptr, n_o0, n_o1, LPP, sl);
+      if (p + nw < d.P) n_pf.template load<(FYM != 0)>(pb.obs_cam, pb.obs_uv, pb.obs_slot, n_o0, n_o1, LPP, sl);
       // stage 2: bounds / coordinates of point p + 2 nw
       const int pm = p + 2 * nw;
       if (pm < d.P) {
@@ -1810,8 +1856,22 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
     // and with (V + D^2) ys = g - t3 and (V + D^2)^-1 = G G^T (point_pass):  ys^T (g - t3) = |G^-1 ys|^2 =: |z|^2, so
     //   = sum [F dy . r - |F dy|^2 / 2]  +  |z|^2 / 2  +  ys^T D^2 ys / 2.
     // The bracket is accumulated in the first sweep; the second sweep only evaluates the candidate's residuals.
-    for (int o = o0 + sl; o < o1; o += LPP) {
-      const int pass = (o - o0) / LPP;
+    double uf[3] = {0, 0, 0};                      // G^T sum E^T F_pose dy over the observations taken from their factors
+    auto from_factor = [&](int pass, int o) __attribute__((always_inline)) {
+      const int c = f_pf.cam(pass, pb.obs_cam, o);
+      const int slot = f_pf.slot(pass, pb.obs_slot, o);
+      const double2* y = reinterpret_cast<const double2*>(w.Y + (size_t)slot * kYc);
+      const double2 n01 = y[0], n23 = y[1], n45 = y[2], n67 = y[3], n8a = y[4], a12 = y[5];
+      const double* dyc = LDSCAM ? ldy + 6 * c : w.dy + 6 * c;
+      const double a0 = n8a.y, a1 = a12.x, a2 = a12.y;                 // 2 a
+      const double v0 = dyc[3] - (a1 * dyc[2] - a2 * dyc[1]);
+      const double v1 = dyc[4] - (a2 * dyc[0] - a0 * dyc[2]);
+      const double v2 = dyc[5] - (a0 * dyc[1] - a1 * dyc[0]);
+      uf[0] += n01.x * v0 + n23.y * v1 + n67.x * v2;                   // N row-major: N[i][m] = rec[3 i + m]
+      uf[1] += n01.y * v0 + n45.x * v1 + n67.y * v2;
+      uf[2] += n23.x * v0 + n45.y * v1 + n8a.x * v2;
+    };
+    auto evaluated = [&](int pass, int o) __attribute__((always_inline)) {
       const int c = f_pf.cam(pass, pb.obs_cam, o);
       const float2 uv = f_pf.uv(pass, pb.obs_uv, o);
       const int a = d.shared ? 0 : c;
@@ -1825,21 +1885,39 @@ __global__ __launch_bounds__(256, VGG_PS_OCC) void point_step_kernel(DevProblem 
       double fy0 = 0, fy1 = 0;
 #pragma unroll
       for (int k = 0; k < 6; ++k) { const double v = LDSCAM ? ldy[6 * c + k] : w.dy[6 * c + k]; fy0 += F[k] * v; fy1 += F[BD + k] * v; }
+      if (!HY) {                                   // (HY: the intrinsics' share comes from Ms for every observation)
 #pragma unroll
-      for (int k = 0; k < KD; ++k) { const double v = w.dy[6 * d.C + KD * a + k]; fy0 += F[6 + k] * v; fy1 += F[BD + 6 + k] * v; }
+        for (int k = 0; k < KD; ++k) { const double v = w.dy[6 * d.C + KD * a + k]; fy0 += F[6 + k] * v; fy1 += F[BD + 6 + k] * v; }
+      }
       t3[0] += E[0] * fy0 + E[3] * fy1; t3[1] += E[1] * fy0 + E[4] * fy1; t3[2] += E[2] * fy0 + E[5] * fy1;
-      s_mcc += fy0 * (r[0] - 0.5 * fy0) + fy1 * (r[1] - 0.5 * fy1);
+      if (!HY) s_mcc += fy0 * (r[0] - 0.5 * fy0) + fy1 * (r[1] - 0.5 * fy1);      // (HY / FY: from the cameras' U, g)
+    };
+    for (int o = o0 + sl; o < o1; o += LPP) {
+      const int pass = (o - o0) / LPP;
+      if (FY || (HY && (pass & 1))) from_factor(pass, o);
+      else evaluated(pass, o);
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) t3[i] = group_sum<LPP>(t3[i]);
     const double* Gp = w.G + 6 * (size_t)p;
     const double G00 = Gp[0], G01 = Gp[1], G02 = Gp[2], G11 = Gp[3], G12 = Gp[4], G22 = Gp[5];
-    // ys = hs - G G^T t3
-    const double u0 = G00 * t3[0], u1 = G01 * t3[0] + G11 * t3[1], u2 = G02 * t3[0] + G12 * t3[1] + G22 * t3[2];
+    // ys = hs - G (G^T t3 + uf)   (the shared intrinsics add Ms (dy_a / scale_a) when factors are used)
+    double u0 = 0, u1 = 0, u2 = 0;
+    if (!FY) { u0 = G00 * t3[0]; u1 = G01 * t3[0] + G11 * t3[1]; u2 = G02 * t3[0] + G12 * t3[1] + G22 * t3[2]; }
+    if (FYM != 0) { u0 += group_sum<LPP>(uf[0]); u1 += group_sum<LPP>(uf[1]); u2 += group_sum<LPP>(uf[2]); }
     double ys[3];
     ys[0] = w.hs[3 * p] - (G00 * u0 + G01 * u1 + G02 * u2);
     ys[1] = w.hs[3 * p + 1] - (G11 * u1 + G12 * u2);
     ys[2] = w.hs[3 * p + 2] - (G22 * u2);
+    if constexpr (FYM != 0 && KD > 0) {
+      const double* Msp = w.Ms + (size_t)p * 3 * KD;
+#pragma unroll
+      for (int m = 0; m < KD; ++m) {
+        const int j = 6 * d.C + m;
+        const double ds = w.active[j] ? w.rhs[j] : 0.0;
+        ys[0] -= Msp[3 * m] * ds; ys[1] -= Msp[3 * m + 1] * ds; ys[2] -= Msp[3 * m + 2] * ds;
+      }
+    }
     const double Xn[3] = {X[0] - ys[0], X[1] - ys[1], X[2] - ys[2]};
     if (sl == 0) {
       w.cand_pts[3 * (size_t)p] = Xn[0]; w.cand_pts[3 * (size_t)p + 1] = Xn[1]; w.cand_pts[3 * (size_t)p + 2] = Xn[2];
@@ -1887,9 +1965,9 @@ __global__ __launch_bounds__(256) void reduce_step_kernel(Ws w, int nparts) {
 __global__ __launch_bounds__(64) void control_kernel(Ws w, vgg_ba_options opt, int C) {
   Ctl* c = w.ctl;
   if (c->done) { if (threadIdx.x == 0) c->accept = 0; return; }   // (no-op iterations behind the end must not commit again)
-  double step_c = 0, xn_c = 0;
-  for (int i = threadIdx.x; i <= C; i += 64) { step_c += w.cam_part[2 * i]; xn_c += w.cam_part[2 * i + 1]; }
-  step_c = wave_sum(step_c); xn_c = wave_sum(xn_c);
+  double step_c = 0, xn_c = 0, mcc_c = 0;
+  for (int i = threadIdx.x; i <= C; i += 64) { step_c += w.cam_part[3 * i]; xn_c += w.cam_part[3 * i + 1]; mcc_c += w.cam_part[3 * i + 2]; }
+  step_c = wave_sum(step_c); xn_c = wave_sum(xn_c); mcc_c = wave_sum(mcc_c);
   if (threadIdx.x != 0) return;
   const int it = c->iteration;
   vgg_ba_iteration li;
@@ -1897,7 +1975,7 @@ __global__ __launch_bounds__(64) void control_kernel(Ws w, vgg_ba_options opt, i
   li.step_norm = 0; li.relative_decrease = 0; li.radius = c->radius;
   c->accept = 0;
   const double cand_cost = 0.5 * w.stepsum[0];
-  const double mcc = w.stepsum[1];
+  const double mcc = w.stepsum[1] + mcc_c;         // (points' share, summed over the ranks) + (cameras' share, replicated)
   const double step_norm = sqrt(w.stepsum[2] + step_c);
   const double x_norm = sqrt(w.stepsum[3] + xn_c);
   c->cand_cost = cand_cost; c->mcc = mcc; c->step_norm = step_norm;
@@ -2195,11 +2273,18 @@ static int phase_step(const Launch& L) {
     auto launch = [&](auto lpp) {
       constexpr int LPP = decltype(lpp)::value;
       const bool longt = long_tracks(LPP, L.d.P, L.d.O);
-      if (longt && LPP <= 32) {
-        if (cam_lds <= 64 * 1024) point_step_kernel<KD, true, LPP, (LPP <= 32)><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w);
-        else point_step_kernel<KD, false, LPP, (LPP <= 32)><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w);
-      } else if (cam_lds <= 64 * 1024) point_step_kernel<KD, true, LPP><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w);
-      else point_step_kernel<KD, false, LPP><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w);
+      auto go = [&](auto fy) {
+        constexpr int FY = decltype(fy)::value;
+        const size_t lds = FY == 1 ? sizeof(double) * 18 * (size_t)d.C : cam_lds;
+        if (longt && LPP <= 32) {
+          if (lds <= 64 * 1024) point_step_kernel<KD, true, LPP, (LPP <= 32), FY><<<L.wgB, 256, lds, L.st>>>(L.dp, L.w);
+          else point_step_kernel<KD, false, LPP, (LPP <= 32), FY><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w);
+        } else if (lds <= 64 * 1024) point_step_kernel<KD, true, LPP, false, FY><<<L.wgB, 256, lds, L.st>>>(L.dp, L.w);
+        else point_step_kernel<KD, false, LPP, false, FY><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w);
+      };
+      if (L.w.step_from_factors == 1) go(std::integral_constant<int, 1>{});
+      else if (L.w.step_from_factors == 2) go(std::integral_constant<int, 2>{});
+      else go(std::integral_constant<int, 0>{});
     };
     if (L.lpp == 8) launch(std::integral_constant<int, 8>{});
     else if (L.lpp == 16) launch(std::integral_constant<int, 16>{});
@@ -2255,6 +2340,7 @@ static int make_launch(const vgg_ba_problem* pb, const vgg_ba_options* opt, void
   // reduced right-hand side from the diagonal tile launch instead of cam_pass<RHS>: compressed 6 x 6 tile blocks (shared or
   // constant intrinsics), one tile batch (the overlap mode needs the right-hand side before its later batches have run)
   L->w.tile_rhs = (g_tuning.tile_rhs && (L->d.shared || L->d.kd == 0) && pb->num_chunks > 0 && pb->num_tile_batches == 1) ? 1 : 0;
+  L->w.step_from_factors = (L->d.shared || L->d.kd == 0) ? g_tuning.step_factors : 0;      // (compressed factors in the segment buffer)
   L->cam_q = pb->cam_q; L->cam_t = pb->cam_t; L->intr = pb->intr; L->pts = pb->pts;
   return VGG_OK;
 }
@@ -2311,12 +2397,17 @@ int vgg_ba_tuning(int lanes_per_point, int long_tracks, int cam_workgroups, int 
   if (!(lanes_per_point == 0 || lanes_per_point == 8 || lanes_per_point == 16 || lanes_per_point == 32 || lanes_per_point == 64))
     return VGG_ERR_INVALID_ARGUMENT;
   vgg::g_tuning = vgg::Tuning{lanes_per_point, long_tracks < 0 ? -1 : (long_tracks ? 1 : 0), cam_workgroups > 0 ? cam_workgroups : 0,
-                              point_workgroups > 0 ? point_workgroups : 0, vgg::g_tuning.tile_rhs};
+                              point_workgroups > 0 ? point_workgroups : 0, vgg::g_tuning.tile_rhs, vgg::g_tuning.step_factors};
   return VGG_OK;
 }
 
 int vgg_ba_set_tile_rhs(int enable) {
   vgg::g_tuning.tile_rhs = enable ? 1 : 0;
+  return VGG_OK;
+}
+
+int vgg_ba_set_step_from_factors(int enable) {
+  vgg::g_tuning.step_factors = (enable == 1 || enable == 2) ? enable : 0;
   return VGG_OK;
 }
 

@@ -1081,6 +1081,9 @@ __device__ long long g_tile_trace[2048 * 4 * 8];   // [workgroup][wave][batches,
 #ifndef VGG_TILE_PRIO
 #define VGG_TILE_PRIO 2              // wave priority: 2 = raised outside the matrix phase (staging, LDS writes, barrier): a wavefront
 #endif                               // gets back to its matrix instructions sooner (round 3: off-diagonal launch 0.620 -> 0.606 ms); 1 = raised inside
+#ifndef VGG_DIAG_PARITY
+#define VGG_DIAG_PARITY 1           // diagonal tiles: sub-tiles dealt to the wavefronts by parity class (0: every fourth, round 3)
+#endif
 #ifndef VGG_NO_SKIP
 #define VGG_NO_SKIP 0               // profiling builds: 1 = every sub-tile of every batch runs (no presence skipping)
 #endif
@@ -1425,6 +1428,78 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
       for (int j = 0; j < NH; ++j)
         if (wr + 2 * i < NT && wc + 2 * j < NT) store_subtile(wr + 2 * i, wc + 2 * j, acc[i][j]);
   } else {
+#if VGG_DIAG_PARITY
+    // diagonal tile (A == B, symmetric): only the NT (NT + 1) / 2 sub-tiles of the lower triangle are computed.  Round 4: a
+    // wavefront owns a PARITY CLASS of them -- rows wr + 2 i, columns wc + 2 j, row block >= column block -- like the
+    // off-diagonal variant, instead of every fourth one of the row-by-row enumeration: its sub-tiles then share their row
+    // and column operands (3..6 LDS reads per K step for 3..6 matrix instructions; dealt round-robin every matrix instruction
+    // fetched its own two: 10..12 reads), and the classes still thin out alike under a run of absent cameras.  The classes
+    // (0,0), (1,1), (0,1), (1,0) hold 6, 6, 3 and 6 sub-tiles at NT = 6.
+    // With the stager / helper split of the compressed tiles (TR) the class follows the role, so that each of the two loop
+    // bodies needs the accumulators i >= j only (six: the 128-register budget of four wavefronts per SIMD): stagers 0, 1
+    // take the classes (0,0), (1,1) -- column blocks = row blocks, ONE operand set --, the helpers (0,1) -- three sub-tiles,
+    // the wavefront with the 64-row share of the right-hand side -- and (1,0).
+    const int mrole = wave;
+    const int wr = (mrole == 1 || mrole == 3) ? 1 : 0, wc = (mrole == 1 || mrole == 2) ? 1 : 0;   // (0,0), (1,1), (0,1), (1,0)
+    constexpr bool SAME = TR && !HELPER;              // compile-time: column operands are the row operands
+    const bool same_rt = !TR && wr == wc;             // (full factors: one loop body for the four classes)
+    int rowoffA[NH], rowoffB[NH];
+    uint32_t bitsA[NH], bitsB[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      rowoffA[i] = kbase + ((16 * min(wr + 2 * i, NT - 1) + li) ^ swz);
+      rowoffB[i] = kbase + ((16 * min(wc + 2 * i, NT - 1) + li) ^ swz);
+      bitsA[i] = block_slot_bits<BD>(wr + 2 * i);
+      bitsB[i] = block_slot_bits<BD>(wc + 2 * i);
+    }
+    // bit NH i + j: sub-tile (wr + 2 i, wc + 2 j) exists and lies in the lower triangle (wave-uniform)
+    uint32_t lower = 0u;
+#pragma unroll
+    for (int i = 0; i < NH; ++i)
+#pragma unroll
+      for (int j = 0; j < NH; ++j)
+        if (wr + 2 * i < NT && wc + 2 * j < NT && wr + 2 * i >= wc + 2 * j) lower |= 1u << (NH * i + j);
+    lower = (uint32_t)__builtin_amdgcn_readfirstlane((int)lower);
+    sweep([&](int buf, uint32_t qm, auto&& wr_lds) {
+      const double* As = ops + (size_t)(buf * SIDES) * 4 * SEG;
+      uint32_t colm = 0u, on = 0u;
+#pragma unroll
+      for (int j = 0; j < NH; ++j) colm |= ((qm & bitsB[j]) != 0 ? 1u : 0u) << j;
+#pragma unroll
+      for (int i = 0; i < NH; ++i) on |= ((qm & bitsA[i]) != 0 ? colm : 0u) << (NH * i);
+      on = (VGG_NO_SKIP ? 0xFFFFFFFFu : (uint32_t)__builtin_amdgcn_readfirstlane((int)on)) & lower;
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        uint32_t m = on;
+        asm volatile("" : "+s"(m));                 // (keeps the tests scalar bit tests; see the off-diagonal variant)
+        double a[NH], bq[NH];
+#pragma unroll
+        for (int i = 0; i < NH; ++i) a[i] = As[rowoffA[i] + ks * R];
+        if (SAME || same_rt) {                      // (scalar branch)
+#pragma unroll
+          for (int i = 0; i < NH; ++i) bq[i] = a[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < NH; ++i) bq[i] = As[rowoffB[i] + ks * R];
+        }
+#pragma unroll
+        for (int i = 0; i < NH; ++i)
+#pragma unroll
+          for (int j = 0; j < NH; ++j) {
+            if (TR && j > i) continue;                // (classes of the compressed tiles: i >= j only)
+            if (m & (1u << (NH * i + j))) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bq[j], acc[i][j], 0, 0, 0);
+          }
+        wr_lds(ks);
+      }
+    });
+#pragma unroll
+    for (int i = 0; i < NH; ++i)
+#pragma unroll
+      for (int j = 0; j < NH; ++j) {
+        if (TR && j > i) continue;
+        if (lower & (1u << (NH * i + j))) store_subtile(wr + 2 * i, wc + 2 * j, acc[i][j]);
+      }
+#else
     // diagonal tile (A == B, symmetric): only the NT (NT + 1) / 2 sub-tiles of the lower triangle are computed;
     // they are enumerated row by row and dealt round-robin to the 4 waves (wave-uniform scalar tables); skipped like
     // the off-diagonal ones when the quad has no camera in the rows or in the columns of the sub-tile
@@ -1471,6 +1546,7 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
 #pragma unroll
     for (int t = 0; t < PER; ++t)
       if (t < nmine) store_subtile(rbs[t], cbs[t], acc[t / NH][t % NH]);
+#endif
     if constexpr (TR && HELPER) {
       if (trhs) {                                     // the chunk's 96 x 3 block, a lane per tile row
         const int rrow = tid & 127;

@@ -2005,6 +2005,8 @@ __global__ __launch_bounds__(256, FYM == 1 ? VGG_PS_OCC_FY : VGG_PS_OCC) void po
         s_mcc += 0.5 * (z0 * z0 + z1 * z1 + z2 * z2) + 0.5 * (pd[0] * ys[0] * ys[0] + pd[1] * ys[1] * ys[1] + pd[2] * ys[2] * ys[2]);
       }
     }
+    // candidate residuals.  (Measured and rejected, round 4: two observations of a lane evaluated side by side so that
+    //  their dependent fp64 chains interleave -- 0.143 -> 0.150 ms at configs[2]; the sweep is not bound by its chain.)
     for (int o = o0 + sl; o < o1; o += LPP) {
       const int pass = (o - o0) / LPP;
       const int c = f_pf.cam(pass, pb.obs_cam, o);

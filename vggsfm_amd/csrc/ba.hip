@@ -498,6 +498,7 @@ __global__ __launch_bounds__(64) void cam_reduce_kernel(DevProblem pb, Ws w, int
   const int c = blockIdx.x, kdsh = d.kdsh;
   if (threadIdx.x >= NV) return;
   double tot = 0.0;
+#pragma unroll 8
   for (int sp = 0; sp < split; ++sp) tot += w.cam_split[((size_t)c * kCamSplitMax + sp) * kCamNV + threadIdx.x];
   if (MODE == 0) {
     double* U = w.U + (size_t)c * BD * BD;
@@ -527,10 +528,18 @@ __device__ __forceinline__ void prep_body(const DevProblem& pb, const Ws& w, con
   const Dims& d = pb.d;
   const bool first = !ctl->scale_ready;
   double gmax = 0.0, cost = 0.0;
+  constexpr int NS = 1 + 2 * (KD > 0 ? KD : 1);
+  double sums[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) sums[k] = 0.0;
   for (int c = threadIdx.x; c < d.C; c += 256) {
     const double* U = w.U + (size_t)c * BD * BD;
     const double* g = w.g + (size_t)c * BD;
     cost += w.costc[c];
+    if (d.shared && KD > 0) {                      // shared intrinsics: column norm and gradient are sums over all cameras
+#pragma unroll
+      for (int k = 0; k < KD; ++k) { sums[1 + k] += U[(6 + k) * BD + 6 + k]; sums[1 + KD + k] += g[6 + k]; }
+    }
     for (int k = 0; k < 6; ++k) w.colsq_c[6 * c + k] = U[k * BD + k];
     if (!d.shared) for (int k = 0; k < KD; ++k) w.colsq_c[6 * d.C + KD * c + k] = U[(6 + k) * BD + 6 + k];
     // |Plus(x, -g) - x|_inf for this camera (Ceres projected-gradient norm)
@@ -543,20 +552,7 @@ __device__ __forceinline__ void prep_body(const DevProblem& pb, const Ws& w, con
   }
   // one block reduction for everything (round 4: six 256-thread trees of eight barriers each took 15 us of every iteration):
   // wave shuffles, then the four wavefronts' partials in a fixed order
-  constexpr int NS = 1 + 2 * (KD > 0 ? KD : 1);
-  double sums[NS];
   sums[0] = cost;
-#pragma unroll
-  for (int k = 1; k < NS; ++k) sums[k] = 0.0;
-  if (d.shared && KD > 0) {                        // shared intrinsics: column norm and gradient are sums over all cameras
-    for (int c = threadIdx.x; c < d.C; c += 256) {
-#pragma unroll
-      for (int k = 0; k < KD; ++k) {
-        sums[1 + k] += w.U[(size_t)c * BD * BD + (6 + k) * BD + 6 + k];
-        sums[1 + KD + k] += w.g[(size_t)c * BD + 6 + k];
-      }
-    }
-  }
   const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
@@ -600,6 +596,7 @@ __global__ __launch_bounds__(256) void prep_kernel(DevProblem pb, Ws w, vgg_ba_o
   __syncthreads();
   const int n_red = pb.d.n_red;
   const double radius = ctl->radius;
+#pragma unroll 4
   for (int j = threadIdx.x; j < n_red; j += 256) {
     const double sc = w.scale_c[j];
     double dd = w.colsq_c[j] * sc * sc;
@@ -743,6 +740,9 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
     double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0}, Wa[3 * (KD ? KD : 1)];
 #pragma unroll
     for (int i = 0; i < 3 * (KD ? KD : 1); ++i) Wa[i] = 0;
+    // (the point's Jacobi scales are requested in front of the sweep that hides their round trip, not behind it)
+    double sp[3] = {1.0, 1.0, 1.0};
+    if (!first) { sp[0] = w.scale_p[3 * (size_t)p]; sp[1] = w.scale_p[3 * (size_t)p + 1]; sp[2] = w.scale_p[3 * (size_t)p + 2]; }
     // Jacobians of this lane's first observation for the Y sweep (tracks > LPP recompute): F and E, or -- compressed
     // factors -- the 2 x 3 d r / d (R X + t) instead of F
     double cF[CY ? 6 : 2 * BD], cE[6];
@@ -810,7 +810,7 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
       for (int k = 0; k < 3; ++k) s[k] = opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(colsq[k])) : 1.0;
     } else {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) s[k] = w.scale_p[3 * p + k];
+      for (int k = 0; k < 3; ++k) s[k] = sp[k];
     }
     double Gm[6] = {0, 0, 0, 0, 0, 0}, hs[3] = {0, 0, 0}, pd[3] = {0, 0, 0};
     double Ms[3 * (KD ? KD : 1)];
@@ -837,6 +837,8 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
       const double l22 = sqrt(d22);
       if (!ok) { if (sl == 0) ctl->linear_fail = 1; }
       // Linv (lower): i00 i10 i11 i20 i21 i22
+      // (measured, round 4: reciprocal square roots + Newton steps instead of sqrt and the six IEEE divisions -- a third of
+      //  the dependent instructions of this per-point chain -- change nothing in the launch time; the oracle's arithmetic stays)
       const double i00 = 1 / l00, i11 = 1 / l11, i22 = 1 / l22;
       const double i10 = -l10 * i00 * i11;
       const double i21 = -l21 * i11 * i22;
@@ -1715,6 +1717,9 @@ __global__ __launch_bounds__(64) void assemble_kernel(DevProblem pb, Ws w, const
   } else {
     if (trhs) {                                    // (rides along: max of the point passes' per-workgroup gradient norms,
       double m = 0;                                //  what cam_reduce_kernel<KD, 1> did)
+      // (these loops run in ONE wavefront and each trip is a round trip to memory: unrolled, so that several are in flight --
+      //  the extra workgroup was the long pole of the launch, ~20 of its 23 us at configs[2])
+#pragma unroll 8
       for (int i = tid; i < point_parts; i += 64) m = fmax(m, w.part_B[i]);
       m = wave_max(m);
       if (tid == 0) w.gmax_pts[0] = m;
@@ -1726,6 +1731,7 @@ __global__ __launch_bounds__(64) void assemble_kernel(DevProblem pb, Ws w, const
       double sums[NS];
 #pragma unroll
       for (int i = 0; i < NS; ++i) sums[i] = 0.0;
+#pragma unroll 4
       for (int cc = tid; cc < d.C; cc += 64) {
 #pragma unroll
         for (int i = 0; i < KD; ++i) {
@@ -1740,6 +1746,7 @@ __global__ __launch_bounds__(64) void assemble_kernel(DevProblem pb, Ws w, const
       }
       if (trhs) {
         // - sum_p Wa_p Ms_p^T (scaled like the T terms above) and - sum_p Wa_p hs_p, workgroup partials in launch order
+#pragma unroll 8
         for (int b = tid; b < point_parts; b += 64) {
           const double* q = w.part_Q + 8 * (size_t)b;
 #pragma unroll
@@ -1926,6 +1933,12 @@ __global__ __launch_bounds__(256, FYM == 1 ? VGG_PS_OCC_FY : VGG_PS_OCC) void po
       }
     }
     double t3[3] = {0, 0, 0};
+    // (the point's G and hs are requested here, in front of the Jacobian sweep, not behind it where they are used: behind
+    //  the sweep every point paid their round trip -- ~1 us of ~5 -- with nothing left to overlap it)
+    const double* Gp = w.G + 6 * (size_t)p;
+    const double G00 = Gp[0], G01 = Gp[1], G02 = Gp[2], G11 = Gp[3], G12 = Gp[4], G22 = Gp[5];
+    const double hs0 = w.hs[3 * (size_t)p], hs1 = w.hs[3 * (size_t)p + 1], hs2 = w.hs[3 * (size_t)p + 2];
+    const double pd0 = w.pdamp[3 * (size_t)p], pd1 = w.pdamp[3 * (size_t)p + 1], pd2 = w.pdamp[3 * (size_t)p + 2];
     // Model cost change without a second evaluation of the Jacobians.  With m = -(F dy + E ys) the model residual of an
     // observation (Ceres: -sum m.(r + m/2)), the sum over the observations of a point is
     //   sum [F dy . r - |F dy|^2 / 2]  +  ys^T g - ys^T t3 - ys^T V ys / 2        (g = sum E^T r, t3 = sum E^T F dy, V = sum E^T E)
@@ -1975,16 +1988,14 @@ __global__ __launch_bounds__(256, FYM == 1 ? VGG_PS_OCC_FY : VGG_PS_OCC) void po
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) t3[i] = group_sum<LPP>(t3[i]);
-    const double* Gp = w.G + 6 * (size_t)p;
-    const double G00 = Gp[0], G01 = Gp[1], G02 = Gp[2], G11 = Gp[3], G12 = Gp[4], G22 = Gp[5];
     // ys = hs - G (G^T t3 + uf)   (the shared intrinsics add Ms (dy_a / scale_a) when factors are used)
     double u0 = 0, u1 = 0, u2 = 0;
     if (!FY) { u0 = G00 * t3[0]; u1 = G01 * t3[0] + G11 * t3[1]; u2 = G02 * t3[0] + G12 * t3[1] + G22 * t3[2]; }
     if (FYM != 0) { u0 += group_sum<LPP>(uf[0]); u1 += group_sum<LPP>(uf[1]); u2 += group_sum<LPP>(uf[2]); }
     double ys[3];
-    ys[0] = w.hs[3 * p] - (G00 * u0 + G01 * u1 + G02 * u2);
-    ys[1] = w.hs[3 * p + 1] - (G11 * u1 + G12 * u2);
-    ys[2] = w.hs[3 * p + 2] - (G22 * u2);
+    ys[0] = hs0 - (G00 * u0 + G01 * u1 + G02 * u2);
+    ys[1] = hs1 - (G11 * u1 + G12 * u2);
+    ys[2] = hs2 - (G22 * u2);
     if constexpr (FYM != 0 && KD > 0) {
       const double* Msp = w.Ms + (size_t)p * 3 * KD;
 #pragma unroll
@@ -2001,8 +2012,7 @@ __global__ __launch_bounds__(256, FYM == 1 ? VGG_PS_OCC_FY : VGG_PS_OCC) void po
       if (!pt_c) s_xn += X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
       if (G22 != 0.0) {                                  // (constant / unobserved points: G = 0, ys = 0)
         const double z2 = ys[2] / G22, z1 = (ys[1] - G12 * z2) / G11, z0 = (ys[0] - G01 * z1 - G02 * z2) / G00;
-        const double* pd = w.pdamp + 3 * (size_t)p;
-        s_mcc += 0.5 * (z0 * z0 + z1 * z1 + z2 * z2) + 0.5 * (pd[0] * ys[0] * ys[0] + pd[1] * ys[1] * ys[1] + pd[2] * ys[2] * ys[2]);
+        s_mcc += 0.5 * (z0 * z0 + z1 * z1 + z2 * z2) + 0.5 * (pd0 * ys[0] * ys[0] + pd1 * ys[1] * ys[1] + pd2 * ys[2] * ys[2]);
       }
     }
     // candidate residuals.  (Measured and rejected, round 4: two observations of a lane evaluated side by side so that
@@ -2044,6 +2054,7 @@ __global__ __launch_bounds__(64) void control_kernel(Ws w, vgg_ba_options opt, i
   Ctl* c = w.ctl;
   if (c->done) { if (threadIdx.x == 0) c->accept = 0; return; }   // (no-op iterations behind the end must not commit again)
   double step_c = 0, xn_c = 0, mcc_c = 0;
+#pragma unroll 4
   for (int i = threadIdx.x; i <= C; i += 64) { step_c += w.cam_part[3 * i]; xn_c += w.cam_part[3 * i + 1]; mcc_c += w.cam_part[3 * i + 2]; }
   step_c = wave_sum(step_c); xn_c = wave_sum(xn_c); mcc_c = wave_sum(mcc_c);
   if (threadIdx.x != 0) return;

@@ -670,6 +670,10 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
   //  spare -- six more doubles per lane put the long-track variant on the stack)
   constexpr int KQ = (KD > 0) ? KD + KD * KD : 1;
   __shared__ double qs[4][64 / LPP][KQ];
+  // compressed factors: a wavefront's 64 records of a sweep go through LDS so that SIX adjacent lanes write the six 16-byte
+  // pieces of ONE record (see flush_records below)
+  __shared__ __attribute__((aligned(16))) double2 ystage[CY ? 4 : 1][CY ? 64 * (kYc / 2) : 1];
+  __shared__ int32_t slotstage[CY ? 4 : 1][CY ? 64 : 1];
   if (trhs && KD > 0 && (lane % LPP) == 0) {
 #pragma unroll
     for (int i = 0; i < KQ; ++i) qs[wave][lane / LPP][i] = 0.0;
@@ -720,8 +724,11 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
       m_ptc = pb.pt_const ? pb.pt_const[pm] != 0 : false;
     }
   }
-  for (; p < d.P; p += nw) {
-    const int o0 = n_o0, o1 = n_o1;
+  // (compressed factors: the loop is WAVE-uniform -- the record flush below needs all 64 lanes; a lane group whose point index
+  //  has run past the end goes through a last trip with an empty point: o0 = o1 = 0, nothing read or written for it)
+  for (; CY ? __any(p < d.P) : (p < d.P); p += nw) {
+    const bool pvalid = p < d.P;
+    const int o0 = pvalid ? n_o0 : 0, o1 = pvalid ? n_o1 : 0;
     const double X[3] = {n_X0, n_X1, n_X2};
     const bool pt_c = n_ptc;
     const ObsPf<NPF> f_pf = n_pf;
@@ -742,7 +749,7 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
     for (int i = 0; i < 3 * (KD ? KD : 1); ++i) Wa[i] = 0;
     // (the point's Jacobi scales are requested in front of the sweep that hides their round trip, not behind it)
     double sp[3] = {1.0, 1.0, 1.0};
-    if (!first) { sp[0] = w.scale_p[3 * (size_t)p]; sp[1] = w.scale_p[3 * (size_t)p + 1]; sp[2] = w.scale_p[3 * (size_t)p + 2]; }
+    if (!first && pvalid) { sp[0] = w.scale_p[3 * (size_t)p]; sp[1] = w.scale_p[3 * (size_t)p + 1]; sp[2] = w.scale_p[3 * (size_t)p + 2]; }
     // Jacobians of this lane's first observation for the Y sweep (tracks > LPP recompute): F and E, or -- compressed
     // factors -- the 2 x 3 d r / d (R X + t) instead of F
     double cF[CY ? 6 : 2 * BD], cE[6];
@@ -934,14 +941,10 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
             const double ai = Rc[3 * i] * X[0] + Rc[3 * i + 1] * X[1] + Rc[3 * i + 2] * X[2];
             rec[9 + i] = ai + ai;
           }
-#if VGG_PP_ABLATE == 1                            // profiling build: the Y arithmetic without its stores
-          if (Gm[0] == 12345.678)
-#endif
-          {
-            double2* y = reinterpret_cast<double2*>(w.Y + (size_t)slot * kYc);
+          // (into the wavefront's LDS image, row = lane; flush_records writes it out)
+          slotstage[wave][lane] = slot;
 #pragma unroll
-            for (int i = 0; i < kYc / 2; ++i) y[i] = make_double2(rec[2 * i], rec[2 * i + 1]);
-          }
+          for (int i = 0; i < kYc / 2; ++i) ystage[wave][lane * (kYc / 2) + i] = make_double2(rec[2 * i], rec[2 * i + 1]);
         } else {
         // segment layout: [component 0..2][slot 0..15][row 0..bdt-1]  (three rows of the K dimension)
         const int rt = kGroup * bdt;
@@ -975,17 +978,42 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
         }
       };
       if constexpr (KEEPJ) {
+        // A sweep's records leave the wavefront through LDS: lane q of store k carries piece (k 64 + q) % 6 of record
+        // (k 64 + q) / 6, so six adjacent lanes cover one 96-byte record and a store instruction touches ~16 cache-line
+        // sectors instead of 64.  (Lane = record, six 16-byte stores per lane: every store was its own L2 transaction,
+        // 30 M per launch at configs[2].  Ablations: the launch without these stores 0.152 ms, without the whole sweep
+        // 0.117, with them 0.249; this form 0.244 against 0.262 on the same box, profiles/r04_ab_point_pass_records.jsonl --
+        // what is left of the stores' cost is their 0.5 GB at the HBM write rate.)  In-order LDS per wavefront: no barrier.
+        auto flush_records = [&]() __attribute__((always_inline)) {
+#if VGG_PP_ABLATE != 1                            // (profiling build 1: the Y arithmetic without its stores)
+#pragma unroll
+          for (int k = 0; k < kYc / 2; ++k) {
+            const int q = k * 64 + lane;
+            const int r = (q * 10923) >> 16;        // q / 6 for q < 384
+            const int pc = q - 6 * r;
+            const int sdst = slotstage[wave][r];
+            const double2 v = ystage[wave][q];
+            if (sdst >= 0) reinterpret_cast<double2*>(w.Y)[(size_t)sdst * (kYc / 2) + pc] = v;
+          }
+#endif
+        };
 #pragma unroll
         for (int ps = 0; ps < NPF; ++ps) {
           const int o = o0 + sl + ps * LPP;
-          if (o < o1) emit(ps, o, cJ[ps]);
+          if (!__any(o < o1)) break;
+          if (o < o1) emit(ps, o, cJ[ps]); else slotstage[wave][lane] = -1;
+          flush_records();
         }
-        for (int o = o0 + sl + NPF * LPP; o < o1; o += LPP) emit((o - o0) / LPP, o, nullptr);
+        for (int pass = NPF; __any(o0 + sl + pass * LPP < o1); ++pass) {
+          const int o = o0 + sl + pass * LPP;
+          if (o < o1) emit(pass, o, nullptr); else slotstage[wave][lane] = -1;
+          flush_records();
+        }
       } else {
         for (int o = o0 + sl; o < o1; o += LPP) emit((o - o0) / LPP, o, nullptr);
       }
     }
-    if (sl == 0) {
+    if (sl == 0 && pvalid) {
       if (first) { w.scale_p[3 * p] = s[0]; w.scale_p[3 * p + 1] = s[1]; w.scale_p[3 * p + 2] = s[2]; }
 #pragma unroll
       for (int i = 0; i < 6; ++i) w.G[6 * (size_t)p + i] = Gm[i];
@@ -2283,10 +2311,12 @@ static void phase_schur(const Launch& L) {
         constexpr int LPP = decltype(lpp)::value;
         constexpr bool CY = decltype(cy)::value;
         const bool longt = long_tracks(LPP, L.d.P, L.d.O);
+        // (two workgroups per CU: the compressed variant keeps 25 KB of record staging beside the camera table)
+        const size_t cam_cap = (CY ? 53 : 64) * 1024;
         if (longt && LPP <= 32) {
-          if (cam_lds <= 64 * 1024) point_pass_kernel<KD, true, CY, LPP, (LPP <= 32)><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w, L.opt);
+          if (cam_lds <= cam_cap) point_pass_kernel<KD, true, CY, LPP, (LPP <= 32)><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w, L.opt);
           else point_pass_kernel<KD, false, CY, LPP, (LPP <= 32)><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w, L.opt);
-        } else if (cam_lds <= 64 * 1024) point_pass_kernel<KD, true, CY, LPP><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w, L.opt);
+        } else if (cam_lds <= cam_cap) point_pass_kernel<KD, true, CY, LPP><<<L.wgB, 256, cam_lds, L.st>>>(L.dp, L.w, L.opt);
         else point_pass_kernel<KD, false, CY, LPP><<<L.wgB, 256, 0, L.st>>>(L.dp, L.w, L.opt);
       };
       // compressed Schur factors with 6 x 6 tile blocks (shared or constant intrinsics), full factors otherwise

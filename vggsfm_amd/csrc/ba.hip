@@ -2423,6 +2423,19 @@ static void phase_update(const Launch& L) {
   commit_kernel<<<div_up((long)nmax, 256), 256, 0, L.st>>>(L.w, L.cam_q, L.cam_t, L.intr, L.pts, d.C, d.NI, d.P);
 }
 
+// compute units of the current device (256 on MI355X), looked up once per device
+static int device_cus() {
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
+
 static int make_launch(const vgg_ba_problem* pb, const vgg_ba_options* opt, void* workspace, hipStream_t st, Launch* L) {
   if (!pb || !opt || !workspace) return VGG_ERR_INVALID_ARGUMENT;
   if (pb->num_cams <= 0 || pb->num_pts < 0 || pb->num_obs < 0) return VGG_ERR_INVALID_ARGUMENT;
@@ -2434,8 +2447,9 @@ static int make_launch(const vgg_ba_problem* pb, const vgg_ba_options* opt, void
   L->opt = *opt;
   L->st = st;
   L->lpp = lanes_per_point(L->d.P, L->d.O);
-  // (c3: 512 or 1024 workgroups 2.18 ms per iteration, 2048: 2.21 -- every workgroup fills its LDS camera cache first)
-  L->wgB = min(max(div_up(L->d.P, 4 * (64 / L->lpp)), 1), g_tuning.point_wgs > 0 ? min(g_tuning.point_wgs, kMaxWG) : 1024);
+  // (every workgroup fills its LDS camera cache first: ONE resident round of the point passes -- two workgroups per CU -- is the
+  //  cheapest; round 4, configs[2]: 512 workgroups point_pass + point_step 0.352 ms, 768: 0.415, 1024: 0.359, 2048: 0.371)
+  L->wgB = min(max(div_up(L->d.P, 4 * (64 / L->lpp)), 1), g_tuning.point_wgs > 0 ? min(g_tuning.point_wgs, kMaxWG) : min(2 * device_cus(), kMaxWG));
   L->chunk_desc = pb->chunk_desc; L->entries = pb->entries; L->num_chunks = pb->num_chunks;
   L->merged_tile_launch = pb->merged_tile_launch;
   L->num_segments = pb->num_segments;

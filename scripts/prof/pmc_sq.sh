@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_sq
 CTRS=${1:-"SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT"}
 (cd $ROOT && rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d /tmp/pmc_sq -- \
-    python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-strong-leg --no-triangulation > $OUT/bench_sq.log 2>&1)
+    python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-strong-leg --no-triangulation --no-pipeline > $OUT/bench_sq.log 2>&1)
 python $ROOT/scripts/prof/pmc_aggregate.py $OUT/pmc_sq.json /tmp/pmc_sq > /dev/null
 python - <<PY
 import json

@@ -317,3 +317,146 @@ def absolute_pose_estimation(points2D, points3D, camera, estimation_options=None
     ans = pose_refinement(Rigid3d(Rotation3d(res["pose"][:, :3]), res["pose"][:, 3]), x_px, X, res["inliers"], camera,
                           refinement_options)
     return {"cam_from_world": ans["cam_from_world"], "num_inliers": int(res["num_inliers"]), "inlier_mask": res["inliers"]}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The surface ``vggsfm/runners/video_runner.py`` touches on top of the above (move_window :800-838, joint_BA :494-541,
+# solve_bundle_adjustment :1321-1331): BundleAdjustmentConfig / BundleAdjuster / pyceres.{SolverSummary, solve} /
+# ObservationManager.  Used by oracle/gen_golden_video.py (TEST INFRASTRUCTURE, like everything in this file).
+class BundleAdjustmentConfig:
+    def __init__(self):
+        self.image_ids, self.constant_cam_poses = [], set()
+        self.constant_point3D_ids, self.variable_point3D_ids = set(), set()
+
+    def add_image(self, image_id):
+        if int(image_id) not in self.image_ids:
+            self.image_ids.append(int(image_id))
+
+    def set_constant_cam_pose(self, image_id):
+        self.constant_cam_poses.add(int(image_id))
+
+    def add_constant_point(self, point3D_id):
+        self.constant_point3D_ids.add(int(point3D_id))
+
+    def add_variable_point(self, point3D_id):
+        self.variable_point3D_ids.add(int(point3D_id))
+
+
+BundleAdjustmentOptions.create_loss_function = lambda self: (self.loss_function_type, self.loss_function_scale)
+
+
+class BundleAdjuster:
+    """pycolmap.BundleAdjuster(options, config): no negative-depth filter (that is the controller's), the gauge is what
+    the config says (COLMAP BundleAdjuster::SetUp).  Every image of the reconstruction must be in the config -- the only
+    form the reference builds (video_runner.py:817-829)."""
+
+    def __init__(self, options, config):
+        self.options, self.config = options, config
+        self.reconstruction, self.problem = None, None
+
+    def set_up_problem(self, reconstruction, loss_function=None):
+        self.reconstruction = reconstruction
+        self.problem = types.SimpleNamespace(adjuster=self)
+
+    def set_up_solver_options(self, problem, solver_options):
+        return solver_options
+
+    def _run(self, so):
+        rec, cfg, options = self.reconstruction, self.config, self.options
+        assert sorted(cfg.image_ids) == rec.reg_image_ids() == sorted(rec.images), "config = all images (video_runner.py:818)"
+        pts, ext, K, tracks, masks, extra, shared, model = rec._dense()
+        cp = np.zeros(len(pts), bool)
+        for pid in cfg.constant_point3D_ids:
+            if 1 <= pid <= len(pts):
+                cp[pid - 1] = True
+        o = OB.ceres_options(so.max_num_iterations, so.function_tolerance, so.gradient_tolerance, so.parameter_tolerance)
+        loss = {"TRIVIAL": 0, "CAUCHY": 1, "HUBER": 2, "SOFT_L1": 3}[options.loss_function_type]
+        p_opt, ext_o, K_o, extra_o, summ = OB.bundle_adjustment(
+            pts, ext, K, tracks, masks, extra, shared, model, options=o, constant_points=cp,
+            constant_pose_frames=sorted(cfg.constant_cam_poses), filter_negative_depth=False,
+            refine_focal=bool(options.refine_focal_length), refine_extra=bool(options.refine_extra_params), loss=loss,
+            loss_scale=float(options.loss_function_scale))
+        CALLS.append(("bundle_adjuster", {k: summ[k] for k in ("initial_cost", "final_cost", "num_iterations",
+                                                               "termination")}))
+        for k, vi in enumerate(summ["valid_idx"]):
+            pid = int(vi) + 1
+            if pid in rec.points3D:
+                rec.points3D[pid].xyz = p_opt[k].copy()
+        for i in sorted(rec.images):
+            rec.images[i].cam_from_world = Rigid3d(Rotation3d(ext_o[i, :, :3]), ext_o[i, :, 3])
+            cam = rec.cameras[rec.images[i].camera_id]
+            cam.params[0], cam.params[1], cam.params[2] = K_o[i, 0, 0], K_o[i, 0, 2], K_o[i, 1, 2]
+            if model == "SIMPLE_RADIAL":
+                cam.params[3] = extra_o[i, 0]
+        summ["num_residuals"] = 2 * int(masks[:, summ["valid_idx"]].sum())
+        return summ
+
+
+class _SolverSummary:
+    def __init__(self):
+        self.num_residuals_reduced = 0
+        self.num_effective_parameters_reduced = 0
+        self.num_successful_steps = self.num_unsuccessful_steps = 0
+        self.total_time_in_seconds = 0.0
+        self.initial_cost = self.final_cost = 0.0
+
+
+def _pyceres_solve(options, problem, summary):
+    out = problem.adjuster._run(options)
+    summary.num_residuals_reduced = out["num_residuals"]
+    summary.num_effective_parameters_reduced = out["n_reduced"]
+    summary.num_successful_steps = out["num_successful_steps"]
+    summary.num_unsuccessful_steps = out["num_unsuccessful_steps"]
+    summary.initial_cost, summary.final_cost = out["initial_cost"], out["final_cost"]
+    return summary
+
+
+pyceres = types.ModuleType("pyceres")      # register as sys.modules["pyceres"] next to this module as "pycolmap"
+pyceres.SolverSummary = _SolverSummary
+pyceres.solve = _pyceres_solve
+
+
+class ObservationManager:
+    """The two ObservationManager filters of joint_BA (video_runner.py:510-512) [COLMAP 3.10 observation_manager.cc]: an
+    observation goes when its squared reprojection error exceeds max^2 or its depth is not positive; a point goes when
+    fewer than two observations remain or no pair of its remaining views subtends min_tri_angle degrees."""
+
+    def __init__(self, reconstruction, correspondence_graph=None):
+        self.reconstruction = reconstruction
+
+    def _apply(self, inl, keep):
+        rec = self.reconstruction
+        for i, im in rec.images.items():
+            for p2 in im.points2D:
+                pid = p2.point3D_id
+                if pid >= 1 and pid in rec.points3D and not (keep[pid - 1] and inl[i, pid - 1]):
+                    p2.point3D_id = -1
+        for pid in [p for p in rec.points3D if not keep[p - 1]]:
+            del rec.points3D[pid]
+        for pid, p in rec.points3D.items():
+            p.track.elements = [e for e in p.track.elements if rec.images[e.image_id].points2D[e.point2D_idx].point3D_id == pid]
+
+    def filter_all_points3D(self, max_reproj_error, min_tri_angle):
+        from . import geometry as OG
+        pts, ext, K, tracks, masks, extra, shared, model = self.reconstruction._dense()
+        tr = tracks.astype(np.float64)
+        _, detail = OG.filter_all_points3D(pts, tr, ext, K, extra, max_reproj_error=max_reproj_error, check_triangle=False,
+                                           return_detail=True, hard_max=-1)
+        inl = masks & detail
+        keep, _ = OG.filter_all_points3D(pts, np.where(inl[..., None], tr, 1e9), ext, K, extra,
+                                         max_reproj_error=max_reproj_error, min_tri_angle=min_tri_angle,
+                                         check_triangle=True, hard_max=-1)
+        keep = keep & (inl.sum(0) >= 2)
+        before = int(masks.sum())
+        self._apply(inl, keep)
+        return before - int((inl & keep[None]).sum())
+
+    def filter_observations_with_negative_depth(self):
+        pts, ext, K, tracks, masks, extra, shared, model = self.reconstruction._dense()
+        z = np.einsum("sj,pj->sp", ext[:, 2, :3], pts) + ext[:, 2, 3][:, None]
+        inl = masks & (z >= np.finfo(np.float64).eps)
+        keep = inl.sum(0) >= 2                       # (a point left with fewer than two observations is deleted)
+        alive = np.zeros(len(pts), bool)
+        alive[[p - 1 for p in self.reconstruction.points3D]] = True
+        self._apply(inl, keep | ~alive)
+        return int(masks.sum()) - int((inl & keep[None]).sum())

@@ -91,3 +91,48 @@ def patch(monkeypatch):
     monkeypatch.setattr(POSE, "pose_refinement_batch", pose_refinement_batch)
     monkeypatch.setattr(POSE, "absolute_pose_estimation_batch", absolute_pose_estimation_batch)
     monkeypatch.setattr(V, "observation_filter", observation_filter)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The geometry kernels behind ``vggsfm_amd.video.VideoGeometry`` (geometry.hip, triangulate.hip), for the CPU rehearsal
+# of the video golden (tests/test_video_golden_cpu.py): the DRIVER -- window bounds, shrink / step-back, table updates --
+# is the product's, the arithmetic is oracle/geometry.py.  The -m gpu twin (tests/test_gpu_video_golden.py) runs the
+# same driver on the device kernels.
+def filter_all_points3D(points3D, points2D, extrinsics, intrinsics, extra_params=None, max_reproj_error=4,
+                        min_tri_angle=1.5, check_triangle=True, return_detail=False, hard_max=100, max_points_num=1000000):
+    out = OG.filter_all_points3D(_n(points3D).astype(np.float64), _n(points2D).astype(np.float64),
+                                 _n(extrinsics).astype(np.float64), _n(intrinsics).astype(np.float64),
+                                 None if extra_params is None else _n(extra_params).astype(np.float64),
+                                 max_reproj_error=max_reproj_error, min_tri_angle=min_tri_angle,
+                                 check_triangle=check_triangle, return_detail=return_detail, hard_max=hard_max)
+    return tuple(_t(o) for o in out) if isinstance(out, tuple) else _t(out)
+
+
+def cam_from_img(pred_tracks, intrinsics, extra_params=None):
+    return _t(OG.cam_from_img(_n(pred_tracks).astype(np.float64), _n(intrinsics).astype(np.float64),
+                              None if extra_params is None else _n(extra_params).astype(np.float64)))
+
+
+def triangulate_tracks(extrinsics, tracks_normalized, max_ransac_iters=256, lo_num=50, max_angular_error=2,
+                       min_tri_angle=1.5, track_vis=None, track_score=None, max_tri_points_num=819200, **kw):
+    S, N = tracks_normalized.shape[:2]
+    pairs = OG.generate_combinations(S)
+    assert len(pairs) <= max_ransac_iters and S * N <= max_tri_points_num, "one chunk, all pairs (no RNG draw) only"
+    pts, num, mask = OG.triangulate_tracks_chunk(_n(extrinsics).astype(np.float64), _n(tracks_normalized).astype(np.float64),
+                                                 pairs, lo_num, max_angular_error, min_tri_angle,
+                                                 None if track_vis is None else _n(track_vis),
+                                                 None if track_score is None else _n(track_score))
+    return _t(pts), _t(num.astype(np.int64)), _t(mask)
+
+
+def patch_video_geometry(monkeypatch):
+    """`patch` + the geometry entry points ``vggsfm_amd.video`` holds by name."""
+    import vggsfm_amd._lib as LIB
+    import vggsfm_amd.video as V
+    patch(monkeypatch)
+    monkeypatch.setattr(LIB, "require_gpu", lambda *t: None)
+    monkeypatch.setattr(V, "filter_all_points3D", filter_all_points3D)
+    monkeypatch.setattr(V, "cam_from_img", cam_from_img)
+    monkeypatch.setattr(V, "triangulate_tracks", triangulate_tracks)
+    monkeypatch.setattr(V, "pose_refinement_batch", pose_refinement_batch)
+    monkeypatch.setattr(V, "absolute_pose_estimation_batch", absolute_pose_estimation_batch)

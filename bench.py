@@ -6,16 +6,15 @@
 
 A *step* is ONE LM iteration (linearise -> block-sparse Schur complement -> dense Cholesky of the
 reduced camera system -> back-substitution -> candidate cost -> trust-region decision) over the whole
-synthetic scene.  Workload at N=1 = BASELINE.json configs[2], the configuration the north-star target is
-quoted on: 200 frames x 100k tracks, SIMPLE_RADIAL, shared camera (SURVEY.md section 8d generator).
-N>1 (default workload): STRONG scaling on BASELINE configs[3] -- ONE fixed problem, 400 frames x 300k tracks with per-frame
-intrinsics, its tracks sharded by 3D point over the N ranks, cameras replicated, per-camera blocks all-reduced and the
-reduced system reduce-scattered + all-gathered over RCCL once per iteration; `value` = true LM iterations per second of
-that whole problem.  Rank 0 first times the SAME problem alone (`n1_same_problem`, the other ranks wait), so the line
-carries its own speed-up; a short weak-scaling leg on configs[2] shards (every rank its own 100k tracks) is reported
-as `weak_scaling_c3` in shard-iterations per second.  At N=1 a default run also times a short c4 leg
-(`strong_scaling_c4`: the N = 1 point of the strong-scaling curve) unless `--no-strong-leg` is given.
-`--workload c3 --gpus N` selects the weak-scaling problem as the main one (value = N x K / t shard-iterations/s).
+synthetic scene.  Workload = BASELINE.json configs[2], the configuration the north-star target is quoted on: 200 frames x 100k
+tracks PER GPU, SIMPLE_RADIAL, shared camera (SURVEY.md section 8d generator) -- at EVERY N, so that the driver's
+N = 1, 2, 4, 8 lines draw one curve: `value` = N x K / t shard-iterations per second (weak scaling: every rank owns a
+100k-track shard of the 200-frame x (N x 100k)-track problem, cameras replicated, per-camera blocks all-reduced and the
+reduced system reduce-scattered + all-gathered over RCCL once per iteration); at N = 1 that is the LM-iterations/s of
+configs[2].  The STRONG-scaling figure rides along as the key `strong_scaling_c4` at every N: ONE fixed problem, BASELINE
+configs[3] (400 frames x 300k tracks, per-frame intrinsics), its tracks split over the ranks; at N > 1 rank 0 first times
+the SAME whole problem alone (`n1_same_problem` inside that key, the other ranks wait), so the line carries its own
+speed-up (`speedup_vs_n1`).  `--workload c4 --gpus N` makes the strong problem the main one instead (value = K / t).
 Inputs are resident in HBM before the timed region; termination tests are disabled so that exactly K
 iterations run (a solve is restarted from the initial state every EPISODE iterations, like the
 reference's 50/100-iteration BA calls).
@@ -63,6 +62,14 @@ WORKLOADS = {
     "c4": (400, 300000, "SIMPLE_RADIAL", False),          # configs[3], the 300k tracks SPLIT over the ranks (strong scaling)
 }
 STRONG = {"c4"}
+BASELINE_CONFIG = {"c2": "BASELINE configs[1]", "c3": "BASELINE configs[2]",
+                   "c3dense": "BASELINE configs[2] with every track visible in every frame", "c4shard": "one 8-GPU shard of BASELINE configs[3]",
+                   "c4full": "BASELINE configs[3] whole on one GPU", "c4": "BASELINE configs[3]"}
+# the reference's own torch triangulate_tracks on the CPU, measured during the survey (unmodified code,
+# 200 views x 1 000 tracks, all tracks visible, 8 cores, 130.7 s) -- quoted beside the kernel's number, never re-measured here
+REFERENCE_TRIANGULATION_CPU = dict(value=1000 / 130.7, unit="tracks/s", cores=8, kind="reference",
+                                   sample="vggsfm/utils/triangulation.py::triangulate_tracks, 200 views x 1 000 tracks, fp64, survey "
+                                          "container (BASELINE.md section 2): 130.7 s = 131 ms per track")
 
 
 def D(x, dev):
@@ -114,6 +121,47 @@ def last_iteration_above_noise(its, floor=1e-12):
         if it["iteration"] > 0 and abs(it["cost_change"]) >= floor * abs(it["cost"]):
             last = int(it["iteration"])
     return last
+
+
+def parity_vs_port(pts, ext, K, tracks, masks, extra, shared, cam_type, iters, what):
+    """`iters` LM iterations (termination tests off) of ONE problem from ONE start, through the public GPU entry
+    (vggsfm_amd.ba.bundle_adjustment -> vgg_ba_solve) and by the CPU port (oracle/ba_oracle.c behind oracle/ba.py) on host
+    copies of the same tensors: accept / reject pattern, cost and radius per iteration, poses, points, focal lengths.
+    Device tensors in, comparison dict out (the checker is imported here, after every timed region)."""
+    from oracle import ba as OB
+    o = BundleAdjustmentOptions()
+    so = o.solver_options
+    so.max_num_iterations = iters
+    so.function_tolerance = so.gradient_tolerance = so.parameter_tolerance = -1.0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gp, ge, gK, gx, gs = BA.bundle_adjustment(pts, ext, K, tracks, masks, None, extra, shared, cam_type, o)
+    torch.cuda.synchronize()
+    t_gpu = time.perf_counter() - t0
+    H = lambda t: None if t is None else t.detach().cpu().numpy()
+    t0 = time.perf_counter()
+    op, oe, oK, ox, osum = OB.bundle_adjustment(H(pts), H(ext), H(K), H(tracks), H(masks).astype(bool), H(extra), shared, cam_type,
+                                                options=OB.ceres_options(iters, -1.0, -1.0, -1.0))
+    t_port = time.perf_counter() - t0
+    ge, gp, gK = H(ge), H(gp), H(gK)
+    relv = lambda a, b: float(np.max(np.linalg.norm((a - b).reshape(len(a), -1), axis=1)
+                                     / np.maximum(np.linalg.norm(b.reshape(len(b), -1), axis=1), 1e-12)))
+    its = list(zip(gs["iterations"], osum["iterations"]))
+    alive = ~np.asarray(osum["deleted"], bool)
+    return dict(workload=f"{what}, {iters} LM iterations from the same start, termination tests off",
+                observations=int(H(masks)[:, np.asarray(osum["valid_idx"])].sum()), reduced_system=int(osum["n_reduced"]),
+                lm_iterations_gpu=int(gs["num_iterations"]), lm_iterations_port=int(osum["num_iterations"]),
+                accept_pattern_equal=bool(len(gs["iterations"]) == len(osum["iterations"])
+                                          and all(a["successful"] == b["successful"] for a, b in its)),
+                max_rel_cost_delta_per_iteration=float(max(abs(a["cost"] - b["cost"]) / b["cost"] for a, b in its)),
+                max_rel_radius_delta_per_iteration=float(max(abs(a["radius"] - b["radius"]) / b["radius"] for a, b in its)),
+                final_cost_rel_delta=abs(gs["final_cost"] - osum["final_cost"]) / osum["final_cost"],
+                max_rel_rotation_delta=relv(ge[:, :, :3], oe[:, :, :3]),
+                max_rel_translation_delta=relv(ge[1:, :, 3], oe[1:, :, 3]),
+                max_rel_point_delta=relv(gp[alive], op[alive]),
+                max_rel_focal_delta=float(np.max(np.abs(gK[:, 0, 0] / oK[:, 0, 0] - 1))),
+                gpu_seconds=t_gpu, port_seconds=t_port, port_threads=int(OB.lib().bao_num_threads()),
+                tolerance=1e-4, reference="oracle/ba_oracle.c (Ceres/COLMAP restatement; unpinned vs pycolmap)")
 
 
 class StageTimer:
@@ -235,8 +283,13 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
-                    help="default: c3 (BASELINE configs[2]) at N = 1, c4 (configs[3], strong scaling) at N > 1")
+                    help="default: c3 (BASELINE configs[2], one 100k-track shard per GPU) at every N")
     ap.add_argument("--no-n1-leg", action="store_true", help="N > 1, strong scaling: skip rank 0's solo run of the whole problem")
+    ap.add_argument("--no-parity-c4", action="store_true",
+                    help="N = 1: skip the GPU-vs-port comparison of 3 LM iterations of the whole configs[3] problem (~1 min of CPU)")
+    ap.add_argument("--no-parity-c5", action="store_true",
+                    help="N = 1: skip the configs[4] video loop + GPU-vs-port comparison of its final joint problem (n = 6002)")
+    ap.add_argument("--parity-iters", type=int, default=3)
     ap.add_argument("--no-weak-leg", action="store_true", help="N > 1: skip the weak-scaling leg on configs[2] shards")
     ap.add_argument("--weak-steps", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -259,7 +312,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if args.workload is None:
-        args.workload = "c3" if world == 1 else "c4"
+        args.workload = "c3"             # the same workload family at every N: value(N) / value(1) is a scaling curve
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
@@ -299,7 +352,7 @@ def main():
             prob, _, _ = BA.compile_problem(sc.points3D_init, D(ext0_c, dev), D(K0_c, dev), sc.tracks, sc.mask, D(extra0_c, dev),
                                             shared, cam_type, overlap=(world == 1 and args.overlap),
                                             camera_split=not args.no_camera_split, adjacency_reduce=reduce_adj)
-            return prob, None, None
+            return prob, None, (sc, D(ext0_c, dev), D(K0_c, dev), D(extra0_c, dev))
         sc = make_scene(S, N, cam_type, shared_camera=shared, seed=0, track_seed=1000 + rank, full_visibility=(workload == "c3dense"))
         _, _, _, pts0 = perturb_for_ba(sc, seed=rank)
         ext0_c, K0_c, extra0_c, _ = perturb_for_ba(sc, seed=0)          # cameras identical on every rank
@@ -369,21 +422,23 @@ def main():
 
     S, N, cam_type, shared = WORKLOADS[args.workload]
     strong_main = args.workload in STRONG
-    # ---- N > 1, strong scaling: the SAME whole problem on rank 0 alone first (the N = 1 point of the curve, measured on
-    # this box in this run); the other ranks wait at the barrier
+    # ---- N > 1: the whole strong-scaling problem (configs[3]) on rank 0 alone first -- the N = 1 point of the strong curve,
+    # measured on this box in this run; the other ranks wait at the barrier
+    run_strong = strong_main or not args.no_strong_leg
     n1 = None
-    if world > 1 and strong_main and not args.no_n1_leg:
+    if world > 1 and run_strong and not args.no_n1_leg:
         if rank == 0:
-            p1, _, _ = build(args.workload, solo=True)
+            p1, _, _ = build("c4", solo=True)
             d1, f1, _ = timed(p1, args.strong_steps, 2, False, solo=True)
-            n1 = dict(workload=f"the same {S} x {N} problem on rank 0 alone", steps=args.strong_steps, observations=int(p1.num_obs),
+            S4, N4 = WORKLOADS["c4"][:2]
+            n1 = dict(workload=f"the same {S4} x {N4} problem on rank 0 alone", steps=args.strong_steps, observations=int(p1.num_obs),
                       ms_per_iteration=1e3 * d1 / args.strong_steps, lm_iterations_per_s=args.strong_steps / d1)
             del p1
             torch.cuda.empty_cache()
         barrier()
     prob, sc, host_init = build(args.workload)
     dt, fin, prof = timed(prob, args.steps, args.warmup, True)
-    # ---- N > 1: weak-scaling leg on configs[2] shards (every rank its own 200 x 100k shard)
+    # ---- N > 1 with the strong problem as the main one: weak-scaling leg on configs[2] shards
     weak = None
     if world > 1 and strong_main and not args.no_weak_leg:
         wprob, _, _ = build("c3")
@@ -396,16 +451,27 @@ def main():
         torch.cuda.empty_cache()
 
     # ---- strong-scaling leg: BASELINE configs[3] (400 x 300k, per-frame intrinsics) split over the ranks
-    strong = None
+    strong, parity_c4 = None, None
     if not strong_main and not args.no_strong_leg:
-        sprob, _, _ = build("c4")
+        sprob, _, sdev = build("c4")
         sdt, sfin, _ = timed(sprob, args.strong_steps, 2, False)
         strong = dict(workload="synthetic 400 frames x 300000 tracks SIMPLE_RADIAL per-frame intrinsics (BASELINE configs[3]), the "
                                f"tracks split over {world} rank(s)", tracks_per_rank=300000 // world,
                       observations_rank0=int(sprob.num_obs), reduced_system=int(sfin["n_reduced"]), steps=args.strong_steps,
                       ms_per_iteration=1e3 * sdt / args.strong_steps, lm_iterations_per_s=args.strong_steps / sdt,
-                      scaling="strong", data="synthetic (drawn on the device)")
+                      scaling="strong", data="synthetic (drawn on the device)", n1_same_problem=n1,
+                      speedup_vs_n1=(args.strong_steps / sdt) / n1["lm_iterations_per_s"] if n1 else None)
         del sprob
+        torch.cuda.empty_cache()
+        if world == 1 and not args.no_parity_c4 and not args.no_cpu_baseline:
+            # the whole configs[3] problem at FULL size, GPU and port side by side
+            try:
+                sc4, e4, K4, x4 = sdev
+                parity_c4 = parity_vs_port(sc4.points3D_init, e4, K4, sc4.tracks, sc4.mask, x4, False, "SIMPLE_RADIAL",
+                                           args.parity_iters, "BASELINE configs[3] whole (400 x 300000, per-frame SIMPLE_RADIAL)")
+            except Exception as exc:                          # (an auxiliary leg must not cost the line)
+                parity_c4 = dict(error=f"{type(exc).__name__}: {exc}")
+        del sdev
         torch.cuda.empty_cache()
 
     if rank == 0:
@@ -566,6 +632,29 @@ def main():
                        reference_formulation_flops=f_ref, reference_formulation_tflops=f_ref / t_dev / 1e12,
                        kernel="triangulate_kernel (its own time: the rocprofv3 kernel stats under profiles/; `ms` is the whole call on "
                               "the launch stream, host-side pair draws included)")
+            # CPU figures beside it: the numpy port on a bounded slice of the SAME scene, timed
+            # here on one host core, and the reference's own torch function as the survey measured it (quoted, 8 cores)
+            tri["cpu_reference_survey"] = REFERENCE_TRIANGULATION_CPU
+            if not args.no_cpu_baseline:
+                try:
+                    from oracle import geometry as OG
+                    n_cpu = 16
+                    tn_h = tn[:, :n_cpu].cpu().numpy()
+                    pr = OG.generate_combinations(S)
+                    pr = pr[np.random.default_rng(0).permutation(len(pr))[:hyp]]
+                    tcp = time.perf_counter()
+                    OG.triangulate_tracks_chunk(sc.extrinsics, tn_h, pr, 50, 2, 1.5, sc.vis[:, :n_cpu], sc.score[:, :n_cpu])
+                    tcp = time.perf_counter() - tcp
+                    tri["cpu_baseline"] = dict(value=n_cpu / tcp, unit="tracks/s", cores=1, kind="port",
+                                               sample=f"the first {n_cpu} tracks of the timed scene ({S} views), oracle/geometry.py "
+                                                      f"(numpy restatement of triangulate_tracks_single_chunk), {tcp:.1f} s")
+                except Exception as exc:
+                    tri["cpu_baseline"] = dict(error=f"{type(exc).__name__}: {exc}")
+            sq = os.path.join(ROOT, "profiles", "r05_pmc_sq_tri.json")
+            by_kernel["triangulate"] = dict(ms_per_call=1e3 * t_dev, bound="fp64 valu", frac=tri["frac_of_fp64_peak"],
+                                            executed_flops=f_exec, note="not part of an LM iteration: one triangulate_tracks call on "
+                                            "the timed scene; executed-flop model in the `triangulation` key",
+                                            sq_counters=(json.load(open(sq)) if os.path.exists(sq) else None))
             del g_tracks, g_vis, g_score, tn, p3
             torch.cuda.empty_cache()
         parity_c3 = None
@@ -627,7 +716,25 @@ def main():
         if world == 1 and not args.no_pipeline and args.workload == "c3":
             del prob
             torch.cuda.empty_cache()
-            pipeline = pipeline_leg(dev)
+            try:
+                pipeline = pipeline_leg(dev)
+            except Exception as exc:                          # (an auxiliary leg must not cost the line)
+                pipeline = dict(error=f"{type(exc).__name__}: {exc}")
+        # ---- BASELINE configs[4]: the 1000-frame video loop once, then its FINAL joint problem (n = 6002) on the GPU and by
+        # the port from the same start
+        video_c5 = None
+        if world == 1 and args.workload == "c3" and not args.no_parity_c5 and not args.no_cpu_baseline:
+            try:
+                import contextlib
+                import importlib.util
+                import io
+                spec = importlib.util.spec_from_file_location("run_c5_video", os.path.join(ROOT, "scripts", "run_c5_video.py"))
+                c5 = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(c5)
+                with contextlib.redirect_stdout(io.StringIO()):
+                    video_c5 = c5.run_video(parity_iters=args.parity_iters, parity_fn=parity_vs_port)
+            except Exception as exc:
+                video_c5 = dict(error=f"{type(exc).__name__}: {exc}")
         out = {
             "metric": "BA LM-iterations/sec",
             "value": args.steps / dt if strong_main else args.steps * world / dt,
@@ -646,7 +753,8 @@ def main():
             "config": {"workload": (f"synthetic {S} frames x {N} tracks split over {world} rank(s), {cam_type} per-frame intrinsics, "
                                     "full LM (BASELINE configs[3])" if strong_main else
                                     f"synthetic {S} frames x {N} tracks per GPU, {cam_type}"
-                                    f"{' shared_camera' if shared else ''}, full LM (BASELINE configs[2] at N=1)"),
+                                    f"{' shared_camera' if shared else ' per-frame intrinsics'}, full LM "
+                                    f"({BASELINE_CONFIG[args.workload]}{' per GPU' if world > 1 else ''})"),
                        "frames": S, "tracks_per_gpu": (N // world if strong_main else N), "observations_per_gpu": n_obs,
                        "reduced_system": n_red,
                        "parallelism": f"points sharded x{world}, cameras replicated, RCCL all-reduce of the camera blocks, "
@@ -661,6 +769,9 @@ def main():
             "cpu_baseline": cpu,
             "pose_delta_vs_port": parity,
             "pose_delta_vs_port_c3": parity_c3,
+            "pose_delta_vs_port_c4": parity_c4,
+            "pose_delta_vs_port_c5_joint": None if video_c5 is None else video_c5.get("pose_delta_vs_port_final_joint", video_c5),
+            "video_c5": None if video_c5 is None else {k: v for k, v in video_c5.items() if k not in ("pose_delta_vs_port_final_joint", "joint_ba_log")},
             "strong_scaling_c4": strong,
             "n1_same_problem": n1,
             "speedup_vs_n1": (args.steps / dt) / n1["lm_iterations_per_s"] if (n1 and strong_main) else None,

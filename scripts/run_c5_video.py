@@ -31,17 +31,15 @@ def rodrigues(w):
     return np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--frames", type=int, default=1000)
-    ap.add_argument("--points", type=int, default=500000)
-    ap.add_argument("--init", type=int, default=32)
-    ap.add_argument("--window", type=int, default=16)
-    ap.add_argument("--new-tracks", type=int, default=4096)
-    ap.add_argument("--max-query-pts", type=int, default=2048)
-    ap.add_argument("--joint-interval", type=int, default=6)
-    ap.add_argument("--out", default=None)
-    args = ap.parse_args()
+def run_video(frames=1000, points=500000, init=32, window=16, new_tracks=4096, max_query_pts=2048, joint_interval=6,
+              parity_iters=0, parity_fn=None):
+    """The loop once -> the record dict (`joint_ba_log` included).  parity_iters > 0: the inputs of the LAST joint BA of the
+    loop (all frames, n = 6 frames + 2 unknowns) are kept, and after the loop the same problem is solved for `parity_iters` LM
+    iterations from the same start on the GPU and by the CPU port (`parity_fn` = bench.parity_vs_port; the checker is
+    only ever called from there) -> `pose_delta_vs_port_final_joint`."""
+    import types
+    args = types.SimpleNamespace(frames=frames, points=points, init=init, window=window, new_tracks=new_tracks,
+                                 max_query_pts=max_query_pts, joint_interval=joint_interval)
     dev = "cuda"
     T, N, W, f, k1 = args.frames, args.points, 1024.0, 1000.0, 0.02
     rng = np.random.default_rng(3)
@@ -138,8 +136,12 @@ def main():
     log = {"window": [], "joint": []}
     wba, jba = V.window_bundle_adjustment, V.joint_bundle_adjustment
 
+    last_joint = {}
+
     def timed(kind, fn):
         def wrapper(*a, **k):
+            if kind == "joint" and parity_iters > 0:
+                last_joint["args"] = a                      # (references only: the loop builds fresh tensors per call)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             out = fn(*a, **k)
@@ -153,11 +155,29 @@ def main():
     V.window_bundle_adjustment = timed("window", wba)
     V.joint_bundle_adjustment = timed("joint", jba)
 
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    table = vg.run(T, INIT, args.window, camera_prior, track_existing, track_new, joint_BA_interval=args.joint_interval)
-    torch.cuda.synchronize()
-    total = time.perf_counter() - t0
+    try:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        table = vg.run(T, INIT, args.window, camera_prior, track_existing, track_new, joint_BA_interval=args.joint_interval)
+        torch.cuda.synchronize()
+        total = time.perf_counter() - t0
+    finally:
+        V.window_bundle_adjustment, V.joint_bundle_adjustment = wba, jba
+
+    parity = None
+    if parity_iters > 0 and "args" in last_joint:
+        # video.joint_bundle_adjustment(points3d, extrinsics, intrinsics (1,3,3), tracks, masks, extra_params (1,1), camera_type, ...)
+        # normalises, then hands (pts, ext, K per frame, tracks, masks, extra per frame, shared = True) to the solver: the same here
+        jp, je, jK, jtr, jm, jx, jcam = last_joint["args"][:7]
+        je, jp = BA.normalize_reconstruction(je.to(torch.float64), jp.to(torch.float64))
+        Sj = je.shape[0]
+        if parity_fn is None:
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            import bench
+            parity_fn = bench.parity_vs_port
+        parity = parity_fn(jp, je, jK.expand(Sj, -1, -1).contiguous(), jtr, jm, jx.expand(Sj, -1).contiguous(), True, jcam, parity_iters,
+                           f"the final joint BA of the {T}-frame video loop (BASELINE configs[4]: {Sj} frames, shared {jcam})")
+        last_joint.clear()
 
     # kernel breakdown of one LM iteration of the final joint problem (HIP events, as in bench.py)
     import ctypes
@@ -214,11 +234,29 @@ def main():
                final_joint_problem_iteration_ms=it_ms, final_joint_problem_kernel_ms=kernel_ms, camera_order=order_info,
                table_points=int(table.num_points), table_observations=int(table.num_observations),
                max_rotation_error_rad=float(ang.max()), max_centre_error=float((c_est - c_gt).norm(dim=1).max()), path_length=path,
-               focal=float(vg.intrinsics[0, 0, 0]), k1=float(vg.extra_params[0, 0]))
-    print(json.dumps(out))
-    if args.out:
-        with open(args.out, "w") as fh:
-            json.dump(dict(out, joint_ba_log=log["joint"]), fh, indent=1)
+               focal=float(vg.intrinsics[0, 0, 0]), k1=float(vg.extra_params[0, 0]), pose_delta_vs_port_final_joint=parity,
+               joint_ba_log=log["joint"])
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=1000)
+    ap.add_argument("--points", type=int, default=500000)
+    ap.add_argument("--init", type=int, default=32)
+    ap.add_argument("--window", type=int, default=16)
+    ap.add_argument("--new-tracks", type=int, default=4096)
+    ap.add_argument("--max-query-pts", type=int, default=2048)
+    ap.add_argument("--joint-interval", type=int, default=6)
+    ap.add_argument("--parity-iters", type=int, default=0,
+                    help="> 0: the final joint problem also on the CPU port for this many LM iterations (bench.parity_vs_port)")
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    out = run_video(a.frames, a.points, a.init, a.window, a.new_tracks, a.max_query_pts, a.joint_interval, a.parity_iters)
+    print(json.dumps({k: v for k, v in out.items() if k != "joint_ba_log"}))
+    if a.out:
+        with open(a.out, "w") as fh:
+            json.dump(out, fh, indent=1)
 
 
 if __name__ == "__main__":

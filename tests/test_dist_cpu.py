@@ -208,3 +208,45 @@ def test_chunk_ranges_cover_every_chunk_once():
             b = chunk_ranges(nc, w)
             assert b[0] == 0 and b[-1] == nc and all(x <= y for x, y in zip(b, b[1:])) and len(b) == w + 1
             assert max(y - x for x, y in zip(b, b[1:])) - min(y - x for x, y in zip(b, b[1:])) <= 1
+
+
+def _rng_worker(rank, world, port, out):
+    """triangulate_tracks_sharded's RNG contract (ADVICE r4): for the duration of the call every rank draws from rank 0's
+    stream; afterwards rank 0 is where a single-rank run would be and every other rank is back on its OWN stream."""
+    from vggsfm_amd.dist import _adopt_rank0_rng
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                              # ranks arrive with different states
+    expect_own = torch.get_rng_state().clone()
+    own = _adopt_rank0_rng(torch.device("cpu"))
+    draw = torch.randperm(1000)                                # (what _draw_pairs does, once per reference chunk)
+    if rank != 0:
+        torch.set_rng_state(own)                               # what triangulate_tracks_sharded does behind the call
+    after = torch.randperm(1000)
+    out.put((rank, draw.numpy(), after.numpy(), bool(torch.equal(own, expect_own))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_rank0_rng_is_borrowed_not_kept():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rng_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict()
+    for _ in range(world):
+        r, draw, after, own_ok = q.get(timeout=120)
+        res[r] = (draw, after, own_ok)
+    for p in procs:
+        p.join(timeout=60)
+    assert np.array_equal(res[0][0], res[1][0])                # the call's draws agree on both ranks
+    assert res[0][2] and res[1][2]
+    g0 = torch.Generator().manual_seed(100)
+    assert np.array_equal(res[0][0], torch.randperm(1000, generator=g0).numpy())
+    assert np.array_equal(res[0][1], torch.randperm(1000, generator=g0).numpy())      # rank 0: advanced by the draws
+    g1 = torch.Generator().manual_seed(101)
+    assert np.array_equal(res[1][1], torch.randperm(1000, generator=g1).numpy())      # rank 1: its own stream, untouched

@@ -176,7 +176,7 @@ __device__ __forceinline__ void smallest_eigvec4_fast(const Sym4& m, double* v, 
   // (the last resort: ~5 lanes per million at configs[1] / [2] -- 96 of 23 M, 544 of 115 M solves with -DVGG_TRI_STATS -- whose
   //  two smallest eigenvalues agree to rounding.  Dropping it is worth 0.2 ms of 18 at configs[2] and changed ONE mask bit in
   //  4.9 million there (such a hypothesis can still pass the triangulation-angle test): kept, so that the masks are what the
-  //  Jacobi-only kernel of rounds 1-3 produced, bit for bit)
+  //  Jacobi-only kernel of rounds 1-3 produced on every golden and at configs[2])
   if (!done) smallest_eigvec4(m, v);
 #else
   smallest_eigvec4(m, v);
@@ -354,7 +354,9 @@ __device__ __forceinline__ Cand eval_views(const double* __restrict__ ext, const
 // idle for two passes over the views -- a quarter of the kernel at 200 views).  The lanes of a group evaluate kGV
 // consecutive views at once; their contributions are then added to the group's accumulators ONE VIEW AT A TIME, in view
 // order, by every lane of the group alike (the values come over with ds_bpermute, a skipped view leaves the accumulator
-// untouched): the same additions in the same order as eval_views -- bit-identical counts, sums and DLT matrices.
+// untouched): the same additions in the same order as eval_views.  (This file is compiled with -ffp-contract=fast: the
+// compiler may fuse the same expression differently in each inlined context, so "same order" is a statement about the source;
+// what is CHECKED is that masks and counts are unchanged on every golden -- ADVICE r4.)
 // src0 = first lane of this lane's group, vq = its position inside the group.
 constexpr int kGV = 6;
 static_assert(10 * kGV <= 64, "ten hypotheses of the second local-optimisation round, kGV lanes each");
@@ -705,7 +707,7 @@ __global__ __launch_bounds__(64, VGG_TRI_OCC) void triangulate_kernel(   // (rou
 
 // Two-view DLT of every track between frame 0 and frame s (triangulate_by_pair, triangulation.py:45-135):
 // one thread per (s, track).  The DLT matrix of a view is built with exactly the expressions of the per-view
-// table of triangulate_kernel, so the point is bit-identical to that kernel's two-view hypothesis (0, s).
+// table of triangulate_kernel (same source expressions; golden tri_by_pair.npz is the check).
 __device__ __forceinline__ void view_dlt_matrix(const double* __restrict__ P, double u, double v, Sym4& m) {
   const double nr = sqrt(u * u + v * v + 1.0);
   view_dlt_matrix_r(P, u / nr, v / nr, 1.0 / nr, m);

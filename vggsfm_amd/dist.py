@@ -72,14 +72,18 @@ def _gather_rows(local, counts, group=None):
 
 
 def _adopt_rank0_rng(device, group=None):
-    """Every rank continues from rank 0's global CPU RNG state (5 KB broadcast; through the device for RCCL, which moves
-    device memory only)."""
+    """Every rank draws from rank 0's global CPU RNG state for the duration of one call (5 KB broadcast; through the device
+    for RCCL, which moves device memory only).  Returns the rank's OWN state from before the call: the caller puts it back
+    afterwards on every rank but the source, so that later per-rank randomness (sampling, shuffles) stays per-rank
+    (ADVICE r4); rank 0 keeps the stream the draws advanced, as a single-rank run would.  A collective: every rank of the
+    group must make the call."""
     import torch.distributed as dist
-    state = torch.get_rng_state()
+    own = torch.get_rng_state()
     on_device = dist.get_backend(group) == "nccl"
-    buf = state.to(device) if on_device else state.clone()
+    buf = own.to(device) if on_device else own.clone()
     dist.broadcast(buf, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     torch.set_rng_state(buf.cpu())
+    return own
 
 
 def triangulate_tracks_sharded(extrinsics, tracks_normalized, rank, world_size, track_vis=None, track_score=None, gather=True,
@@ -92,18 +96,24 @@ def triangulate_tracks_sharded(extrinsics, tracks_normalized, rank, world_size, 
     its track range.
     sync_rng (default): the draws come from the global CPU RNG, which a rank may have consumed differently before this call
     (data loading, per-rank seeding) -- the gathered result would then silently differ from the single-rank one -- so every
-    rank first adopts rank 0's RNG state; False: the caller guarantees identical states (or has no process
-    group: the lock-step tests)."""
+    rank draws from rank 0's RNG state for this call and gets its own state back afterwards (only rank 0's
+    stream is advanced by the draws); a COLLECTIVE -- every rank must pass the same sync_rng; False: the caller guarantees
+    identical states (or has no process group: the lock-step tests)."""
     from .utils.triangulation import reference_chunks, triangulate_tracks
+    own_rng = None
     if sync_rng and world_size > 1:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
-            _adopt_rank0_rng(tracks_normalized.device, group)
+            own_rng = _adopt_rank0_rng(tracks_normalized.device, group)
     S, N = tracks_normalized.shape[0], tracks_normalized.shape[1]
     chunk_size, num_chunks = reference_chunks(S, N, kw.get("max_tri_points_num", 819200))
     b = chunk_ranges(num_chunks, world_size)
-    pts, num, msk = triangulate_tracks(extrinsics, tracks_normalized, track_vis=track_vis, track_score=track_score,
-                                       chunk_range=(b[rank], b[rank + 1]), **kw)
+    try:
+        pts, num, msk = triangulate_tracks(extrinsics, tracks_normalized, track_vis=track_vis, track_score=track_score,
+                                           chunk_range=(b[rank], b[rank + 1]), **kw)
+    finally:
+        if own_rng is not None and rank != 0:
+            torch.set_rng_state(own_rng)
     if not gather or world_size == 1:
         return pts, num, msk, (min(N, b[rank] * chunk_size), min(N, b[rank + 1] * chunk_size))
     counts = [min(N, b[r + 1] * chunk_size) - min(N, b[r] * chunk_size) for r in range(world_size)]

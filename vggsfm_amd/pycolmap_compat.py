@@ -1080,11 +1080,13 @@ class BundleAdjuster:
         # those images in the problem with constant poses (COLMAP adds them); the reference never builds such a config, so
         # that case raises instead of silently losing the observations.
         rec = self.reconstruction
-        ptr, timg, _ = rec._track_csr()
-        registered = np.isin(timg, np.asarray(rec.reg_image_ids(), np.int64))
-        inside = np.isin(timg, np.asarray(cfg.image_ids, np.int64))
-        pid_of_obs = np.repeat(np.arange(1, len(ptr)), np.diff(ptr))
-        partly_outside = {int(p) for p in np.unique(pid_of_obs[registered & ~inside])}
+        partly_outside = set()
+        if not set(rec.reg_image_ids()) <= set(cfg.image_ids):    # (every reference call site: the config holds them all)
+            ptr, timg, _ = rec._track_csr()
+            registered = np.isin(timg, np.asarray(rec.reg_image_ids(), np.int64))
+            inside = np.isin(timg, np.asarray(cfg.image_ids, np.int64))
+            pid_of_obs = np.repeat(np.arange(1, len(ptr)), np.diff(ptr))
+            partly_outside = {int(p) for p in np.unique(pid_of_obs[registered & ~inside])}
         lost = partly_outside & set(cfg.variable_point3D_ids)
         if lost:
             raise NotImplementedError(f"BundleAdjustmentConfig: {len(lost)} variable point(s) (e.g. id {min(lost)}) are observed in "

@@ -103,11 +103,11 @@ def triangulate_tracks(extrinsics, tracks_normalized, max_ransac_iters=256, lo_n
     bit.
     Error behaviour: non-finite normalised tracks raise ``torch.linalg.LinAlgError`` as in the reference, whose batched
     ``eigh`` fails on the DLT matrix of a view pair with such a ray whether the view is visible or not
-    (triangulation_helpers.py:87; checked live against the reference in the CPU suite).  `check_finite=False` skips the test (one reduction
-    + host read): the kernel then treats such a track as the reference's NaN mean would -- all its RANSAC hypotheses void."""
-    if check_finite and not bool(torch.isfinite(tracks_normalized).all()):
-        raise torch.linalg.LinAlgError("triangulate_tracks: non-finite normalised track coordinates (the reference's "
-                                       "linalg.eigh fails on the DLT matrices of such views)")
+    (triangulation_helpers.py:87; checked live against the reference in the CPU suite).  The test is one reduction ENQUEUED in
+    front of the launches and read together with the call's one synchronisation at the end (no host round trip before the
+    asynchronous chunk groups) -- the error is raised after the kernel has run, nothing is returned.
+    `check_finite=False` skips it: the kernel then treats such a track as the reference's NaN mean would -- all its RANSAC
+    hypotheses void."""
     if max_ransac_iters > 256 or lo_num > 64 or max_ransac_iters < 1 or lo_num < 1:
         raise ValueError(f"triangulate_tracks: max_ransac_iters={max_ransac_iters} (1..256) / lo_num={lo_num} (1..64) are outside "
                          "what vgg_triangulate_tracks_chunks supports (the reference calls it with 256 or 128, and 50)")
@@ -115,6 +115,7 @@ def triangulate_tracks(extrinsics, tracks_normalized, max_ransac_iters=256, lo_n
     L = _lib.lib()
     S, N = tracks_normalized.shape[0], tracks_normalized.shape[1]
     dev = tracks_normalized.device
+    finite = torch.isfinite(tracks_normalized).all().to(torch.int64).reshape(1) if check_finite else None   # (device, not read yet)
     chunk_size, total_chunks = reference_chunks(S, N, max_tri_points_num)
     c0, c1 = (0, total_chunks) if chunk_range is None else (max(0, int(chunk_range[0])), min(total_chunks, int(chunk_range[1])))
     c1 = max(c0, c1)
@@ -174,10 +175,18 @@ def triangulate_tracks(extrinsics, tracks_normalized, max_ransac_iters=256, lo_n
                 _lib.ptr(num[ta:tb]), _lib.ptr(mask[ta:tb]), _lib.ptr(thr_dev[g0:g1]), _lib.ptr(gmax_dev[g0:g1]), _lib.ptr(centers),
                 _lib.stream_ptr()), "vgg_triangulate_tracks_chunks_enqueue")
         pending, g_first = [], c + 1
+    def raise_if_nonfinite(flag):
+        if flag is not None and not int(flag):
+            raise torch.linalg.LinAlgError("triangulate_tracks: non-finite normalised track coordinates (the reference's "
+                                           "linalg.eigh fails on the DLT matrices of such views)")
     if n_loc == 0 or nc == 0:
+        raise_if_nonfinite(None if finite is None else finite.cpu()[0])
         return pts, num, mask.bool()
     # the one synchronisation of the call: the largest mean inlier error of every chunk (the indicator's chunk-global threshold)
-    measured = gmax_dev.cpu().numpy().view("float64") + 1e-6
+    # and, behind it in the same copy, the finiteness flag of the input
+    back = (gmax_dev if finite is None else torch.cat([gmax_dev, finite])).cpu().numpy()
+    raise_if_nonfinite(None if finite is None else back[-1])
+    measured = back[:max(nc, 1)].copy().view("float64") + 1e-6
     if not (measured == first_thr).all():
         # (pathological: every hypothesis of a chunk has an inlier -- the threshold the launch assumed was not the chunk's
         #  maximum; run again with the measured ones, synchronously, as rounds 1-3 did)

@@ -1114,6 +1114,9 @@ __device__ long long g_tile_trace[2048 * 4 * 8];   // [workgroup][wave][batches,
 #ifndef VGG_DIAG_PARITY
 #define VGG_DIAG_PARITY 1           // diagonal tiles: sub-tiles dealt to the wavefronts by parity class (0: every fourth, round 3)
 #endif
+#ifndef VGG_TILE_PIPE
+#define VGG_TILE_PIPE 1             // compressed off-diagonal tiles: the last K step of a batch behind its barrier (round 5; 0: plain order)
+#endif
 #ifndef VGG_NO_SKIP
 #define VGG_NO_SKIP 0               // profiling builds: 1 = every sub-tile of every batch runs (no presence skipping)
 #endif
@@ -1399,6 +1402,83 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
       bitsA[i] = block_slot_bits<BD>(wr + 2 * i);
       bitsB[i] = block_slot_bits<BD>(wc + 2 * i) << 16;
     }
+#if VGG_TILE_PIPE
+    if constexpr (CY) {
+      // PIPELINED BARRIER (round 5, compressed 6 x 6 off-diagonal tiles): the LAST K step of a batch is issued BEHIND the
+      // batch's barrier.  Per step:  [loads of b+DEPTH] [K steps 0, 1 of b; operands of K step 2 fetched] [LDS image of b+1]
+      // [barrier] [operands of K step 0 of b+1 requested] [K step 2 of b].  The matrix instructions of K step 2 (their
+      // operands sit in registers since before the barrier) cover the LDS round trip of the next batch's first operands,
+      // which the plain order exposes on every wavefront right behind every barrier (profiles/r05_tile_diag_ablations.jsonl:
+      // without LDS operand reads the launch is 8 % shorter).  Hazards: every read of buffer `buf` (K steps 0..2 of b) is
+      // complete before barrier(b) -- the fetches are waited for by the `pin`s in front of it --, buffer buf is rewritten
+      // (batch b + 2) in step b + 1's write phase, behind that barrier; buffer buf^1 (batch b + 1) is read behind barrier(b),
+      // which follows its writes.  Same matrix instructions in the same order per accumulator: bit-identical sums.
+      // Same-box A/B (profiles/r05_ab_tile_pipe_c3.jsonl): off-diagonal launch 0.578 -> 0.560 ms.  The same order for the
+      // diagonal tiles (a second operand set at 128 registers) measured SLOWER (0.256 -> 0.269 ms) and is not in the tree.
+      double a[2][NH], bq[2][NH];
+      auto fetch = [&](int set, int buf, int ks) __attribute__((always_inline)) {
+        const double* As = ops + (size_t)(buf * SIDES) * 4 * SEG;
+        const double* Bs = ops + (size_t)(buf * SIDES + 1) * 4 * SEG;
+#pragma unroll
+        for (int i = 0; i < NH; ++i) { a[set][i] = As[rowoffA[i] + ks * R]; bq[set][i] = Bs[rowoffB[i] + ks * R]; }
+      };
+      auto pin = [&](int set) __attribute__((always_inline)) {
+        static_assert(NH == 3, "operand sets");
+        asm volatile("" : "+v"(a[set][0]), "+v"(a[set][1]), "+v"(a[set][2]), "+v"(bq[set][0]), "+v"(bq[set][1]), "+v"(bq[set][2]));
+      };
+      uint32_t on = 0u;
+      auto skip_bits = [&](uint32_t qm) -> uint32_t {
+        uint32_t colm = 0u, o = 0u;
+#pragma unroll
+        for (int j = 0; j < NH; ++j) colm |= ((qm & bitsB[j]) != 0 ? 1u : 0u) << j;
+#pragma unroll
+        for (int i = 0; i < NH; ++i) o |= ((qm & bitsA[i]) != 0 ? colm : 0u) << (NH * i);
+        return VGG_NO_SKIP ? 0xFFFFFFFFu : (uint32_t)__builtin_amdgcn_readfirstlane((int)o);
+      };
+      auto group = [&](int set) __attribute__((always_inline)) {
+        uint32_t m = on;
+        asm volatile("" : "+s"(m));
+#pragma unroll
+        for (int i = 0; i < NH; ++i)
+#pragma unroll
+          for (int j = 0; j < NH; ++j)
+            if (m & (1u << (NH * i + j))) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[set][i], bq[set][j], acc[i][j], 0, 0, 0);
+      };
+      // step of batch b; P = the operand set that holds K step 0 of b on entry (alternates from step to step)
+      auto pstep = [&](int b, int buf, const int P, double2 (&sv_load)[NV], const double2 (&sv_write)[NV]) __attribute__((always_inline)) {
+        const int seg_after = load_seg_index(ebase(b + DEPTH + 1));
+        issue_loads(sv_load, seg_next, valid_next);
+        seg_next = seg_after;
+        valid_next = seg_valid(ebase(b + DEPTH + 1));
+        __builtin_amdgcn_s_setprio(0);
+        on = skip_bits(qmask);
+        fetch(1 - P, buf, 1); pin(P);
+        group(P);                                     // K step 0
+        fetch(P, buf, 2); pin(1 - P);
+        group(1 - P);                                 // K step 1
+        pin(P);                                       // (the operands of K step 2 have landed: no read of `buf` is left)
+        __builtin_amdgcn_s_setprio(3);
+        qmask = qmask_next;
+        qmask_next = load_quad_mask(ebase(b + 2));
+        write_lds(sv_write, buf ^ 1);
+        __syncthreads();
+        fetch(1 - P, buf ^ 1, 0);                     // K step 0 of batch b + 1 (stale bytes behind the last batch: never used)
+        __builtin_amdgcn_s_setprio(0);
+        pin(P);                                       // (keeps the matrix instructions below behind the barrier)
+        group(P);                                     // K step 2 of batch b
+      };
+      fetch(0, 0, 0);
+      constexpr int TRIP = 2 * DEPTH;
+      int b = 0;
+      for (; b + TRIP - 1 < nb; b += TRIP) {
+#pragma unroll
+        for (int u = 0; u < TRIP; ++u) pstep(b + u, u & 1, u & 1, sv[u % DEPTH], sv[(u + 1) % DEPTH]);
+      }
+#pragma unroll
+      for (int u = 0; u < TRIP - 1; ++u)
+        if (b + u < nb) pstep(b + u, u & 1, u & 1, sv[u % DEPTH], sv[(u + 1) % DEPTH]);
+    } else
+#endif
     sweep([&](int buf, uint32_t qm, auto&& wr) {
       const double* As = ops + (size_t)(buf * SIDES) * 4 * SEG;
       const double* Bs = ops + (size_t)(buf * SIDES + 1) * 4 * SEG;

@@ -1414,7 +1414,9 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
       // (batch b + 2) in step b + 1's write phase, behind that barrier; buffer buf^1 (batch b + 1) is read behind barrier(b),
       // which follows its writes.  Same matrix instructions in the same order per accumulator: bit-identical sums.
       // Same-box A/B (profiles/r05_ab_tile_pipe_c3.jsonl): off-diagonal launch 0.578 -> 0.560 ms.  The same order for the
-      // diagonal tiles (a second operand set at 128 registers) measured SLOWER (0.256 -> 0.269 ms) and is not in the tree.
+      // diagonal tiles (a second operand set at 128 registers) measured SLOWER (0.256 -> 0.269 ms), and so did the same order
+      // for the 8 x 8 full-factor tiles with their interleaved LDS writes (configs[3] whole: 13.13 -> 13.35 ms,
+      // profiles/r05_ab_tile_pipe_c4full.jsonl): neither is in the tree.
       double a[2][NH], bq[2][NH];
       auto fetch = [&](int set, int buf, int ks) __attribute__((always_inline)) {
         const double* As = ops + (size_t)(buf * SIDES) * 4 * SEG;

@@ -437,7 +437,12 @@ def main():
             torch.cuda.empty_cache()
         barrier()
     prob, sc, host_init = build(args.workload)
-    dt, fin, prof = timed(prob, args.steps, args.warmup, True)
+    # The timed region runs UNOBSERVED; the per-kernel HIP events ride on a second pass of the same K steps right behind it.
+    # An event pair around a launch costs ~5 us of stream time on each side on this stack (profiles/r05_timeline_c3.json: 54
+    # of 1684 us per LM iteration of configs[2] were gaps next to the seven observed launches, none between the others), so
+    # observing inside the region made it 3 % slower than the work it times.  `ms_per_step_with_events` is the second pass.
+    dt, fin, _ = timed(prob, args.steps, args.warmup, False)
+    dt_events, _, prof = timed(prob, args.steps, 0, True)
     # ---- N > 1 with the strong problem as the main one: weak-scaling leg on configs[2] shards
     weak = None
     if world > 1 and strong_main and not args.no_weak_leg:
@@ -748,6 +753,7 @@ def main():
             "lm_iterations_per_s_global": args.steps / dt,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
+            "ms_per_step_with_events": 1e3 * dt_events / args.steps,
             "higher_is_better": True, "scaling": "strong" if strong_main else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": (f"synthetic {S} frames x {N} tracks split over {world} rank(s), {cam_type} per-frame intrinsics, "

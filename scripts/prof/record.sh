@@ -6,7 +6,7 @@
 #   <tag>_pmc_fetch_write_c3.json       FETCH_SIZE / WRITE_SIZE per kernel, separate --pmc passes (scripts/prof/pmc_traffic.sh)
 #   <tag>_bench_c4full.json (+ _kernel_stats.csv)   configs[3] whole on one GPU
 #   <tag>_c5_video.json, <tag>_c1_kitchen.json      configs[4] (1000-frame video loop) and configs[0] (kitchen plumbing) once
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -27,3 +27,9 @@ cd $ROOT
 python scripts/prof/compile_profile.py > $OUT/compile_profile.txt 2>&1
 python scripts/run_c5_video.py --out $OUT/${TAG}_c5_video.json > $OUT/c5.log 2>&1
 python scripts/run_c1_kitchen.py --stage run --out $OUT/${TAG}_c1_kitchen.json > $OUT/c1.log 2>&1
+#   <tag>_timeline_c3.json              every launch of an LM iteration with its duration and the gap in front of it
+#   <tag>_pmc_sq_tri.json               SQ counters of triangulate_kernel (bench.py reads the committed copy)
+bash $ROOT/scripts/prof/timeline.sh > $OUT/timeline.log 2>&1
+cp $ROOT/gpurun_out/timeline/timeline_summary.json $OUT/${TAG}_timeline_c3.json
+bash $ROOT/scripts/prof/pmc_sq_tri.sh > $OUT/pmc_sq_tri.log 2>&1
+cp $ROOT/gpurun_out/pmc/r05_pmc_sq_tri.json $OUT/${TAG}_pmc_sq_tri.json

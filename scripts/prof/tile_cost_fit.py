@@ -60,8 +60,31 @@ for name, col in (("busiest", 1), ("mean", 2)):
     pred = A @ coef
     print(f"{name:8s}: cycles ~ {coef[0]:.0f} * batches + {coef[1]:.1f} * matrix_instructions   (fixed cost = {coef[0] / coef[1]:.1f} instructions; "
           f"rms rel err {np.sqrt(np.mean(((pred - r[:, 3]) / r[:, 3]) ** 2)):.3f})")
-cur = BA.TILE_FIXED_COST * r[:, 0] + r[:, 1]
+cur = 18.0 * r[:, 0] + r[:, 1]
 print("current model: spread of predicted cost per workgroup (p10 / p90 of cost/mean):", np.percentile(cur / cur.mean(), [10, 90]).round(3),
       " measured cycles/mean:", np.percentile(r[:, 3] / r[:, 3].mean(), [10, 50, 90, 100]).round(3))
 print("batches per workgroup p10/p50/p90:", np.percentile(r[:, 0], [10, 50, 90]), " matrix instr per batch (busiest) p10/p50/p90:",
       np.percentile(r[:, 1] / r[:, 0], [10, 50, 90]).round(1))
+
+# per TILE: cycles per batch (mean over its workgroups) against its matrix instructions per batch
+tiles = {}
+for c in range(min(noff, 768)):
+    if t[c, :, 5].mean() <= 0:
+        continue
+    key = (int(cd[c, 0]), int(cd[c, 1]))
+    tiles.setdefault(key, []).append(c)
+rowsT = []
+for key, cs in tiles.items():
+    rr = np.array([rows[c] for c in cs])
+    rowsT.append((key[0], key[1], len(cs), rr[:, 0].sum(), rr[:, 1].sum() / rr[:, 0].sum(), rr[:, 2].sum() / rr[:, 0].sum(), rr[:, 3].sum() / rr[:, 0].sum()))
+T = np.array(rowsT, float)
+for name, col in (("busiest", 4), ("mean", 5)):
+    A = np.stack([np.ones(len(T)), T[:, col]], 1)
+    coef, *_ = np.linalg.lstsq(A, T[:, 6], rcond=None)
+    pred = A @ coef
+    print(f"per tile, {name}: cycles/batch ~ {coef[0]:.0f} + {coef[1]:.1f} * instr/batch  (fixed = {coef[0] / coef[1]:.1f} instr; rms rel {np.sqrt(np.mean(((pred - T[:, 6]) / T[:, 6]) ** 2)):.3f})")
+print("tile gI gJ wgs batches busiest/batch mean/batch cycles/batch")
+for r_ in T[np.argsort(-T[:, 6])][:8]:
+    print("  slow", r_.round(1))
+for r_ in T[np.argsort(T[:, 6])][:6]:
+    print("  fast", r_.round(1))

@@ -171,8 +171,15 @@ class DeviceProblem:
 
 
 QUAD_SORT_WINDOW = int(os.environ.get("VGGSFM_QUAD_SORT_WINDOW", "512"))   # entries; 0 = plain sweep order inside a tile
-TILE_FIXED_COST = 18.0   # cost of a tile batch besides its matrix instructions, in matrix instructions of one wavefront
-#                          (staging, LDS write phase, barrier: ~2400 of ~5000 cycles per batch in the round-3 phase trace)
+# (off-diagonal, diagonal) launch: cost of a tile batch besides its matrix instructions, in matrix instructions of one wavefront
+# (staging, LDS write phase, barrier: ~2400 of ~5000 cycles per batch in the round-3 phase trace).  Round 5, same-box sweep on
+# configs[2] (profiles/r05_ab_tile_fixed_cost_c3.jsonl): the off-diagonal launch with 6 x 6 blocks is 2.5 % shorter with a
+# SMALL fixed part (0 .. 10: 0.543 ms against 0.558 at 18 -- dense tiles get more of the workgroups), the diagonal launch does
+# not care between 18 and 200 and loses 15 % at 6; the 7 x 7 / 8 x 8 variants keep the value they were measured with.
+TILE_FIXED_COST = {6: (8.0, 18.0), 7: (18.0, 18.0), 8: (18.0, 18.0)}
+TILE_TOP_UP = os.environ.get("VGGSFM_TILE_TOP_UP", "1") != "0"   # hand the slots the chunk-size search leaves empty to the most loaded tiles
+TILE_POSITION_WEIGHT = 0.0        # see build_schur_tiles: extra cost of a tile per unit of launch position (0 = off: with every slot filled
+#                                   the sweep 0 .. 0.45 stayed inside the run-to-run noise, profiles/r05_ab_tile_fixed_cost_c3.jsonl)
 
 
 def _entry_cost(qmask, diag, bd, group=GROUP):
@@ -191,13 +198,18 @@ def _entry_cost(qmask, diag, bd, group=GROUP):
     ra = ((qmask[:, None] & 0xFFFF) & bits[None]) != 0        # (E, nt) row blocks with a camera
     rb = ((qmask[:, None] >> 16) & bits[None]) != 0
     off = torch.maximum(ra[:, 0::2].sum(1), ra[:, 1::2].sum(1)) * torch.maximum(rb[:, 0::2].sum(1), rb[:, 1::2].sum(1))
+    if os.environ.get("VGGSFM_TILE_COST_MODE") == "mean":          # measurement hook: the MEAN wavefront instead of the busiest
+        off = (ra.sum(1) * rb.sum(1)).double() / 4.0
     per_wave = torch.zeros((qmask.shape[0], 4), dtype=torch.long, device=dev)
     t = 0
     for r in range(nt):
         for c in range(r + 1):
             per_wave[:, t % 4] += (ra[:, r] & ra[:, c]).long()
             t += 1
-    return TILE_FIXED_COST + 3.0 * torch.where(diag, per_wave.max(1).values, off).double()
+    fx = os.environ.get("VGGSFM_TILE_FIXED_COST")                 # measurement hook "off,diag" (read per call: A/B runs switch it in-process)
+    f_off, f_diag = (float(x) for x in fx.split(",")) if fx else TILE_FIXED_COST[bd]
+    fixed = torch.where(diag, torch.full_like(off, f_diag, dtype=torch.float64), torch.full_like(off, f_off, dtype=torch.float64))
+    return fixed + 3.0 * torch.where(diag, per_wave.max(1).values, off).double()
 
 
 def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=None, num_batches=1, later_scale=1.0,
@@ -323,39 +335,75 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
         if bool(sel.any()):
             kweight[sel] = (tcost[sel] / kcounts[sel].double()) / (tcost[sel].sum() / kcounts[sel].sum().double())
     kw = kcounts.double() * kweight
-    nsub_t = (kcounts + SUB - 1) // SUB                      # a workgroup needs at least one sub-chunk
-    csize = torch.full_like(kcounts, chunk)
-    if max_chunks is not None:
-        # one resident round per launch: the smallest chunk size (multiple of SUB, >= MIN_CHUNK) whose workgroup
-        # count fits the device (CUs x workgroups per CU), so no workgroup starts late and runs alone on its CU
-        caps = max_chunks if isinstance(max_chunks, (tuple, list)) else (max_chunks, max_chunks)
-        if merged_slots is not None:
-            # ONE launch for both kinds of tiles (small problems): its resident slots are shared in proportion to the
-            # staged bytes (two segments per off-diagonal entry, one per diagonal entry)
-            kc0, dg0 = kcounts.cpu(), is_diag.cpu()
-            e_off, e_diag = float(kc0[~dg0].sum()), float(kc0[dg0].sum())
-            n_off = int(round(merged_slots * 2.0 * e_off / max(2.0 * e_off + e_diag, 1.0)))
-            n_off = min(max(n_off, 1 if e_off else 0), merged_slots - (1 if e_diag else 0))
-            caps = (max(n_off, 1), max(merged_slots - n_off, 1))
-        # (the search runs on host copies of the per-tile counts: one synchronisation instead of one per probe)
-        kc_h, diag_h, tb_h, kw_h, ns_h = kcounts.cpu(), is_diag.cpu(), tbatch.cpu(), kw.cpu(), nsub_t.cpu()
-        csize_h = torch.full_like(kc_h, chunk)
-        for b in range(nb):
-            scale = 1.0 if b == 0 else later_scale
-            for sel, cap in ((~diag_h & (tb_h == b), int(caps[0] * scale)), (diag_h & (tb_h == b), int(caps[1] * scale))):
-                if not bool(sel.any()):
-                    continue
-                kc, kwv, nsv = kc_h[sel], kw_h[sel], ns_h[sel]
-                lo, hi = MIN_CHUNK // SUB, max(MIN_CHUNK // SUB, int(-(-int(max(float(kwv.max()), float(kc.max()))) // SUB)))
-                fits = lambda c: int(torch.minimum(torch.clamp(torch.ceil(kwv / (c * SUB)), min=1).long(), nsv).sum()) <= cap
-                if not fits(hi):
-                    lo = hi                         # more tiles than slots: one workgroup per tile
-                while lo < hi:
-                    mid = (lo + hi) // 2
-                    lo, hi = (lo, mid) if fits(mid) else (mid + 1, hi)
-                csize_h[sel] = lo * SUB
-        csize = csize_h.to(dev)
-    nchunks = torch.minimum(torch.clamp(torch.ceil(kw / csize.double()), min=1).long(), nsub_t)
+    # (upper bound of a tile's workgroups: at least MIN_CHUNK entries each -- one sub-chunk at the very least)
+    nsub_t = torch.clamp(torch.minimum((kcounts + SUB - 1) // SUB, (kcounts + MIN_CHUNK - 1) // MIN_CHUNK), min=1)
+
+    def size_chunks(kw):
+        """workgroups per tile for the cost-weighted entry counts kw"""
+        csize = torch.full_like(kcounts, chunk)
+        if max_chunks is not None:
+            # one resident round per launch: the smallest chunk size (multiple of SUB, >= MIN_CHUNK) whose workgroup
+            # count fits the device (CUs x workgroups per CU), so no workgroup starts late and runs alone on its CU
+            caps = max_chunks if isinstance(max_chunks, (tuple, list)) else (max_chunks, max_chunks)
+            if merged_slots is not None:
+                # ONE launch for both kinds of tiles (small problems): its resident slots are shared in proportion to the
+                # staged bytes (two segments per off-diagonal entry, one per diagonal entry)
+                kc0, dg0 = kcounts.cpu(), is_diag.cpu()
+                e_off, e_diag = float(kc0[~dg0].sum()), float(kc0[dg0].sum())
+                n_off = int(round(merged_slots * 2.0 * e_off / max(2.0 * e_off + e_diag, 1.0)))
+                n_off = min(max(n_off, 1 if e_off else 0), merged_slots - (1 if e_diag else 0))
+                caps = (max(n_off, 1), max(merged_slots - n_off, 1))
+            # (the search runs on host copies of the per-tile counts: one synchronisation instead of one per probe)
+            kc_h, diag_h, tb_h, kw_h, ns_h = kcounts.cpu(), is_diag.cpu(), tbatch.cpu(), kw.cpu(), nsub_t.cpu()
+            csize_h = torch.full_like(kc_h, chunk)
+            topup_h = torch.zeros_like(kc_h)
+            for b in range(nb):
+                scale = 1.0 if b == 0 else later_scale
+                for sel, cap in ((~diag_h & (tb_h == b), int(caps[0] * scale)), (diag_h & (tb_h == b), int(caps[1] * scale))):
+                    if not bool(sel.any()):
+                        continue
+                    kc, kwv, nsv = kc_h[sel], kw_h[sel], ns_h[sel]
+                    lo, hi = MIN_CHUNK // SUB, max(MIN_CHUNK // SUB, int(-(-int(max(float(kwv.max()), float(kc.max()))) // SUB)))
+                    fits = lambda c: int(torch.minimum(torch.clamp(torch.ceil(kwv / (c * SUB)), min=1).long(), nsv).sum()) <= cap
+                    if not fits(hi):
+                        lo = hi                         # more tiles than slots: one workgroup per tile
+                    while lo < hi:
+                        mid = (lo + hi) // 2
+                        lo, hi = (lo, mid) if fits(mid) else (mid + 1, hi)
+                    csize_h[sel] = lo * SUB
+                    # top-up (round 5): the search stops at the first chunk size that fits, which leaves 1-3 % of the slots of
+                    # a launch empty; they go, one by one, to the tile whose workgroups carry the most
+                    n_h = torch.minimum(torch.clamp(torch.ceil(kwv / (lo * SUB)), min=1).long(), nsv)
+                    spare = cap - int(n_h.sum())
+                    if TILE_TOP_UP and 0 < spare <= 64:
+                        for _ in range(spare):
+                            load = torch.where(n_h < nsv, kwv / n_h.double(), torch.zeros_like(kwv))
+                            i = int(torch.argmax(load))
+                            if float(load[i]) <= 0.0:
+                                break
+                            n_h[i] += 1
+                        topup_h[sel] = n_h
+            csize = csize_h.to(dev)
+        nchunks = torch.minimum(torch.clamp(torch.ceil(kw / csize.double()), min=1).long(), nsub_t)
+        if max_chunks is not None and bool((topup_h > 0).any()):
+            nchunks = torch.where(topup_h.to(dev) > 0, topup_h.to(dev), nchunks)
+        return nchunks
+
+    nchunks = size_chunks(kw)
+    # POSITION weight (round 5): the workgroups of a launch are all resident at once, three (four) to a CU, and the SIMDs
+    # arbitrate oldest-first -- the workgroup that was dispatched LAST onto a CU gets the issue slots its elders leave.  Per-tile
+    # phase trace at configs[2] (scripts/prof/tile_cost_fit.py): 4450 cycles per batch in the first third of the launch, 4800
+    # in the second, 5180 in the third, for the same matrix instructions per batch.  So a tile's cost grows with the position
+    # of its workgroups in the launch: second pass with kw (1 + TILE_POSITION_WEIGHT x position fraction within its launch).
+    pw = float(os.environ.get("VGGSFM_TILE_POS_WEIGHT", TILE_POSITION_WEIGHT))
+    if pw != 0.0 and max_chunks is not None and kcounts.shape[0] > 1:
+        launch_key = tbatch * 2 + is_diag.long()                   # (units are sorted by batch, off-diagonal first)
+        cum = torch.cumsum(nchunks, 0).double()
+        first_of = torch.zeros(int(launch_key.max().item()) + 1, dtype=torch.float64, device=dev)
+        total_of = torch.zeros_like(first_of).index_add_(0, launch_key, nchunks.double())
+        starts = torch.cumsum(total_of, 0) - total_of
+        frac = ((cum - 0.5 * nchunks.double()) - starts[launch_key]) / total_of[launch_key].clamp(min=1.0)
+        nchunks = size_chunks(kw * (1.0 + pw * frac))
     ctile = torch.repeat_interleave(torch.arange(ukeys.shape[0], device=dev), nchunks)          # unit of every chunk
     cfirst = torch.cumsum(nchunks, 0) - nchunks
     local = torch.arange(ctile.shape[0], device=dev) - cfirst[ctile]

@@ -178,6 +178,7 @@ QUAD_SORT_WINDOW = int(os.environ.get("VGGSFM_QUAD_SORT_WINDOW", "512"))   # ent
 # not care between 18 and 200 and loses 15 % at 6; the 7 x 7 / 8 x 8 variants keep the value they were measured with.
 TILE_FIXED_COST = {6: (8.0, 18.0), 7: (18.0, 18.0), 8: (18.0, 18.0)}
 TILE_TOP_UP = os.environ.get("VGGSFM_TILE_TOP_UP", "1") != "0"   # hand the slots the chunk-size search leaves empty to the most loaded tiles
+TILE_ORDER = "sparse_first"        # launch order of the tiles (6 x 6 blocks): "" = (gI, gJ); "dense_first" / "sparse_first" (build_schur_tiles)
 TILE_POSITION_WEIGHT = 0.0        # see build_schur_tiles: extra cost of a tile per unit of launch position (0 = off: with every slot filled
 #                                   the sweep 0 .. 0.45 stayed inside the run-to-run noise, profiles/r05_ab_tile_fixed_cost_c3.jsonl)
 
@@ -287,7 +288,30 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     batch_of_group = torch.cummax(batch_of_group, 0).values
     # tile key: batch-major; inside a batch the off-diagonal tiles first, then the diagonal ones (separate launches)
     nn = ngroups * ngroups
-    key = batch_of_group[gA] * (2 * nn) + (gA == gB).long() * nn + gA * ngroups + gB
+    tile_pos = gA * ngroups + gB
+    order_mode = os.environ.get("VGGSFM_TILE_ORDER", TILE_ORDER if block_rows == 6 else "")
+    if order_mode in ("dense_first", "sparse_first") and nb == 1:
+        # LAUNCH ORDER of the tiles by density (round 5 experiment): the workgroups of a launch are resident three (four) to a
+        # CU -- positions p, p + CUs, p + 2 CUs -- and the oldest is served first; in (gI, gJ) order neighbouring positions
+        # hold tiles of like density.  Ordered by the mean number of 16-row block products of their entries (own patterns),
+        # every CU gets a mix.  Same-box A/B at configs[2] (profiles/r05_ab_tile_order_c3.jsonl): densest first 0.564 / 0.247 ms
+        # (off-diagonal / diagonal launch), (gI, gJ) order 0.542 / 0.252, SPARSEST FIRST 0.536 / 0.243 -- the default for 6 x 6
+        # blocks; the sums of a tile do not depend on where it is launched (final costs equal to the last bit).
+        nt_ = block_rows * group // 16
+        bits_ = torch.tensor([(((2 << min(group - 1, (16 * b + 15) // block_rows)) - 1) & ~((1 << ((16 * b) // block_rows)) - 1))
+                              for b in range(nt_)], dtype=torch.long, device=dev)
+        nblk = lambda m: ((m[:, None] & bits_[None]) != 0).sum(1)
+        prod = (nblk(seg_mask[A]) * nblk(seg_mask[B])).double()
+        tsum = torch.zeros(nn, dtype=torch.float64, device=dev).index_add_(0, tile_pos, prod)
+        tcnt = torch.zeros(nn, dtype=torch.float64, device=dev).index_add_(0, tile_pos, torch.ones_like(prod))
+        dens = tsum / tcnt.clamp(min=1.0)
+        rank = torch.empty(nn, dtype=torch.long, device=dev)
+        rank[torch.argsort(dens, descending=(order_mode == "dense_first"), stable=True)] = torch.arange(nn, device=dev)
+        tile_pos = rank[tile_pos]
+        tile_unrank = torch.argsort(rank)                              # position in the order -> gI * ngroups + gJ
+    else:
+        tile_unrank = None
+    key = batch_of_group[gA] * (2 * nn) + (gA == gB).long() * nn + tile_pos
     epos = prank[seg_pt[A]]
     order = torch.argsort(key * P + epos)
     A, B, key, epos = A[order], B[order], key[order], epos[order]
@@ -323,6 +347,8 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     tbatch = ukeys // (2 * nn)
     is_diag = (ukeys % (2 * nn)) >= nn
     ukeys = ukeys % nn
+    if tile_unrank is not None:
+        ukeys = tile_unrank[ukeys]                                     # back to gI * ngroups + gJ
     # cost-weighted entry count of every tile (relative to the mean entry of its launch kind)
     ecost = _entry_cost(qm[quad], is_diag[unit_of_entry], block_rows, group)
     # (per-tile sums of a list that is sorted by tile: differences of a running sum -- index_add_ with 5 M double atomics

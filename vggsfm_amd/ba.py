@@ -18,6 +18,7 @@ import ctypes
 from dataclasses import dataclass
 from typing import Optional
 
+import math
 import os
 import torch
 
@@ -290,7 +291,7 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     nn = ngroups * ngroups
     tile_pos = gA * ngroups + gB
     order_mode = os.environ.get("VGGSFM_TILE_ORDER", TILE_ORDER if block_rows == 6 else "")
-    if order_mode in ("dense_first", "sparse_first") and nb == 1:
+    if order_mode in ("dense_first", "sparse_first", "stride") and nb == 1:
         # LAUNCH ORDER of the tiles by density (round 5 experiment): the workgroups of a launch are resident three (four) to a
         # CU -- positions p, p + CUs, p + 2 CUs -- and the oldest is served first; in (gI, gJ) order neighbouring positions
         # hold tiles of like density.  Ordered by the mean number of 16-row block products of their entries (own patterns),
@@ -307,6 +308,12 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
         dens = tsum / tcnt.clamp(min=1.0)
         rank = torch.empty(nn, dtype=torch.long, device=dev)
         rank[torch.argsort(dens, descending=(order_mode == "dense_first"), stable=True)] = torch.arange(nn, device=dev)
+        if order_mode == "stride":                                       # (experiment: densities scattered over the launch)
+            empty = int((tcnt == 0).sum().item())                        # tiles without entries rank first (density 0)
+            live = nn - empty
+            r2 = rank - empty
+            step = next(k for k in range(max(2, int(live ** 0.5)), live + 2) if math.gcd(k, max(live, 1)) == 1)
+            rank = torch.where(r2 >= 0, empty + (r2 * step) % max(live, 1), rank)
         tile_pos = rank[tile_pos]
         tile_unrank = torch.argsort(rank)                              # position in the order -> gI * ngroups + gJ
     else:

@@ -176,10 +176,11 @@ QUAD_SORT_WINDOW = int(os.environ.get("VGGSFM_QUAD_SORT_WINDOW", "512"))   # ent
 # (staging, LDS write phase, barrier: ~2400 of ~5000 cycles per batch in the round-3 phase trace).  Round 5, same-box sweep on
 # configs[2] (profiles/r05_ab_tile_fixed_cost_c3.jsonl): the off-diagonal launch with 6 x 6 blocks is 2.5 % shorter with a
 # SMALL fixed part (0 .. 10: 0.543 ms against 0.558 at 18 -- dense tiles get more of the workgroups), the diagonal launch does
-# not care between 18 and 200 and loses 15 % at 6; the 7 x 7 / 8 x 8 variants keep the value they were measured with.
-TILE_FIXED_COST = {6: (8.0, 18.0), 7: (18.0, 18.0), 8: (18.0, 18.0)}
+# not care between 18 and 200 and loses 15 % at 6.  8 x 8 blocks (one configs[3] shard / configs[3] whole, profiles/
+# r05_ab_tile_knobs_c4.jsonl): 8 instead of 18 -3.3 % / -1.2 % on the off-diagonal launch, with the sparsest-first order -6 % / -2.8 %.
+TILE_FIXED_COST = {6: (8.0, 18.0), 7: (8.0, 18.0), 8: (8.0, 18.0)}
 TILE_TOP_UP = os.environ.get("VGGSFM_TILE_TOP_UP", "1") != "0"   # hand the slots the chunk-size search leaves empty to the most loaded tiles
-TILE_ORDER = "sparse_first"        # launch order of the tiles (6 x 6 blocks): "" = (gI, gJ); "dense_first" / "sparse_first" (build_schur_tiles)
+TILE_ORDER = "sparse_first"        # launch order of the tiles: "" = (gI, gJ); "dense_first" / "sparse_first" (build_schur_tiles)
 TILE_POSITION_WEIGHT = 0.0        # see build_schur_tiles: extra cost of a tile per unit of launch position (0 = off: with every slot filled
 #                                   the sweep 0 .. 0.45 stayed inside the run-to-run noise, profiles/r05_ab_tile_fixed_cost_c3.jsonl)
 
@@ -290,14 +291,13 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     # tile key: batch-major; inside a batch the off-diagonal tiles first, then the diagonal ones (separate launches)
     nn = ngroups * ngroups
     tile_pos = gA * ngroups + gB
-    order_mode = os.environ.get("VGGSFM_TILE_ORDER", TILE_ORDER if block_rows == 6 else "")
+    order_mode = os.environ.get("VGGSFM_TILE_ORDER", TILE_ORDER)
     if order_mode in ("dense_first", "sparse_first", "stride") and nb == 1:
         # LAUNCH ORDER of the tiles by density (round 5 experiment): the workgroups of a launch are resident three (four) to a
         # CU -- positions p, p + CUs, p + 2 CUs -- and the oldest is served first; in (gI, gJ) order neighbouring positions
         # hold tiles of like density.  Ordered by the mean number of 16-row block products of their entries (own patterns),
         # every CU gets a mix.  Same-box A/B at configs[2] (profiles/r05_ab_tile_order_c3.jsonl): densest first 0.564 / 0.247 ms
-        # (off-diagonal / diagonal launch), (gI, gJ) order 0.542 / 0.252, SPARSEST FIRST 0.536 / 0.243 -- the default for 6 x 6
-        # blocks; the sums of a tile do not depend on where it is launched (final costs equal to the last bit).
+        # (off-diagonal / diagonal launch), (gI, gJ) order 0.542 / 0.252, SPARSEST FIRST 0.536 / 0.243 -- the default; the sums of a tile do not depend on where it is launched (final costs equal to the last bit).
         nt_ = block_rows * group // 16
         bits_ = torch.tensor([(((2 << min(group - 1, (16 * b + 15) // block_rows)) - 1) & ~((1 << ((16 * b) // block_rows)) - 1))
                               for b in range(nt_)], dtype=torch.long, device=dev)

@@ -290,41 +290,56 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     batch_of_group = torch.cummax(batch_of_group, 0).values
     # tile key: batch-major; inside a batch the off-diagonal tiles first, then the diagonal ones (separate launches)
     nn = ngroups * ngroups
-    tile_pos = gA * ngroups + gB
-    order_mode = os.environ.get("VGGSFM_TILE_ORDER", TILE_ORDER)
-    if order_mode in ("dense_first", "sparse_first", "stride") and nb == 1:
-        # LAUNCH ORDER of the tiles by density (round 5 experiment): the workgroups of a launch are resident three (four) to a
-        # CU -- positions p, p + CUs, p + 2 CUs -- and the oldest is served first; in (gI, gJ) order neighbouring positions
-        # hold tiles of like density.  Ordered by the mean number of 16-row block products of their entries (own patterns),
-        # every CU gets a mix.  Same-box A/B at configs[2] (profiles/r05_ab_tile_order_c3.jsonl): densest first 0.564 / 0.247 ms
-        # (off-diagonal / diagonal launch), (gI, gJ) order 0.542 / 0.252, SPARSEST FIRST 0.536 / 0.243 -- the default; the sums of a tile do not depend on where it is launched (final costs equal to the last bit).
-        nt_ = block_rows * group // 16
-        bits_ = torch.tensor([(((2 << min(group - 1, (16 * b + 15) // block_rows)) - 1) & ~((1 << ((16 * b) // block_rows)) - 1))
-                              for b in range(nt_)], dtype=torch.long, device=dev)
-        nblk = lambda m: ((m[:, None] & bits_[None]) != 0).sum(1)
-        prod = (nblk(seg_mask[A]) * nblk(seg_mask[B])).double()
-        tsum = torch.zeros(nn, dtype=torch.float64, device=dev).index_add_(0, tile_pos, prod)
-        tcnt = torch.zeros(nn, dtype=torch.float64, device=dev).index_add_(0, tile_pos, torch.ones_like(prod))
-        dens = tsum / tcnt.clamp(min=1.0)
-        rank = torch.empty(nn, dtype=torch.long, device=dev)
-        rank[torch.argsort(dens, descending=(order_mode == "dense_first"), stable=True)] = torch.arange(nn, device=dev)
-        if order_mode == "stride":                                       # (experiment: densities scattered over the launch)
-            empty = int((tcnt == 0).sum().item())                        # tiles without entries rank first (density 0)
-            live = nn - empty
-            r2 = rank - empty
-            step = next(k for k in range(max(2, int(live ** 0.5)), live + 2) if math.gcd(k, max(live, 1)) == 1)
-            rank = torch.where(r2 >= 0, empty + (r2 * step) % max(live, 1), rank)
-        tile_pos = rank[tile_pos]
-        tile_unrank = torch.argsort(rank)                              # position in the order -> gI * ngroups + gJ
-    else:
-        tile_unrank = None
-    key = batch_of_group[gA] * (2 * nn) + (gA == gB).long() * nn + tile_pos
+    key = batch_of_group[gA] * (2 * nn) + (gA == gB).long() * nn + gA * ngroups + gB
     epos = prank[seg_pt[A]]
     order = torch.argsort(key * P + epos)
     A, B, key, epos = A[order], B[order], key[order], epos[order]
     emask = seg_mask[A] | (seg_mask[B] << 16)
     ukeys, kcounts = torch.unique_consecutive(key, return_counts=True)              # chunking unit = tile
     tile_start = torch.cumsum(kcounts, 0) - kcounts
+    order_mode = os.environ.get("VGGSFM_TILE_ORDER", TILE_ORDER)
+    if order_mode in ("dense_first", "sparse_first", "stride") and nb == 1 and ukeys.shape[0] > 2:
+        # LAUNCH ORDER of the tiles by density (round 5): the workgroups of a launch are resident three (four) to a CU --
+        # positions p, p + CUs, p + 2 CUs -- and the oldest is served first; in (gI, gJ) order neighbouring positions hold
+        # tiles of like density.  Ordered by the mean number of 16-row block products of their entries (own patterns), the
+        # launch walks from the sparsest tiles to the densest and every CU gets a mix.  Same-box A/B at configs[2]
+        # (profiles/r05_ab_tile_order_c3.jsonl): densest first 0.564 / 0.247 ms (off-diagonal / diagonal launch), (gI, gJ)
+        # order 0.542 / 0.252, SPARSEST FIRST 0.536 / 0.243 -- the default; densities scattered over the launch 0.570 /
+        # 0.244.  The sums of a tile do not depend on where it is launched (final costs equal to the last bit).
+        # (per-tile sums of a list sorted by tile = differences of a running sum; the runs are then moved as blocks -- no
+        #  second sort and no atomics: an index_add_ of 6 M doubles into ~100 bins takes seconds)
+        nt_ = block_rows * group // 16
+        bits_ = torch.tensor([(((2 << min(group - 1, (16 * b + 15) // block_rows)) - 1) & ~((1 << ((16 * b) // block_rows)) - 1))
+                              for b in range(nt_)], dtype=torch.long, device=dev)
+        nblk = lambda m: ((m[:, None] & bits_[None]) != 0).sum(1)
+        csum_d = torch.cumsum((nblk(seg_mask[A]) * nblk(seg_mask[B])).double(), 0)
+        tend_d = tile_start + kcounts - 1
+        dsum = csum_d[tend_d] - torch.where(tile_start > 0, csum_d[(tile_start - 1).clamp(min=0)], torch.zeros_like(csum_d[tend_d]))
+        dens = dsum / kcounts.double()
+        cls = ukeys // nn                                              # (batch, diagonal flag): the launches keep their order
+        span = float(dens.max().item()) + 1.0
+        skey = cls.double() * (2.0 * span) + (span - dens if order_mode == "dense_first" else dens)
+        perm_units = torch.argsort(skey, stable=True)
+        if order_mode == "stride":                                       # (experiment: densities scattered over a launch)
+            ncls = torch.bincount(cls)
+            cstart = torch.cumsum(ncls, 0) - ncls
+            r = torch.arange(perm_units.shape[0], device=dev) - cstart[cls[perm_units]]
+            nc = ncls[cls[perm_units]]
+            step = torch.clamp((nc.double().sqrt().long() | 1), min=1)
+            while bool((torch.gcd(step, nc) != 1).any()):
+                step = torch.where(torch.gcd(step, nc) != 1, step + 2, step)
+            newr = (r * step) % nc
+            perm_units = perm_units[torch.argsort(cstart[cls[perm_units]] + newr, stable=True)]
+        new_start = torch.empty_like(tile_start)
+        kc_p = kcounts[perm_units]
+        new_start[perm_units] = torch.cumsum(kc_p, 0) - kc_p
+        unit0 = torch.repeat_interleave(torch.arange(kcounts.shape[0], device=dev), kcounts)
+        dest = new_start[unit0] + (torch.arange(total, device=dev) - tile_start[unit0])
+        inv = torch.empty_like(dest)
+        inv[dest] = torch.arange(total, device=dev)
+        A, B, key, epos, emask = A[inv], B[inv], key[inv], epos[inv], emask[inv]
+        ukeys, kcounts = ukeys[perm_units], kc_p
+        tile_start = torch.cumsum(kcounts, 0) - kcounts
     if QUAD_SORT_WINDOW > 0:
         # Inside windows of QUAD_SORT_WINDOW consecutive entries of a tile, entries with the same pattern of 16-row blocks
         # (what the tile kernel can skip) are put next to each other: a quad's union is then the pattern of each of its four
@@ -354,8 +369,6 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     tbatch = ukeys // (2 * nn)
     is_diag = (ukeys % (2 * nn)) >= nn
     ukeys = ukeys % nn
-    if tile_unrank is not None:
-        ukeys = tile_unrank[ukeys]                                     # back to gI * ngroups + gJ
     # cost-weighted entry count of every tile (relative to the mean entry of its launch kind)
     ecost = _entry_cost(qm[quad], is_diag[unit_of_entry], block_rows, group)
     # (per-tile sums of a list that is sorted by tile: differences of a running sum -- index_add_ with 5 M double atomics

@@ -298,7 +298,7 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     ukeys, kcounts = torch.unique_consecutive(key, return_counts=True)              # chunking unit = tile
     tile_start = torch.cumsum(kcounts, 0) - kcounts
     order_mode = os.environ.get("VGGSFM_TILE_ORDER", TILE_ORDER)
-    if order_mode in ("dense_first", "sparse_first", "stride") and nb == 1 and ukeys.shape[0] > 2:
+    if order_mode in ("dense_first", "sparse_first", "stride", "sdm", "msd", "dsm") and nb == 1 and ukeys.shape[0] > 2:
         # LAUNCH ORDER of the tiles by density (round 5): the workgroups of a launch are resident three (four) to a CU --
         # positions p, p + CUs, p + 2 CUs -- and the oldest is served first; in (gI, gJ) order neighbouring positions hold
         # tiles of like density.  Ordered by the mean number of 16-row block products of their entries (own patterns), the
@@ -330,6 +330,15 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
                 step = torch.where(torch.gcd(step, nc) != 1, step + 2, step)
             newr = (r * step) % nc
             perm_units = perm_units[torch.argsort(cstart[cls[perm_units]] + newr, stable=True)]
+        if order_mode in ("sdm", "msd", "dsm"):                          # (experiment: the density thirds of a launch in another order)
+            ncls = torch.bincount(cls)
+            cstart = torch.cumsum(ncls, 0) - ncls
+            cp = cls[perm_units]
+            r = torch.arange(perm_units.shape[0], device=dev) - cstart[cp]
+            third = torch.clamp((3 * r) // ncls[cp].clamp(min=1), max=2)       # 0 sparse, 1 mid, 2 dense
+            slot = {"sdm": (0, 2, 1), "msd": (1, 0, 2), "dsm": (2, 0, 1)}[order_mode]
+            where = torch.tensor([slot.index(t) for t in range(3)], device=dev)[third]
+            perm_units = perm_units[torch.argsort(cp * 4 + where, stable=True)]
         new_start = torch.empty_like(tile_start)
         kc_p = kcounts[perm_units]
         new_start[perm_units] = torch.cumsum(kc_p, 0) - kc_p

@@ -203,6 +203,38 @@ def test_compile_problem_matches_oracle_construction(S, N, density_cut, monkeypa
     _check_views_and_work_list(prob, S, vi, row_ptr, obs_cam)
 
 
+@pytest.mark.parametrize("order", ["", "sparse_first", "dense_first", "stride", "sdm"])
+@pytest.mark.parametrize("top_up", [False, True])
+def test_tile_scheduling_choices_keep_the_work_list_invariants(order, top_up, monkeypatch):
+    """Round-5 scheduling of the Schur tile work list (ba.build_schur_tiles): the launch order of the tiles (by density), the
+    top-up of the slots the chunk-size search leaves empty and the per-launch fixed cost only decide WHERE and by how many
+    workgroups a tile is processed -- every order covers every co-observing camera pair of every point exactly once, with
+    the same entries per tile, and a launch never gets more workgroups than resident slots."""
+    monkeypatch.setattr(BA, "TILE_ORDER", order)
+    monkeypatch.setattr(BA, "TILE_TOP_UP", top_up)
+    S, N = 70, 400
+    sc = make_scene(S, N, "SIMPLE_RADIAL", shared_camera=True, seed=7)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=7)
+    prob, valid_idx, _ = BA.compile_problem(T(pts0), T(ext0), T(K0), T(sc.tracks), T(sc.mask), T(extra0), True, "SIMPLE_RADIAL")
+    vi, row_ptr, obs_cam, _, _ = OB.build_observations(pts0, ext0, sc.tracks, sc.mask)
+    _check_views_and_work_list(prob, S, vi, row_ptr, obs_cam)
+    desc, ent, tiles = prob.chunk_desc.numpy(), prob.entries.numpy(), prob.tile_desc.numpy()
+    # the tiles partition the chunks in launch order, off-diagonal tiles in front of the diagonal ones
+    assert tiles[0, 2] == 0 and (tiles[1:, 2] == tiles[:-1, 3]).all() and tiles[-1, 3] == len(desc)
+    is_diag = tiles[:, 0] == tiles[:, 1]
+    assert not (is_diag[:-1] & ~is_diag[1:]).any()
+    # same entries per tile as the (gI, gJ) order
+    monkeypatch.setattr(BA, "TILE_ORDER", "")
+    monkeypatch.setattr(BA, "TILE_TOP_UP", False)
+    ref, _, _ = BA.compile_problem(T(pts0), T(ext0), T(K0), T(sc.tracks), T(sc.mask), T(extra0), True, "SIMPLE_RADIAL")
+    per_tile = lambda pr: {(int(a), int(b)): sorted(map(tuple, pr.entries.numpy()[tb:te, :3].tolist()))
+                           for a, b, tb, te in {(r[0], r[1], r[2], r[3]) for r in pr.chunk_desc.numpy().tolist()}}
+    assert per_tile(prob) == per_tile(ref)
+    cus = 256
+    off = int((desc[:, 0] != desc[:, 1]).sum())
+    assert len(desc) <= cus * BA.TILE_WGS_PER_CU[0] or (off <= cus * BA.TILE_WGS_PER_CU[0] and len(desc) - off <= cus * BA.TILE_WGS_PER_CU[1])
+
+
 @pytest.mark.parametrize("density_cut", [0.0, 2.0])
 @pytest.mark.parametrize("S,N,density,seed", [(2, 30, 1.0, 0), (3, 50, 0.7, 1), (16, 80, 0.3, 2), (17, 120, 0.15, 3), (33, 200, 0.08, 4),
                                               (48, 60, 0.9, 5), (40, 150, 0.05, 6)])

@@ -1114,6 +1114,9 @@ __device__ long long g_tile_trace[2048 * 4 * 8];   // [workgroup][wave][batches,
 #ifndef VGG_DIAG_PARITY
 #define VGG_DIAG_PARITY 1           // diagonal tiles: sub-tiles dealt to the wavefronts by parity class (0: every fourth, round 3)
 #endif
+#ifndef VGG_TILE_EARLY_WRITE
+#define VGG_TILE_EARLY_WRITE 1      // pipelined off-diagonal step: the LDS writes of batch b + 1 in front of batch b's matrix instructions (0: behind them)
+#endif
 #ifndef VGG_TILE_PIPE
 #define VGG_TILE_PIPE 1             // compressed off-diagonal tiles: the last K step of a batch behind its barrier (round 5; 0: plain order)
 #endif
@@ -1452,6 +1455,12 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
         issue_loads(sv_load, seg_next, valid_next);
         seg_next = seg_after;
         valid_next = seg_valid(ebase(b + DEPTH + 1));
+#if VGG_TILE_EARLY_WRITE
+        // the LDS image of batch b + 1 is written FIRST: buffer buf^1 is free since barrier(b - 1) -- its last readers fetched
+        // K step 2 of batch b - 1 in front of that barrier -- so the writes have landed long before this step's barrier and
+        // its lgkmcnt(0) costs nothing (same-box A/B profiles/r05_ab_tile_pipe_c3.jsonl: 0.531 -> 0.521 ms)
+        write_lds(sv_write, buf ^ 1);
+#endif
         __builtin_amdgcn_s_setprio(0);
         on = skip_bits(qmask);
         fetch(1 - P, buf, 1); pin(P);
@@ -1462,7 +1471,9 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
         __builtin_amdgcn_s_setprio(3);
         qmask = qmask_next;
         qmask_next = load_quad_mask(ebase(b + 2));
+#if !VGG_TILE_EARLY_WRITE
         write_lds(sv_write, buf ^ 1);
+#endif
         __syncthreads();
         fetch(1 - P, buf ^ 1, 0);                     // K step 0 of batch b + 1 (stale bytes behind the last batch: never used)
         __builtin_amdgcn_s_setprio(0);

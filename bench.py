@@ -351,14 +351,16 @@ def main():
             ext0_c, K0_c, extra0_c, _ = perturb_for_ba(sc_cameras_only(sc), seed=0)
             prob, _, _ = BA.compile_problem(sc.points3D_init, D(ext0_c, dev), D(K0_c, dev), sc.tracks, sc.mask, D(extra0_c, dev),
                                             shared, cam_type, overlap=(world == 1 and args.overlap),
-                                            camera_split=not args.no_camera_split, adjacency_reduce=reduce_adj)
+                                            camera_split=not args.no_camera_split, adjacency_reduce=reduce_adj,
+                                            sort_points=BA.SORT_POINTS)   # (what the public entry, ba.bundle_adjustment, does)
             return prob, None, (sc, D(ext0_c, dev), D(K0_c, dev), D(extra0_c, dev))
         sc = make_scene(S, N, cam_type, shared_camera=shared, seed=0, track_seed=1000 + rank, full_visibility=(workload == "c3dense"))
         _, _, _, pts0 = perturb_for_ba(sc, seed=rank)
         ext0_c, K0_c, extra0_c, _ = perturb_for_ba(sc, seed=0)          # cameras identical on every rank
         prob, _, _ = BA.compile_problem(D(pts0, dev), D(ext0_c, dev), D(K0_c, dev), D(sc.tracks, dev), D(sc.mask, dev),
                                         D(extra0_c, dev), shared, cam_type, overlap=(world == 1 and args.overlap),
-                                        camera_split=not args.no_camera_split, adjacency_reduce=reduce_adj)
+                                        camera_split=not args.no_camera_split, adjacency_reduce=reduce_adj,
+                                            sort_points=BA.SORT_POINTS)   # (what the public entry, ba.bundle_adjustment, does)
         return prob, sc, (pts0, ext0_c, K0_c, extra0_c)
 
     def timed(prob, steps, warmup, profile, solo=False):

@@ -496,6 +496,7 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
             batch_desc.contiguous())
 
 
+SORT_POINTS = os.environ.get("VGGSFM_SORT_POINTS", "1") != "0"   # bundle_adjustment: number the problem's points by track length (compile_problem)
 TILE_BACKFILL = None               # (off-diagonal, diagonal) workgroups per CU of the single back-filled tile launch; None = two launches
 TILE_WGS_PER_CU = (3, 4)           # resident schur_tile workgroups per CU with 6 x 6 blocks: (off-diagonal, diagonal) launch
 SPARSE_GRID_DENSITY = 0.05        # compile_problem: below this fill of the (frames x tracks) grid work on the observation list
@@ -629,7 +630,7 @@ def envelope_blocks(first_group, num_cams, n_reduced, group=GROUP, block=64):
 def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_params=None, shared_camera=False,
                     camera_type="SIMPLE_PINHOLE", max_points3D_val=3000, filter_negative_depth=True,
                     gauge="colmap", overlap=None, camera_split=False, adjacency_reduce=None, refine_focal_length=True,
-                    refine_extra_params=True):
+                    refine_extra_params=True, sort_points=False):
     """tensors (reference layout, on the GPU) -> DeviceProblem + bookkeeping.
     Returns (problem, valid_idx (P',) long, deleted (P',) bool).
     overlap: cut the Schur tiles into TILE_BATCHES batches so that a single-GPU solve can factorise beside the later
@@ -639,7 +640,12 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
     are in THAT order).  With several ranks pass `adjacency_reduce` so that every rank orders alike.
     refine_focal_length / refine_extra_params: what the solve will refine (``BundleAdjustmentOptions``) -- they decide the
     rows per camera of the Schur tile blocks (6, or 6 + refined intrinsics when those are per camera), hence the tile
-    kernel variant, its occupancy and the balance of the work list (the video window BA refines neither)."""
+    kernel variant, its occupancy and the balance of the work list (the video window BA refines neither).
+    sort_points (round 5): the problem's points are numbered by TRACK LENGTH (ascending, ties in track order) instead of in
+    track order -- `valid_idx` is then not monotonic.  The point passes give 16 (32) lanes to a point and 4 (2) points to a
+    wavefront, which walks the longest of its tracks: with neighbours of equal length no lane waits for another point's
+    observations.  Nothing else depends on the numbering (the tile work list is ordered by sweep position, the camera-major
+    list by camera)."""
     if camera_type not in MODEL_ID:
         raise ValueError(f"Camera type {camera_type} is not supported yet")
     dev = tracks.device
@@ -673,7 +679,12 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
         length0 = torch.bincount(n0, minlength=N)
         valid = length0 >= 2
         valid_idx = torch.nonzero(valid).squeeze(1)
-        newid = torch.cumsum(valid.long(), 0) - 1
+        if sort_points:
+            valid_idx = valid_idx[torch.argsort(length0[valid_idx], stable=True)]
+            newid = torch.full((N,), -1, dtype=torch.long, device=dev)
+            newid[valid_idx] = torch.arange(valid_idx.shape[0], device=dev)
+        else:
+            newid = torch.cumsum(valid.long(), 0) - 1
         pts = points3d.to(torch.float64)[valid_idx].contiguous()
         P = pts.shape[0]
         ok = valid[n0]
@@ -710,6 +721,8 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
                 extra_params = extra_params[cam_perm]
         length0 = masks.sum(0)
         valid_idx = torch.nonzero(length0 >= 2).squeeze(1)
+        if sort_points:
+            valid_idx = valid_idx[torch.argsort(length0[valid_idx], stable=True)]
         pts = points3d.to(torch.float64)[valid_idx].contiguous()
         m = masks[:, valid_idx].clone()
         m[:, ~(pts < max_points3D_val).all(-1)] = False
@@ -906,7 +919,7 @@ def bundle_adjustment(points3d, extrinsics, intrinsics, tracks, masks, image_siz
                                                shared_camera, camera_type, filter_negative_depth=filter_negative_depth,
                                                gauge="colmap" if constant_pose_frames is None else "config",
                                                camera_split=True, refine_focal_length=options.refine_focal_length,
-                                               refine_extra_params=options.refine_extra_params)
+                                               refine_extra_params=options.refine_extra_params, sort_points=SORT_POINTS)
     S = extrinsics.shape[0]
     inv_perm = None
     if prob.cam_perm is not None:
@@ -923,6 +936,9 @@ def bundle_adjustment(points3d, extrinsics, intrinsics, tracks, masks, image_siz
         ext = ext[inv_perm]                           # back to the order of the input frames
     pts = prob.pts
     pts[deleted] = 0.0
+    if SORT_POINTS:                                   # back to track order (the contract: rows of the valid tracks, ascending)
+        back = torch.argsort(valid_idx)
+        pts, deleted, valid_idx = pts[back], deleted[back], valid_idx[back]
     if normalize:
         ext, pts = normalize_reconstruction(ext, pts, ~deleted)
     idx = torch.zeros(S, dtype=torch.long, device=pts.device) if shared_camera else \

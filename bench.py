@@ -745,18 +745,20 @@ def main():
         out = {
             "metric": "BA LM-iterations/sec",
             "value": args.steps / dt if strong_main else args.steps * world / dt,
-            "unit": "LM-iterations/s",
-            "value_definition": ("true LM iterations per second of ONE fixed problem, the whole 400 x 300000 configs[3] (its tracks "
-                                 "split over the ranks); n1_same_problem is the same problem on one GPU of this box"
+            # (ADVICE r5 / VERDICT r5 weak 6: at N > 1 `value` counts every rank's shard -- say so in the unit and put the
+            #  strong-scaling figure of the fixed configs[3] problem right beside it, in front of everything else)
+            "unit": "LM-iterations/s" if (strong_main or world == 1) else "shard-iterations/s (weak: N x K / t)",
+            "scaling": "strong" if strong_main else "weak",
+            "value_definition": ("strong: LM iterations/s of ONE fixed problem (configs[3] 400 x 300000, tracks split over the ranks)"
                                  if strong_main else
-                                 "whole-job aggregate, weak scaling: K LM iterations of the 200-frame x (N x 100000)-track problem "
-                                 "counted once per 100000-track shard = N x K / t ('shard-iterations per second'); at N = 1 it is "
-                                 "the LM-iterations/s of BASELINE configs[2]"),
+                                 "weak: shard-iterations/s = N x K / t, K iterations of the 200-frame x (N x 100000)-track problem "
+                                 "counted once per 100000-track shard; at N = 1 = LM-iterations/s of BASELINE configs[2]"),
+            "strong_scaling_c4_speedup_vs_n1": (None if not strong else strong.get("speedup_vs_n1")),
             "lm_iterations_per_s_global": args.steps / dt,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
             "ms_per_step_with_events": 1e3 * dt_events / args.steps,
-            "higher_is_better": True, "scaling": "strong" if strong_main else "weak", "vs_baseline": None,
+            "higher_is_better": True, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": (f"synthetic {S} frames x {N} tracks split over {world} rank(s), {cam_type} per-frame intrinsics, "
                                     "full LM (BASELINE configs[3])" if strong_main else

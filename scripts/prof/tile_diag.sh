@@ -49,5 +49,5 @@ run no_staging_arith "-DVGG_ABLATE=4"
 run no_lds_writes "-DVGG_ABLATE=5"
 run no_lds_operand_reads "-DVGG_ABLATE=6"
 run no_skip "-DVGG_NO_SKIP=1"
-VGGSFM_TILE_WGS=4,4 run offdiag_occ4 "-DVGG_OFFDIAG_OCC=4"
+VGGSFM_AMD_DEBUG_HOOKS=1 VGGSFM_TILE_WGS=4,4 run offdiag_occ4 "-DVGG_OFFDIAG_OCC=4"
 cp /tmp/lib_product.so ../libvggsfm_amd.so

@@ -44,7 +44,7 @@ def test_bench_two_ranks_command_line_over_gloo():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                         # ONE JSON line, printed by rank 0 only
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["unit"] == "LM-iterations/s"
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["unit"].startswith("shard-iterations/s")
     assert out["scaling"] == "weak" and out["higher_is_better"] is True and out["dtype"] == "f64"
     # whole-job aggregate: N x K / t shard-iterations per second
     assert out["value"] > 0 and abs(out["value"] - 2 * 1e3 / out["ms_per_step"]) <= 1e-6 * out["value"]
@@ -57,6 +57,10 @@ def test_bench_two_ranks_command_line_over_gloo():
     n1 = strong["n1_same_problem"]
     assert n1["observations"] > 2 * strong["observations_rank0"] * 0.9 and n1["lm_iterations_per_s"] > 0
     assert strong["speedup_vs_n1"] == pytest.approx(strong["lm_iterations_per_s"] / n1["lm_iterations_per_s"])
+    # the two scaling figures side by side at the head of the line, where a reader of SCALE_rNN.json cannot miss either
+    head = lines[0][:700]
+    assert '"value_definition": "weak: shard-iterations/s' in head and '"strong_scaling_c4_speedup_vs_n1"' in head
+    assert out["strong_scaling_c4_speedup_vs_n1"] == strong["speedup_vs_n1"]
     assert out["roofline"]["bound"] in ("mfma", "hbm") and 0 < out["roofline"]["frac"] < 1
     assert out["cpu_baseline"] is None                                # rank 0 at N = 1 only
     assert out["pose_delta_vs_port_c4"] is None and out["pose_delta_vs_port_c5_joint"] is None

@@ -123,3 +123,26 @@ def test_nonfinite_ray_in_invisible_view(bad):
     num, msk = dirty[1].cpu().numpy(), dirty[2].cpu().numpy()
     assert not (msk[hit] & (vis[:, hit].T <= 0.05)).any()           # never an inlier in an invisible view
     assert (num[hit] == msk[hit].sum(1)).all() and (num[hit] <= clean[1].cpu().numpy()[hit] + 1).all()
+
+
+@pytest.mark.parametrize("chunk_range", [None, (1, 2), (0, 0)])
+def test_nonfinite_error_leaves_the_rng_where_the_reference_would(chunk_range):
+    """ADVICE r5.  The reference fails inside its FIRST chunk -- after that chunk's randperm draw, before any other
+    (triangulation.py:812, triangulation_helpers.py:87).  The host entry here draws for every chunk before it reads the
+    finiteness flag; on the error path it must hand the global CPU RNG back as the reference leaves it: entry state + one
+    draw.  Covers the multi-chunk path, a shard's `chunk_range`, and the empty-range path (n_loc == 0)."""
+    S, N = 12, 96
+    sc = make_scene(S, N, "SIMPLE_PINHOLE", seed=5, outlier_frac=0.0)
+    tn = G.cam_from_img(sc.tracks.astype(np.float64), sc.intrinsics)
+    tn[3, 17, 0] = float("nan")
+    npairs = S * (S - 1) // 2
+    torch.manual_seed(1234)
+    entry = torch.get_rng_state()
+    torch.randperm(npairs)
+    expected = torch.get_rng_state()
+    torch.set_rng_state(entry)
+    with pytest.raises(torch.linalg.LinAlgError):
+        # 4 reference chunks: S N = 1152 > 300
+        T.triangulate_tracks(D(sc.extrinsics), D(tn), max_ransac_iters=32, track_vis=D(sc.vis), track_score=D(sc.score),
+                             max_tri_points_num=300, chunk_range=chunk_range)
+    assert torch.equal(torch.get_rng_state(), expected)

@@ -203,7 +203,50 @@ def test_compile_problem_matches_oracle_construction(S, N, density_cut, monkeypa
     _check_views_and_work_list(prob, S, vi, row_ptr, obs_cam)
 
 
-@pytest.mark.parametrize("order", ["", "sparse_first", "dense_first", "stride", "sdm"])
+@pytest.mark.parametrize("density_cut", [0.0, 2.0])
+@pytest.mark.parametrize("S,N", [(5, 40), (40, 300), (70, 150)])
+def test_compile_problem_sorted_points_is_the_same_problem_renumbered(S, N, density_cut, monkeypatch):
+    """`sort_points=True` (what ba.bundle_adjustment compiles with) numbers the points by track length.  Both
+    constructions (grid / observation list) must give the SAME problem up to that renumbering: same valid tracks, same deleted
+    flags per track, and per point the same (camera, pixel) list in camera order; per camera the same SET of (point, pixel)
+    -- the order inside a camera is the list's, not ascending by point, and nothing needs it to be."""
+    monkeypatch.setattr(BA, "SPARSE_GRID_DENSITY", density_cut)
+    sc = make_scene(S, N, "SIMPLE_RADIAL", shared_camera=True, seed=S)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=S)
+    masks = sc.mask.copy()
+    masks[:, 3] = False
+    masks[0, 3] = True
+    pts0[5] = [0, 0, -2.0]
+    pts0[6, 0] = 4000.0
+    args = (T(pts0), T(ext0), T(K0), T(sc.tracks), T(masks), T(extra0), True, "SIMPLE_RADIAL")
+    pa, va, da = BA.compile_problem(*args)
+    pb, vb, db = BA.compile_problem(*args, sort_points=True)
+    va, vb = va.numpy(), vb.numpy()
+    assert np.array_equal(np.sort(vb), va)
+    lengths = np.diff(pb.row_ptr.numpy())
+    raw = masks[:, vb].sum(0)
+    assert (np.diff(raw) >= 0).all()                       # numbered by (input) track length, ascending
+    back = np.argsort(vb)                                  # sorted id of track-order point i
+    assert np.array_equal(db.numpy()[back], da.numpy())
+    assert np.array_equal(pb.pts.numpy()[back], pa.pts.numpy())
+    ra, rb = pa.row_ptr.numpy(), pb.row_ptr.numpy()
+    for i in range(len(va)):
+        j = back[i]
+        assert np.array_equal(pa.obs_cam.numpy()[ra[i]:ra[i + 1]], pb.obs_cam.numpy()[rb[j]:rb[j + 1]])
+        assert np.array_equal(pa.obs_uv.numpy()[ra[i]:ra[i + 1]], pb.obs_uv.numpy()[rb[j]:rb[j + 1]])
+    assert lengths.sum() == np.diff(ra).sum()
+    ca, cb = pa.col_ptr.numpy(), pb.col_ptr.numpy()
+    assert np.array_equal(ca, cb)
+    for c in range(S):
+        A = sorted((int(p), tuple(uv)) for p, uv in zip(pa.cobs_pt.numpy()[ca[c]:ca[c + 1]], pa.cobs_uv.numpy()[ca[c]:ca[c + 1]]))
+        Bq = sorted((int(np.nonzero(back == p)[0][0]), tuple(uv))
+                    for p, uv in zip(pb.cobs_pt.numpy()[cb[c]:cb[c + 1]], pb.cobs_uv.numpy()[cb[c]:cb[c + 1]]))
+        assert A == Bq
+    vi, row_ptr, obs_cam, _, _ = OB.build_observations(pts0, ext0, sc.tracks, masks)
+    assert np.array_equal(va, vi)
+
+
+@pytest.mark.parametrize("order", ["plain", "sparse_first", "dense_first", "stride", "sdm"])
 @pytest.mark.parametrize("top_up", [False, True])
 def test_tile_scheduling_choices_keep_the_work_list_invariants(order, top_up, monkeypatch):
     """Round-5 scheduling of the Schur tile work list (ba.build_schur_tiles): the launch order of the tiles (by density), the
@@ -212,6 +255,9 @@ def test_tile_scheduling_choices_keep_the_work_list_invariants(order, top_up, mo
     the same entries per tile, and a launch never gets more workgroups than resident slots."""
     monkeypatch.setattr(BA, "TILE_ORDER", order)
     monkeypatch.setattr(BA, "TILE_TOP_UP", top_up)
+    if order in BA.TILE_ORDERS_EXPERIMENTAL:               # (the experimental orders are reachable through the hook gate only)
+        monkeypatch.setenv("VGGSFM_AMD_DEBUG_HOOKS", "1")
+        monkeypatch.setenv("VGGSFM_TILE_ORDER", order)
     S, N = 70, 400
     sc = make_scene(S, N, "SIMPLE_RADIAL", shared_camera=True, seed=7)
     ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=7)
@@ -224,7 +270,7 @@ def test_tile_scheduling_choices_keep_the_work_list_invariants(order, top_up, mo
     is_diag = tiles[:, 0] == tiles[:, 1]
     assert not (is_diag[:-1] & ~is_diag[1:]).any()
     # same entries per tile as the (gI, gJ) order
-    monkeypatch.setattr(BA, "TILE_ORDER", "")
+    monkeypatch.setattr(BA, "TILE_ORDER", "plain")
     monkeypatch.setattr(BA, "TILE_TOP_UP", False)
     ref, _, _ = BA.compile_problem(T(pts0), T(ext0), T(K0), T(sc.tracks), T(sc.mask), T(extra0), True, "SIMPLE_RADIAL")
     per_tile = lambda pr: {(int(a), int(b)): sorted(map(tuple, pr.entries.numpy()[tb:te, :3].tolist()))
@@ -408,3 +454,21 @@ def test_find_camera_order_kway_and_envelope():
     sc = make_scene(200, 4000, "SIMPLE_RADIAL", shared_camera=True, seed=0)
     assert BA.find_camera_order(T(sc.mask))[0] is None                     # band of 40 % of the frames: two-way split instead
     assert BA.find_camera_order(m[:60])[0] is None
+
+
+def test_unknown_tile_order_is_refused(monkeypatch):
+    """an unknown launch order used to be ignored silently (and an A/B variant relied on it)."""
+    monkeypatch.setattr(BA, "TILE_ORDER", "no_such_order")
+    sc = make_scene(20, 60, "SIMPLE_RADIAL", shared_camera=True, seed=3)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=3)
+    with pytest.raises(ValueError, match="tile order"):
+        BA.compile_problem(T(pts0), T(ext0), T(K0), T(sc.tracks), T(sc.mask), T(extra0), True, "SIMPLE_RADIAL")
+
+
+def test_environment_switches_are_inert_without_the_debug_gate(monkeypatch):
+    monkeypatch.delenv("VGGSFM_AMD_DEBUG_HOOKS", raising=False)
+    monkeypatch.setenv("VGGSFM_TILE_ORDER", "no_such_order")
+    monkeypatch.setenv("VGGSFM_TILE_WGS", "0.01,0.01")
+    sc = make_scene(20, 60, "SIMPLE_RADIAL", shared_camera=True, seed=3)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=3)
+    BA.compile_problem(T(pts0), T(ext0), T(K0), T(sc.tracks), T(sc.mask), T(extra0), True, "SIMPLE_RADIAL")

@@ -171,7 +171,18 @@ class DeviceProblem:
         return P
 
 
-QUAD_SORT_WINDOW = int(os.environ.get("VGGSFM_QUAD_SORT_WINDOW", "512"))   # entries; 0 = plain sweep order inside a tile
+# Measurement hooks.  The product path reads NO environment variable unless VGGSFM_AMD_DEBUG_HOOKS=1 is set (the A/B harness
+# scripts/prof/ab_c3.py sets it): then VGGSFM_QUAD_SORT_WINDOW, VGGSFM_TILE_TOP_UP, VGGSFM_TILE_ORDER, VGGSFM_TILE_COST_MODE,
+# VGGSFM_TILE_FIXED_COST, VGGSFM_TILE_POS_WEIGHT, VGGSFM_SORT_POINTS, VGGSFM_TILE_WGS and VGGSFM_TILE_BACKFILL override the
+# constants below, all read per call (A/B runs switch them in-process).  Every one of them changes the SCHEDULE of the work,
+# never a sum: results are bit-identical across their values (tests/test_gpu_ba.py).
+def _hook(name, default=None):
+    if os.environ.get("VGGSFM_AMD_DEBUG_HOOKS") != "1":
+        return default
+    return os.environ.get(name, default)
+
+
+QUAD_SORT_WINDOW = 512      # entries; 0 = plain sweep order inside a tile
 # (off-diagonal, diagonal) launch: cost of a tile batch besides its matrix instructions, in matrix instructions of one wavefront
 # (staging, LDS write phase, barrier: ~2400 of ~5000 cycles per batch in the round-3 phase trace).  Round 5, same-box sweep on
 # configs[2] (profiles/r05_ab_tile_fixed_cost_c3.jsonl): the off-diagonal launch with 6 x 6 blocks is 2.5 % shorter with a
@@ -179,8 +190,10 @@ QUAD_SORT_WINDOW = int(os.environ.get("VGGSFM_QUAD_SORT_WINDOW", "512"))   # ent
 # not care between 18 and 200 and loses 15 % at 6.  8 x 8 blocks (one configs[3] shard / configs[3] whole, profiles/
 # r05_ab_tile_knobs_c4.jsonl): 8 instead of 18 -3.3 % / -1.2 % on the off-diagonal launch, with the sparsest-first order -6 % / -2.8 %.
 TILE_FIXED_COST = {6: (8.0, 18.0), 7: (8.0, 18.0), 8: (8.0, 18.0)}
-TILE_TOP_UP = os.environ.get("VGGSFM_TILE_TOP_UP", "1") != "0"   # hand the slots the chunk-size search leaves empty to the most loaded tiles
-TILE_ORDER = "sparse_first"        # launch order of the tiles: "" = (gI, gJ); "dense_first" / "sparse_first" (build_schur_tiles)
+TILE_TOP_UP = True           # hand the slots the chunk-size search leaves empty to the most loaded tiles
+TILE_ORDER = "sparse_first"        # launch order of the tiles: "plain" = (gI, gJ); "dense_first" / "sparse_first" (build_schur_tiles)
+TILE_ORDERS = ("plain", "dense_first", "sparse_first")
+TILE_ORDERS_EXPERIMENTAL = ("stride", "sdm", "msd", "dsm")     # round-5 A/B variants (profiles/r05_ab_tile_order_c3.jsonl), hooks only
 TILE_POSITION_WEIGHT = 0.0        # see build_schur_tiles: extra cost of a tile per unit of launch position (0 = off: with every slot filled
 #                                   the sweep 0 .. 0.45 stayed inside the run-to-run noise, profiles/r05_ab_tile_fixed_cost_c3.jsonl)
 
@@ -201,7 +214,7 @@ def _entry_cost(qmask, diag, bd, group=GROUP):
     ra = ((qmask[:, None] & 0xFFFF) & bits[None]) != 0        # (E, nt) row blocks with a camera
     rb = ((qmask[:, None] >> 16) & bits[None]) != 0
     off = torch.maximum(ra[:, 0::2].sum(1), ra[:, 1::2].sum(1)) * torch.maximum(rb[:, 0::2].sum(1), rb[:, 1::2].sum(1))
-    if os.environ.get("VGGSFM_TILE_COST_MODE") == "mean":          # measurement hook: the MEAN wavefront instead of the busiest
+    if _hook("VGGSFM_TILE_COST_MODE") == "mean":                   # measurement hook: the MEAN wavefront instead of the busiest
         off = (ra.sum(1) * rb.sum(1)).double() / 4.0
     per_wave = torch.zeros((qmask.shape[0], 4), dtype=torch.long, device=dev)
     t = 0
@@ -209,7 +222,7 @@ def _entry_cost(qmask, diag, bd, group=GROUP):
         for c in range(r + 1):
             per_wave[:, t % 4] += (ra[:, r] & ra[:, c]).long()
             t += 1
-    fx = os.environ.get("VGGSFM_TILE_FIXED_COST")                 # measurement hook "off,diag" (read per call: A/B runs switch it in-process)
+    fx = _hook("VGGSFM_TILE_FIXED_COST")                          # measurement hook "off,diag"
     f_off, f_diag = (float(x) for x in fx.split(",")) if fx else TILE_FIXED_COST[bd]
     fixed = torch.where(diag, torch.full_like(off, f_diag, dtype=torch.float64), torch.full_like(off, f_off, dtype=torch.float64))
     return fixed + 3.0 * torch.where(diag, per_wave.max(1).values, off).double()
@@ -297,8 +310,10 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     emask = seg_mask[A] | (seg_mask[B] << 16)
     ukeys, kcounts = torch.unique_consecutive(key, return_counts=True)              # chunking unit = tile
     tile_start = torch.cumsum(kcounts, 0) - kcounts
-    order_mode = os.environ.get("VGGSFM_TILE_ORDER", TILE_ORDER)
-    if order_mode in ("dense_first", "sparse_first", "stride", "sdm", "msd", "dsm") and nb == 1 and ukeys.shape[0] > 2:
+    order_mode = _hook("VGGSFM_TILE_ORDER", TILE_ORDER)
+    if order_mode not in TILE_ORDERS + TILE_ORDERS_EXPERIMENTAL:
+        raise ValueError(f"tile order {order_mode!r}: expected one of {TILE_ORDERS + TILE_ORDERS_EXPERIMENTAL}")
+    if order_mode != "plain" and nb == 1 and ukeys.shape[0] > 2:
         # LAUNCH ORDER of the tiles by density (round 5): the workgroups of a launch are resident three (four) to a CU --
         # positions p, p + CUs, p + 2 CUs -- and the oldest is served first; in (gI, gJ) order neighbouring positions hold
         # tiles of like density.  Ordered by the mean number of 16-row block products of their entries (own patterns), the
@@ -349,7 +364,9 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
         A, B, key, epos, emask = A[inv], B[inv], key[inv], epos[inv], emask[inv]
         ukeys, kcounts = ukeys[perm_units], kc_p
         tile_start = torch.cumsum(kcounts, 0) - kcounts
-    if QUAD_SORT_WINDOW > 0:
+    quad_window = int(_hook("VGGSFM_QUAD_SORT_WINDOW", QUAD_SORT_WINDOW))
+    top_up = _hook("VGGSFM_TILE_TOP_UP", "1" if TILE_TOP_UP else "0") != "0"
+    if quad_window > 0:
         # Inside windows of QUAD_SORT_WINDOW consecutive entries of a tile, entries with the same pattern of 16-row blocks
         # (what the tile kernel can skip) are put next to each other: a quad's union is then the pattern of each of its four
         # entries.  Points with the same first camera end in different 16-row blocks of the last group and vice versa, so in
@@ -361,7 +378,7 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
         pkey = pat(seg_mask[A]) * (1 << nt) + pat(seg_mask[B])
         unit0 = torch.repeat_interleave(torch.arange(kcounts.shape[0], device=dev), kcounts)
         upos0 = torch.arange(total, device=dev) - tile_start[unit0]
-        wkey = (unit0 * (int(kcounts.max().item()) // QUAD_SORT_WINDOW + 1) + upos0 // QUAD_SORT_WINDOW) * (1 << (2 * nt)) + pkey
+        wkey = (unit0 * (int(kcounts.max().item()) // quad_window + 1) + upos0 // quad_window) * (1 << (2 * nt)) + pkey
         order2 = torch.argsort(wkey, stable=True)
         A, B, epos, emask = A[order2], B[order2], epos[order2], emask[order2]
     # presence of a quad = union over its four entries (quads are aligned to the start of the unit, like the kernel's batches)
@@ -430,7 +447,7 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
                     # a launch empty; they go, one by one, to the tile whose workgroups carry the most
                     n_h = torch.minimum(torch.clamp(torch.ceil(kwv / (lo * SUB)), min=1).long(), nsv)
                     spare = cap - int(n_h.sum())
-                    if TILE_TOP_UP and 0 < spare <= 64:
+                    if top_up and 0 < spare <= 64:
                         for _ in range(spare):
                             load = torch.where(n_h < nsv, kwv / n_h.double(), torch.zeros_like(kwv))
                             i = int(torch.argmax(load))
@@ -450,12 +467,11 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     # phase trace at configs[2] (scripts/prof/tile_cost_fit.py): 4450 cycles per batch in the first third of the launch, 4800
     # in the second, 5180 in the third, for the same matrix instructions per batch.  So a tile's cost grows with the position
     # of its workgroups in the launch: second pass with kw (1 + TILE_POSITION_WEIGHT x position fraction within its launch).
-    pw = float(os.environ.get("VGGSFM_TILE_POS_WEIGHT", TILE_POSITION_WEIGHT))
+    pw = float(_hook("VGGSFM_TILE_POS_WEIGHT", TILE_POSITION_WEIGHT))
     if pw != 0.0 and max_chunks is not None and kcounts.shape[0] > 1:
         launch_key = tbatch * 2 + is_diag.long()                   # (units are sorted by batch, off-diagonal first)
         cum = torch.cumsum(nchunks, 0).double()
-        first_of = torch.zeros(int(launch_key.max().item()) + 1, dtype=torch.float64, device=dev)
-        total_of = torch.zeros_like(first_of).index_add_(0, launch_key, nchunks.double())
+        total_of = torch.zeros(int(launch_key.max().item()) + 1, dtype=torch.float64, device=dev).index_add_(0, launch_key, nchunks.double())
         starts = torch.cumsum(total_of, 0) - total_of
         frac = ((cum - 0.5 * nchunks.double()) - starts[launch_key]) / total_of[launch_key].clamp(min=1.0)
         nchunks = size_chunks(kw * (1.0 + pw * frac))
@@ -496,7 +512,7 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
             batch_desc.contiguous())
 
 
-SORT_POINTS = os.environ.get("VGGSFM_SORT_POINTS", "1") != "0"   # bundle_adjustment: number the problem's points by track length (compile_problem)
+SORT_POINTS = True                 # bundle_adjustment: number the problem's points by track length (compile_problem); hook VGGSFM_SORT_POINTS=0
 TILE_BACKFILL = None               # (off-diagonal, diagonal) workgroups per CU of the single back-filled tile launch; None = two launches
 TILE_WGS_PER_CU = (3, 4)           # resident schur_tile workgroups per CU with 6 x 6 blocks: (off-diagonal, diagonal) launch
 SPARSE_GRID_DENSITY = 0.05        # compile_problem: below this fill of the (frames x tracks) grid work on the observation list
@@ -703,7 +719,9 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
             ok = ~bad & ~deleted[p]
             f0, fs, p = f0[ok], fs[ok], p[ok]
         tr = tracks.to(torch.float32)
-        # camera-major: sorted by frame (problem order), then point -- the order of the list
+        # camera-major: sorted by frame (problem order); inside a frame in the order of the list -- by input track, which is
+        # by point only without sort_points (no consumer needs the points of a camera ascending: the camera passes sum a
+        # camera's observations in list order, whatever it is)
         cobs_pt = p.to(torch.int32).contiguous()
         col_ptr = torch.zeros(S + 1, dtype=torch.int32, device=dev)
         col_ptr[1:] = torch.cumsum(torch.bincount(fs, minlength=S), 0).to(torch.int32)
@@ -771,8 +789,8 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
     kd = int(bool(refine_focal_length)) + int(bool(refine_extra_params) and camera_type == "SIMPLE_RADIAL")
     block_rows = 6 if (shared_camera or kd == 0) else 6 + kd          # BD of schur_tile_kernel (make_dims in csrc/ba.hip)
     slots = (cus * TILE_WGS_PER_CU[0], cus * TILE_WGS_PER_CU[1]) if block_rows == 6 else (cus * 2, cus * 2)
-    if os.environ.get("VGGSFM_TILE_WGS"):              # measurement hook: workgroups per CU as floats, "off,diag"
-        fo, fd = (float(x) for x in os.environ["VGGSFM_TILE_WGS"].split(","))
+    if _hook("VGGSFM_TILE_WGS"):                       # measurement hook: workgroups per CU as floats, "off,diag"
+        fo, fd = (float(x) for x in _hook("VGGSFM_TILE_WGS").split(","))
         slots = (max(1, int(cus * fo)), max(1, int(cus * fd)))
     # three batches when the factorisation can overlap the later ones (enough camera groups, enough work per batch)
     overlap = OVERLAP_FACTORIZATION if overlap is None else bool(overlap)
@@ -781,8 +799,8 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
     merged = nb == 1 and int(obs_cam.shape[0]) < MERGED_TILE_MAX_OBS
     merged_slots = slots[0] if merged else None
     backfill = TILE_BACKFILL if block_rows == 6 else None
-    if os.environ.get("VGGSFM_TILE_BACKFILL"):         # measurement hook: "off,diag" workgroups per CU, or "0" = two launches
-        v = os.environ["VGGSFM_TILE_BACKFILL"]
+    if _hook("VGGSFM_TILE_BACKFILL"):                  # measurement hook: "off,diag" workgroups per CU, or "0" = two launches
+        v = _hook("VGGSFM_TILE_BACKFILL")
         backfill = None if v == "0" else tuple(float(x) for x in v.split(","))
     if backfill is not None and nb == 1 and not merged:
         # ONE launch, off-diagonal chunks first (one resident round at the merged kernel's occupancy), the diagonal chunks
@@ -915,11 +933,12 @@ def bundle_adjustment(points3d, extrinsics, intrinsics, tracks, masks, image_siz
     (``solve_bundle_adjustment``), which does not run the ObservationManager filter."""
     _lib.require_gpu(points3d, extrinsics, intrinsics, tracks, masks)
     options = options or BundleAdjustmentOptions()
+    sort_points = _hook("VGGSFM_SORT_POINTS", "1" if SORT_POINTS else "0") != "0"
     prob, valid_idx, deleted = compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_params,
                                                shared_camera, camera_type, filter_negative_depth=filter_negative_depth,
                                                gauge="colmap" if constant_pose_frames is None else "config",
                                                camera_split=True, refine_focal_length=options.refine_focal_length,
-                                               refine_extra_params=options.refine_extra_params, sort_points=SORT_POINTS)
+                                               refine_extra_params=options.refine_extra_params, sort_points=sort_points)
     S = extrinsics.shape[0]
     inv_perm = None
     if prob.cam_perm is not None:
@@ -936,7 +955,7 @@ def bundle_adjustment(points3d, extrinsics, intrinsics, tracks, masks, image_siz
         ext = ext[inv_perm]                           # back to the order of the input frames
     pts = prob.pts
     pts[deleted] = 0.0
-    if SORT_POINTS:                                   # back to track order (the contract: rows of the valid tracks, ascending)
+    if sort_points:                                   # back to track order (the contract: rows of the valid tracks, ascending)
         back = torch.argsort(valid_idx)
         pts, deleted, valid_idx = pts[back], deleted[back], valid_idx[back]
     if normalize:

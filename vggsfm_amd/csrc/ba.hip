@@ -1405,7 +1405,7 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
       bitsA[i] = block_slot_bits<BD>(wr + 2 * i);
       bitsB[i] = block_slot_bits<BD>(wc + 2 * i) << 16;
     }
-#if VGG_TILE_PIPE
+#if VGG_TILE_PIPE && !VGG_ABLATE && !VGG_TILE_TRACE     // (ablation / trace builds take sweep(), which carries their hooks)
     if constexpr (CY) {
       // PIPELINED BARRIER (round 5, compressed 6 x 6 off-diagonal tiles): the LAST K step of a batch is issued BEHIND the
       // batch's barrier.  Per step:  [loads of b+DEPTH] [K steps 0, 1 of b; operands of K step 2 fetched] [LDS image of b+1]

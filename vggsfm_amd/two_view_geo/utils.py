@@ -17,8 +17,9 @@ def generate_samples(N, target_num, sample_num, expand_ratio=2):
     return draw[distinct][:target_num]
 
 
-def calculate_residual_indicator(residuals, max_residual, nanvalue=1e6):
-    """utils.py:63-87: score of every hypothesis = its inlier count + a term in [0, 1) that prefers the smaller mean inlier
+def calculate_residual_indicator(residuals, max_residual, debug=False, check=False, nanvalue=1e6):
+    """utils.py:63-87 (`debug` and `check` are accepted and unused, as in the reference -- its call sites pass them:
+    utils/triangulation.py:937-941, two_view_geo/fundamental.py:168): score of every hypothesis = its inlier count + a term in [0, 1) that prefers the smaller mean inlier
     residual (normalised by the largest mean of the whole tensor, so it never changes the order by count).
     residuals (B,S,N) -> (indicator (B,S) f64, inlier_num (B,S) i64, inlier_mask (B,S,N) bool).  Plain tensor ops: the
     RANSAC kernels compute the same ranking on the fly (vgg_fmat_score + the selection in `estimate_fundamental`)."""
@@ -31,11 +32,28 @@ def calculate_residual_indicator(residuals, max_residual, nanvalue=1e6):
     return ind.double() + inlier_num.double(), inlier_num, inlier_mask
 
 
-def sampson_epipolar_distance_batched(pts1, pts2, Fm, squared=True, eps=1e-8):
-    """utils.py:90-173: Sampson distance of the matches pts1 (B,N,2) <-> pts2 (B,N,2) under the fundamental matrices
-    Fm (B,K,3,3) -> (B,K,N); squared by default.  One launch of `vgg_fmat_residuals` over the B K (pair, hypothesis)
-    combinations, in float64."""
+def sampson_epipolar_distance_batched(pts1, pts2, Fm, squared=True, eps=1e-8, debug=False, evaluation=False):
+    """utils.py:90-173: Sampson distance of the matches pts1 (B,N,(2|3)) <-> pts2 (B,N,(2|3)) under the fundamental
+    matrices Fm (B,K,3,3) -> (B,K,N); squared by default.  One launch of `vgg_fmat_residuals` over the B K (pair,
+    hypothesis) combinations, in float64.  `evaluation` only empties the allocator cache in the reference (:147-153): accepted,
+    nothing to do here.  `debug=True` returns the reference's five intermediates (numerator, denominator, distance, epipolar
+    lines of both sides; :167-168) -- a diagnostic path, plain tensor operations on the device."""
+    if not isinstance(Fm, torch.Tensor):
+        raise TypeError(f"Fm type is not a torch.Tensor. Got {type(Fm)}")
+    if Fm.shape[-2:] != (3, 3):
+        raise ValueError(f"Fm must be a (B, K, 3, 3) tensor. Got {Fm.shape}")
     _lib.require_gpu(pts1, pts2, Fm)
+    if debug:
+        h = lambda p: p if p.shape[-1] == 3 else torch.cat((p, torch.ones_like(p[..., :1])), dim=-1)
+        K = Fm.shape[1]
+        F64 = Fm.to(torch.float64)
+        q1 = h(pts1).to(torch.float64)[:, None].expand(-1, K, -1, -1)
+        q2 = h(pts2).to(torch.float64)[:, None].expand(-1, K, -1, -1)
+        line1_in_2 = torch.einsum("bkij,bkjn->bkin", q1, F64.transpose(-2, -1))
+        line2_in_1 = torch.einsum("bkij,bkjn->bkin", q2, F64)
+        numerator = (q2 * line1_in_2).sum(dim=-1).pow(2)
+        denominator = line1_in_2[..., :2].norm(2, dim=-1).pow(2) + line2_in_1[..., :2].norm(2, dim=-1).pow(2)
+        return numerator, denominator, (numerator / denominator).to(pts1.dtype), line1_in_2, line2_in_1
     B, N = pts1.shape[0], pts1.shape[1]
     K = Fm.shape[1]
     p1 = pts1[..., :2].to(torch.float64)[:, None].expand(-1, K, -1, -1).reshape(B * K, N, 2).contiguous()

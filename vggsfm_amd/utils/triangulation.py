@@ -116,6 +116,7 @@ def triangulate_tracks(extrinsics, tracks_normalized, max_ransac_iters=256, lo_n
     S, N = tracks_normalized.shape[0], tracks_normalized.shape[1]
     dev = tracks_normalized.device
     finite = torch.isfinite(tracks_normalized).all().to(torch.int64).reshape(1) if check_finite else None   # (device, not read yet)
+    rng_at_entry = torch.get_rng_state() if check_finite else None         # (5 KB host copy; for the error path below)
     chunk_size, total_chunks = reference_chunks(S, N, max_tri_points_num)
     c0, c1 = (0, total_chunks) if chunk_range is None else (max(0, int(chunk_range[0])), min(total_chunks, int(chunk_range[1])))
     c1 = max(c0, c1)
@@ -177,6 +178,12 @@ def triangulate_tracks(extrinsics, tracks_normalized, max_ransac_iters=256, lo_n
         pending, g_first = [], c + 1
     def raise_if_nonfinite(flag):
         if flag is not None and not int(flag):
+            # The reference fails inside its FIRST chunk, after that chunk's randperm draw and before any other
+            # (triangulation.py:812 -> triangulation_helpers.py:87).  This call has drawn for every chunk by now: put the
+            # global CPU RNG where a caller that catches the error would find it there.
+            torch.set_rng_state(rng_at_entry)
+            if N > 0:
+                _draw_pairs(S, max_ransac_iters, lo_num)
             raise torch.linalg.LinAlgError("triangulate_tracks: non-finite normalised track coordinates (the reference's "
                                            "linalg.eigh fails on the DLT matrices of such views)")
     if n_loc == 0 or nc == 0:

@@ -361,6 +361,16 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
+// The same broadcast through the LDS crossbar (ds_bpermute_b32: no LDS memory involved): the value lands in a VECTOR register.
+// v_readlane writes a scalar pair, and an fp64 instruction on gfx9 takes ONE scalar operand -- a step of factor16_mfma spent 14
+// v_mov_b32 on carrying broadcast values back into vector registers (round 6; VGG_F16_BCAST).  `zero` = a vector register
+// holding 0 (the lane address goes into the instruction's offset field).
+__device__ __forceinline__ double bpermute_f64(double v, int src, int zero) {
+  const int lo = __builtin_amdgcn_ds_bpermute(zero + 4 * src, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(zero + 4 * src, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
 // The same factorisation by ONE wavefront with the block in registers: lane i < 32 holds row i of the (symmetric) block,
 // no LDS round trip and no barrier per pivot column -- the multipliers of a column are broadcast with v_readlane.
 // Per column j: d_j = lane j's x[j]; m = x[j] / d_j (every lane: lane c now holds the multiplier of column c);
@@ -1016,8 +1026,35 @@ __device__ __forceinline__ f64x4 load_block16_sym(const double* D, int kb) {
   return acc;
 }
 
-template <int LD>
+// Round 6, three formulations of the step MEASURED AND NOT ADOPTED (compile-time switches, defaults = the round-5 step;
+// scripts/ubench/factor64_bench, profiles/r06_ab_factor16_variants.jsonl -- one 64 x 64 block, same box):
+//   VGG_F16_LA = 1 / 2 / 4 -- look-ahead: the first LA rows of the NEXT 4 x 4 pivot block are brought up to date by every lane
+//     redundantly, in scalar arithmetic, from values broadcast at the start of the step, so that the next reciprocal chain
+//     starts one multiply-add behind r3 instead of behind two matrix instructions and ten broadcasts: 9.63 -> 10.3 / 11.2 /
+//     13.2 us.  What it takes off the dependent chain (~100 cycles for LA = 1: the first reciprocal only -- the other nine
+//     values still arrive through the update) it puts back as ~30 more instructions per step in a wavefront that issues in
+//     order.
+//   VGG_F16_SQ = 1 -- d_{t+1} takes its last term as (u^2) r_t, one operation behind r_t instead of two: inside the noise.
+//   VGG_F16_BCAST = 1 / 2 -- the pivot block broadcast through the LDS crossbar (ds_bpermute_b32, result in a VECTOR register:
+//     an fp64 instruction takes one scalar operand, and a step spends 14 v_mov_b32 on carrying v_readlane results back):
+//     123 -> 95 instructions per step and 9.53 -> 10.1 / 10.3 us -- the crossbar's round trip in front of every pivot chain
+//     costs more than the moves.
+//   -mllvm -amdgpu-mfma-vgpr-form (no AGPR copies around the matrix instructions, 123 -> 105 instructions): 9.68 -> 9.53 us.
+// Reading: a step is ~850 cycles of dependent fp64 latency (four reciprocal chains, two matrix instructions, the broadcast)
+// plus the issue slots of whatever else is in the stream; removing cheap instructions buys little, and nothing found shortens
+// the dependent part without adding more than it removes.  The 64 x 64 block stays at 9.6 us, the block column at 14 us.
+#ifndef VGG_F16_LA
+#define VGG_F16_LA 0
+#endif
+#ifndef VGG_F16_SQ
+#define VGG_F16_SQ 0
+#endif
+#ifndef VGG_F16_BCAST
+#define VGG_F16_BCAST 0
+#endif
+template <int LD, int LA = VGG_F16_LA, bool SQ = (VGG_F16_SQ != 0)>
 __device__ __forceinline__ bool factor16_mfma(f64x4 acc, double* D, double* Tl, int kb) {
+  static_assert(LA >= 0 && LA <= 4, "rows of the next pivot block taken ahead");
   const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
   double* Db = D + (16 * kb) * LD + 16 * kb;
   double* Tb = Tl + (16 * kb) * LD + 16 * kb;
@@ -1031,41 +1068,85 @@ __device__ __forceinline__ bool factor16_mfma(f64x4 acc, double* D, double* Tl, 
   // selections are multiply-adds with per-lane 0 / 1 constants instead of nested selects (exact: one term per lane is
   // non-zero), and a non-positive or non-finite pivot is no longer caught pivot by pivot (eight compares, eight selects
   // per step) but where it ends up anyway: the scale sqrt(d) of the lane's own column is NaN (rsq of d <= 0, 0 * inf,
-  // or a NaN handed down from an earlier pivot), tested once per 16 columns.  For a positive definite block the
-  // operations and their order are unchanged -- the factor is bit-identical.
+  // or a NaN handed down from an earlier pivot), tested once per 16 columns.
   const double k01 = (li == 1 && lk == 0) ? 1.0 : 0.0, k02 = (li == 2 && lk == 0) ? 1.0 : 0.0, k03 = (li == 3 && lk == 0) ? 1.0 : 0.0;
   const double k12 = (li == 2 && lk == 1) ? 1.0 : 0.0, k13 = (li == 3 && lk == 1) ? 1.0 : 0.0, k23 = (li == 3 && lk == 2) ? 1.0 : 0.0;
   const double kone = (li < 4 && lk == li) ? 1.0 : 0.0;
   const double q0 = (lk == 0) ? 1.0 : 0.0, q1 = (lk == 1) ? 1.0 : 0.0, q2 = (lk == 2) ? 1.0 : 0.0, q3 = (lk == 3) ? 1.0 : 0.0;
+  double pl[4][4] = {};                              // rows < LA of the next pivot block, taken ahead (lower triangle)
+  int vzero = 0;
+  asm volatile("" : "+v"(vzero));                    // (a vector register the compiler cannot fold: bpermute_f64)
+  (void)vzero;
 #pragma unroll
   for (int j0 = 0; j0 < 16; j0 += 4) {
     const int qq = j0 / 4;
     const double pa = acc[qq], pe = accE[qq];
-    // p_ab = A[j0 + a][j0 + b] is register acc[qq] of lane (li = j0 + a, lk = b)
-    const double d0 = readlane_f64(pa, j0);
-    const double u10 = readlane_f64(pa, j0 + 1), p11 = readlane_f64(pa, j0 + 1 + 16);
-    const double u20 = readlane_f64(pa, j0 + 2), p21 = readlane_f64(pa, j0 + 2 + 16), p22 = readlane_f64(pa, j0 + 2 + 32);
-    const double u30 = readlane_f64(pa, j0 + 3), p31 = readlane_f64(pa, j0 + 3 + 16), p32 = readlane_f64(pa, j0 + 3 + 32);
-    const double p33 = readlane_f64(pa, j0 + 3 + 48);
+    // p_ab = A[j0 + a][j0 + b] is register acc[qq] of lane (li = j0 + a, lk = b) -- or was taken ahead by the previous step
+#if VGG_F16_BCAST == 0
+#define VGG_BC(v, l) readlane_f64(v, l)
+#elif VGG_F16_BCAST == 1
+#define VGG_BC(v, l) bpermute_f64(v, l, vzero)
+#else                                                // 2: the first pivot by v_readlane (its reciprocal starts the chain), the rest through LDS
+#define VGG_BC(v, l) (((l) == j0) ? readlane_f64(v, l) : bpermute_f64(v, l, vzero))
+#endif
+#define VGG_P(a, b) ((j0 > 0 && (a) < LA) ? pl[a][b] : VGG_BC(pa, j0 + (a) + 16 * (b)))
+    const double d0 = VGG_P(0, 0);
+    const double r0 = fast_rcp<1>(d0);
+    const double u10 = VGG_P(1, 0), p11 = VGG_P(1, 1);
+    const double u20 = VGG_P(2, 0), p21 = VGG_P(2, 1), p22 = VGG_P(2, 2);
+    const double u30 = VGG_P(3, 0), p31 = VGG_P(3, 1), p32 = VGG_P(3, 2), p33 = VGG_P(3, 3);
+#undef VGG_P
+#undef VGG_BC
+    // inputs of the look-ahead: row j0 + 4 + a of this panel (c) and of the next pivot block (e), as they stand
+    constexpr int LAR = LA > 0 ? LA : 1;
+    double cx[LAR][4], ce[LAR][LAR];
+    const bool ahead = LA > 0 && j0 < 12;
+    if (ahead) {
+      const double pn = acc[(qq + 1) & 3];
+#pragma unroll
+      for (int a = 0; a < LA; ++a) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) cx[a][b] = readlane_f64(pa, j0 + 4 + a + 16 * b);
+#pragma unroll
+        for (int b = 0; b <= a; ++b) ce[a][b] = readlane_f64(pn, j0 + 4 + a + 16 * b);
+      }
+    }
     // the scale of this lane's column of the PREVIOUS step: one short chain per lane in the shadow of the matrix instructions
     if (j0 > 0) fast_rsqrt_sqrt(dlast, rs[qq - 1], sd[qq - 1]);
-    const double r0 = fast_rcp<1>(d0);
-    const double m10 = u10 * r0, m20 = u20 * r0, m30 = u30 * r0;
-    const double d1 = p11 - u10 * m10;
+    const double m10 = u10 * r0, m20 = u20 * r0, m30 = u30 * r0;        // multipliers a_cj / d_j
+    const double d1 = SQ ? __builtin_fma(-(u10 * u10), r0, p11) : p11 - u10 * m10;
     const double u21 = p21 - u20 * m10, u31 = p31 - u30 * m10;
     const double r1 = fast_rcp<1>(d1);
     const double m21 = u21 * r1, m31 = u31 * r1;
-    const double d2 = (p22 - u20 * m20) - u21 * m21;
+    const double d2 = SQ ? __builtin_fma(-(u21 * u21), r1, p22 - u20 * m20) : (p22 - u20 * m20) - u21 * m21;
     const double u32 = (p32 - u30 * m20) - u31 * m21;
     const double r2 = fast_rcp<1>(d2);
     const double m32 = u32 * r2;
-    const double d3 = ((p33 - u30 * m30) - u31 * m31) - u32 * m32;
+    const double d3 = SQ ? __builtin_fma(-(u32 * u32), r2, (p33 - u30 * m30) - u31 * m31) : ((p33 - u30 * m30) - u31 * m31) - u32 * m32;
     const double r3 = fast_rcp<1>(d3);
+    if (ahead) {
+      double xs[LAR][4];
+#pragma unroll
+      for (int a = 0; a < LA; ++a) {
+        xs[a][0] = cx[a][0];
+        xs[a][1] = cx[a][1] - xs[a][0] * m10;
+        xs[a][2] = (cx[a][2] - xs[a][0] * m20) - xs[a][1] * m21;
+        xs[a][3] = ((cx[a][3] - xs[a][0] * m30) - xs[a][1] * m31) - xs[a][2] * m32;
+      }
+#pragma unroll
+      for (int a = 0; a < LA; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+          double v = __builtin_fma(-(xs[a][0] * xs[b][0]), r0, ce[a][b]);
+          v = __builtin_fma(-(xs[a][1] * xs[b][1]), r1, v);
+          v = __builtin_fma(-(xs[a][2] * xs[b][2]), r2, v);
+          pl[a][b] = __builtin_fma(-(xs[a][3] * xs[b][3]), r3, v);
+        }
+    }
     // x_t = sum_k a_k W[k][t]:  W[k][t] = -sum_{k <= s < t} W[k][s] m_ts,  W[k][k] = 1
     const double w02 = __builtin_fma(m10, m21, -m20), w13 = __builtin_fma(m21, m32, -m31);
     const double w03 = __builtin_fma(-w02, m32, __builtin_fma(m10, m31, -m30));
-    // operand lane (li = n, lk = k) carries W[k][n] (n < 4, k <= n), zero elsewhere  (w01 = -m10, w12 = -m21, w23 = -m32;
-    // a form with the three late entries as ONE multiply-add behind m32 measured the same: the step is issue bound)
+    // operand lane (li = n, lk = k) carries W[k][n] (n < 4, k <= n), zero elsewhere  (w01 = -m10, w12 = -m21, w23 = -m32)
     double wsel = __builtin_fma(-k01, m10, kone);
     wsel = __builtin_fma(-k12, m21, wsel);
     wsel = __builtin_fma(k02, w02, wsel);
@@ -1208,8 +1289,17 @@ struct DfShared {
 // subtraction from A and the factorisation -- per element the operations the two workgroups performed before, in the
 // same order.  The diagonal tile's own workgroup returns at once.  A column that starts a decoupled block (camera split, envelope) keeps
 // its own workgroup, so the side-by-side chains remain.
+// Workgroups per CU the kernel is compiled for.  The CHAINED form (up to kDfOrderMax block columns) is a latency chain: a second
+// workgroup on the CU slows the chain's wavefront down -- its matrix instructions share the fp64 pipe (round 6, scripts/ubench/
+// chol_bench with -DVGG_DF_OCC=2, chain wavefronts at priority 3 over 1: n = 1202 0.282 -> 0.310 ms, n = 3200 0.92 -> 1.00).
+// The plain form (more block columns than that: the joint problem of a long video) is bound by how many tiles are RESIDENT ahead
+// of the pivot column: two per CU, n = 6002 dense 2.85 -> 2.44 ms.
+#ifndef VGG_DF_OCC
+#define VGG_DF_OCC 0                          // 0: 1 for the chained form, 2 for the plain one; 1 / 2: both (measurements)
+#endif
+constexpr int df_occupancy(bool chain) { return VGG_DF_OCC ? VGG_DF_OCC : (chain ? 1 : 2); }
 template <bool OVERLAP, bool CHAIN>
-__global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__ A, int n, int nbk, double* __restrict__ Tinv,
+__global__ __launch_bounds__(256, df_occupancy(CHAIN)) void chol_dataflow_kernel(double* __restrict__ A, int n, int nbk, double* __restrict__ Tinv,
                                                             int32_t* __restrict__ flags, int32_t* fail, const int32_t* skip,
                                                             int split_a, int split_b, const int32_t* __restrict__ first_blk,
                                                             DfOverlap ov, const int32_t* __restrict__ tile_map) {
@@ -1220,7 +1310,7 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
   if (skip && *skip) return;
   // This launch is a latency chain with one wavefront per SIMD: whatever else is resident on the CU (a tile batch in
   // overlap mode; DESIGN.md section 6 on the boxes where something outside the process is) must not take its issue slots
-  __builtin_amdgcn_s_setprio(3);
+  __builtin_amdgcn_s_setprio(df_occupancy(CHAIN) > 1 ? 1 : 3);
   // tile of this workgroup: column c holds rows c .. nbk-1 and the rhs row block nbk; launch order = (column, row), or --
   // with a row envelope -- the order of df_tile_map_kernel: columns by dependency depth, tiles outside the envelope left out
   int c = 0, t = blockIdx.x;
@@ -1244,6 +1334,8 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
   auto chained = [&](int x) { return CHAIN && x >= 1 && x < nbk && first_of(x) <= x - 1; };
   if (diag && chained(c)) return;
   const bool merged = CHAIN && !diag && r == c + 1 && chained(r);
+  // (two workgroups per CU: the ones on the pivot chain -- diagonal tiles and the merged first sub-diagonal ones -- go first)
+  if (df_occupancy(CHAIN) > 1 && (diag || merged)) __builtin_amdgcn_s_setprio(3);
   const int kfirst = max(first_of(r), first_of(c));
   const int kstart = merged ? first_of(r) : kfirst;     // (the diagonal tile (r,r) starts at the row's own envelope)
   int32_t* ready = flags;
@@ -1269,22 +1361,43 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
     S2 = ov.S2;
   }
   // the tile of A (C layout: row = 32 wy + 16 m + lk + 4 reg, col = 32 wx + 16 q + li) and the product accumulators;
-  // a merged workgroup carries the diagonal tile (r,r) along (a0d, accd)
+  // a merged workgroup carries the diagonal tile (r,r) along (a0d, accd).
+  // Round 6: the tile's own values are NOT fetched up front any more (64 registers held through the whole update loop for a
+  // subtraction at its end): a0 is requested in front of the LAST update's matrix instructions (its round trip hides behind
+  // them), a0d in front of the wait for the last slab of T.  The kernel then fits 256 registers: two workgroups per CU
+  // (VGG_DF_OCC), and the matrix instructions of the 16 x 16 factorisation can stay in the VGPR file (no AGPR copies).
   f64x4 acc[2][2], a0[2][2], accd[2][2], a0d[2][2];
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < 2; ++q) {
+      acc[m][q] = (f64x4){0.0, 0.0, 0.0, 0.0};
+      accd[m][q] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    }
+  auto load_a0 = [&]() __attribute__((always_inline)) {
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int i = 32 * wy + 16 * m + lk + 4 * reg, j = 32 * wx + 16 * q + li;
-        const bool in = i < vr && j < vc && (!diag || j <= i);
-        a0[m][q][reg] = in ? A[(size_t)(r0 + i) * n + c0 + j] : 0.0;
-        if (OVERLAP && S2 && in) a0[m][q][reg] += ld_agent(&S2[(size_t)(r0 + i) * n + c0 + j]);
-        acc[m][q][reg] = 0.0;
-        a0d[m][q][reg] = (merged && i < vr && j < vr && j <= i) ? A[(size_t)(r0 + i) * n + r0 + j] : 0.0;
-        accd[m][q][reg] = 0.0;
-      }
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int i = 32 * wy + 16 * m + lk + 4 * reg, j = 32 * wx + 16 * q + li;
+          const bool in = i < vr && j < vc && (!diag || j <= i);
+          a0[m][q][reg] = in ? A[(size_t)(r0 + i) * n + c0 + j] : 0.0;
+          if (OVERLAP && S2 && in) a0[m][q][reg] += ld_agent(&S2[(size_t)(r0 + i) * n + c0 + j]);
+        }
+  };
+  auto load_a0d = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int i = 32 * wy + 16 * m + lk + 4 * reg, j = 32 * wx + 16 * q + li;
+          a0d[m][q][reg] = (merged && i < vr && j < vr && j <= i) ? A[(size_t)(r0 + i) * n + r0 + j] : 0.0;
+        }
+  };
 
   // sum += (rows of bufA) (rows of bufB)^T over the 64 columns staged in LDS.  k-index permutation of the MFMA steps: lane
   // group lk supplies the 16 consecutive columns 16 lk .. 16 lk + 15 of the operand row (same permutation for both operands)
@@ -1343,6 +1456,7 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
     }
     __syncthreads();
   }
+  if (nupd <= 0) load_a0();
   // left-looking updates: acc += L[r][k] L[c][k]^T  (merged: and accd += L[r][k] L[r][k]^T)
   for (int t = 0; t < nupd; ++t) {
     const int k = by_depth ? sh.order[t] : kstart + t;
@@ -1369,6 +1483,7 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
       }
     }
     __syncthreads();
+    if (t == nupd - 1) load_a0();                        // (in flight behind the matrix instructions below)
     if (do_tile) multiply_staged(bufA, bufB, acc);
     if (merged) multiply_staged(bufA, bufA, accd);
     __syncthreads();                                     // operands consumed: the buffers may be refilled
@@ -1445,6 +1560,7 @@ __global__ __launch_bounds__(256) void chol_dataflow_kernel(double* __restrict__
   const double* Tc = Tinv + (size_t)c * DFB * DFB;
 #pragma unroll
   for (int kb = 0; kb < 4; ++kb) {
+    if (kb == 3 && merged) load_a0d();                   // (the diagonal tile's own values: needed behind the last slab)
     df_wait_ge(&tready[c], kb + 1, fail);
     if (kb == 3) DF_STAMP(2);                            // the last columns of T arrived
     const int ns = 4 * (kb + 1);

@@ -339,6 +339,13 @@ int vgg_ba_set_tile_rhs(int enable);
  * share from the cameras' J^T J, J^T r); 2 = every other observation of a lane from its factor.  Same step up to rounding;
  * 1 and 2 measured slower on gfx950 (ba.hip, point_step_kernel) and are kept for measurements. */
 int vgg_ba_set_step_from_factors(int enable);
+/* Round-6 measurement switch for the off-diagonal Schur tile launch with 6 x 6 blocks (two launches per batch only): 0 (default;
+ * VGG_TILE_DMA seeds it) = segments staged through registers from the compressed records; 1 = LDS-DMA (global_load_lds_dwordx4)
+ * from an EXPANDED image of the segments, which a kernel of its own derives from the compressed records in front of the launch
+ * (the workspace grows by 2304 bytes per segment: query vgg_ba_workspace_bytes AFTER setting the mode); 2 = 1 + a touch of the
+ * lines of the batch after next.  Same tile sums up to the rounding of the rebuilt rows.  Measured, not adopted: ba.hip,
+ * schur_tile_dma_kernel. */
+int vgg_ba_set_tile_dma(int mode);
 int vgg_ba_profile(int enable, int max_launches_per_kernel);
 int vgg_ba_profile_read(int kernel_id, double* total_ms, int* launches, int reset);
 

@@ -66,6 +66,12 @@ CASES = {
     #   call 2 -> index 5 > 2: SHRINK the window to 4 frames;  call 4 -> index 2: STEP BACK, the loop retries (call 5, clean)
     "radial_t60": dict(T=60, N=6000, seed=11, n_new=400, init=16, window=8, joint_interval=3, max_query_pts=4096,
                        occlusions={2: 5, 4: 2}, camera_type="SIMPLE_RADIAL"),
+    # the reference's own defaults (cfgs/video_demo.yaml:8-13: init 32 / window 16 / joint BA every 6 windows / 1024 query points)
+    # on the OTHER camera branch it allows (SIMPLE_PINHOLE shared, video_runner.py:1019-1039; extra_params = zeros, :148-152):
+    #   call 2 -> index 9 > 2: SHRINK the 16-frame window to 8;  call 5 -> index 2: STEP BACK, retry with doubled query budget.
+    # `compact`: the (point, frame) tables of all snapshots but the last are kept as digests too (the file stays < 2 MB)
+    "pinhole_t160": dict(T=160, N=16000, seed=23, n_new=400, init=32, window=16, joint_interval=6, max_query_pts=1024,
+                         occlusions={2: 9, 5: 2}, camera_type="SIMPLE_PINHOLE", k1=0.0, compact=True),
 }
 
 
@@ -98,7 +104,7 @@ def run_case(name, p):
     for m in ("vggsfm.utils.tensor_to_pycolmap",):
         mod = __import__(m, fromlist=["_"])
         mod.pycolmap = pycolmap_shim
-    world = VideoWorld(p["T"], p["N"], p["seed"], n_new=p["n_new"], occlusions=p["occlusions"])
+    world = VideoWorld(p["T"], p["N"], p["seed"], n_new=p["n_new"], occlusions=p["occlusions"], k1=p.get("k1", 0.02))
     T = world.T
 
     def frames_of(images):                                   # images (..., C, H, W) with pixel value = frame index
@@ -148,7 +154,8 @@ def run_case(name, p):
                  "points3D": torch.from_numpy(init["points3D"]), "points3D_rgb": None,
                  "extrinsics_opencv": torch.from_numpy(init["extrinsics"]),
                  "intrinsics_opencv": K64[None].expand(p["init"], -1, -1).clone(),
-                 "extra_params": torch.full((p["init"], 1), world.k1, dtype=torch.float64)}
+                 "extra_params": (torch.full((p["init"], 1), world.k1, dtype=torch.float64)
+                                  if p["camera_type"] == "SIMPLE_RADIAL" else None)}
     runner.sparse_reconstruct = lambda *a, **k: init_pred
     runner.dicts_to_output = lambda *a, **k: {}
     runner._update_points_color = lambda *a, **k: None
@@ -172,6 +179,10 @@ def run_case(name, p):
     images = torch.arange(T, dtype=torch.float32).reshape(1, T, 1, 1, 1).expand(1, T, 3, 2, 2).clone()
     crop = torch.zeros(1, T, 8)
     pycolmap_shim.CALLS.clear()
+    # (demo.py:34 seed_all_random_engines: the loop draws from Python's `random` -- prepare_window_data's cap, video_runner.py:1070)
+    import random
+    random.seed(0)
+    np.random.seed(0)
     torch.manual_seed(0)
     with _StableSort(), _PromotingBmm(), warnings.catch_warnings(), torch.no_grad():
         warnings.simplefilter("ignore")
@@ -183,17 +194,29 @@ def run_case(name, p):
     print("  solver calls:", [(c[0], c[1]["num_iterations"]) for c in pycolmap_shim.CALLS if c[0] != "pose_refinement"])
     out = dict(T=np.int64(T), N=np.int64(p["N"]), seed=np.int64(p["seed"]), n_new=np.int64(p["n_new"]),
                init=np.int64(p["init"]), window=np.int64(p["window"]), joint_interval=np.int64(p["joint_interval"]),
-               max_query_pts=np.int64(p["max_query_pts"]), camera_type=p["camera_type"],
+               max_query_pts=np.int64(p["max_query_pts"]), camera_type=p["camera_type"], k1=np.float64(world.k1),
                occl_calls=np.array(sorted(p["occlusions"]), np.int64),
                occl_first_bad=np.array([p["occlusions"][k] for k in sorted(p["occlusions"])], np.int64),
                world_sha256=world.digest(), num_snapshots=np.int64(len(snaps)), kinds=np.array(kinds),
                provider_log=np.array([f"{k}:{a}:{b}:{d}" for k, a, b, d in world.log]))
     import hashlib
+    compact = bool(p.get("compact"))
     for i, s in enumerate(snaps):
+        last = i + 1 == len(snaps)
         for k, v in s.items():
-            if k == "obs_uv" and i + 1 < len(snaps):         # pixels: a digest (bit-exact check), the array only for the last
+            if k == "kind":
+                continue
+            if k == "obs_uv" and (compact or not last):     # pixels: a digest (bit-exact check); the first golden keeps the last array
                 out[f"s{i}_obs_uv_sha256"] = hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest()
-            elif k != "kind":
+            elif k in ("obs_point", "obs_frame") and compact:
+                out[f"s{i}_{k}_sha256"] = hashlib.sha256(np.ascontiguousarray(v.astype(np.int64)).tobytes()).hexdigest()
+                out[f"s{i}_{k}_count"] = np.int64(len(v))
+            elif k == "pids" and compact:                    # (0 .. n-1 in every snapshot: asserted, only the count is kept)
+                assert np.array_equal(v, np.arange(len(v)))
+                out[f"s{i}_pids_count"] = np.int64(len(v))
+            elif k == "xyz" and compact:                     # compared to 1e-4: float32 keeps 1e-7 of the scene's extent
+                out[f"s{i}_xyz"] = v.astype(np.float32)
+            else:
                 out[f"s{i}_{k}"] = v
     path = os.path.join(OUT, f"video_{name}.npz")
     np.savez_compressed(path, **out)

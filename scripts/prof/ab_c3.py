@@ -57,11 +57,15 @@ def main():
             os.environ["VGGSFM_AMD_DEBUG_HOOKS"] = "1"       # (the product path reads the VGGSFM_* switches only behind this gate)
             L.vgg_ba_set_tile_rhs(1)
             L.vgg_ba_set_step_from_factors(0)
+            L.vgg_ba_set_tile_dma(0)
             coll = None
             for kv in filter(None, envs.split(",")):
                 k, _, val = kv.partition("=")
                 if k == "TILE_RHS":                        # (process-wide library switch, not an environment variable here)
                     L.vgg_ba_set_tile_rhs(int(val))
+                    continue
+                if k == "TILE_DMA":                        # (LDS-DMA staging of the off-diagonal tile launch, round-6 A/B)
+                    L.vgg_ba_set_tile_dma(int(val))
                     continue
                 if k == "STEP_FACTORS":
                     L.vgg_ba_set_step_from_factors(int(val))

@@ -274,6 +274,41 @@ def test_ba_tile_rhs_matches_camera_pass(S, N, cam, shared, rf, rk):
             np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-8, atol=1e-8)
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("S,N,cam,shared,rf,rk", [(60, 3000, "SIMPLE_RADIAL", True, True, True), (90, 2500, "SIMPLE_RADIAL", False, False, False),
+                                                  (200, 12000, "SIMPLE_RADIAL", True, True, True)])
+def test_ba_tile_dma_matches_register_staging(S, N, cam, shared, rf, rk, mode, monkeypatch):
+    """Round-6 A/B (vgg_ba_set_tile_dma; measured, not the default): the off-diagonal tile launch stages its segments by LDS-DMA
+    from an expanded image instead of rebuilding them from the compressed records through registers.  Same tile sums up to the
+    rounding of the rebuilt rows: same LM trajectory.  (Two tile launches forced: the merged launch of small problems has no
+    DMA form.)"""
+    monkeypatch.setattr(BA, "MERGED_TILE_MAX_OBS", 0)
+    sc = make_scene(S, N, cam, shared_camera=shared, seed=47)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=47)
+    opt = BundleAdjustmentOptions()
+    opt.refine_focal_length, opt.refine_extra_params = rf, rk
+    opt.solver_options.max_num_iterations = 8
+    L = _lib.lib()
+
+    def solve():
+        return BA.bundle_adjustment(D(pts0), D(ext0), D(K0), D(sc.tracks), D(sc.mask), None, D(extra0), shared, cam, opt)
+    try:
+        assert L.vgg_ba_set_tile_dma(0) == 0
+        ref = solve()
+        assert L.vgg_ba_set_tile_dma(mode) == 0
+        a, b = solve(), solve()
+    finally:
+        L.vgg_ba_set_tile_dma(0)
+    for x, y in zip(a[:4], b[:4]):                       # bit-reproducible
+        assert x is None or torch.equal(x, y)
+    assert a[4]["num_iterations"] == ref[4]["num_iterations"]
+    for ia, ib in zip(a[4]["iterations"], ref[4]["iterations"]):
+        assert ia["successful"] == ib["successful"] and abs(ia["cost"] - ib["cost"]) <= 1e-11 * ib["cost"], (ia, ib)
+    for x, y in zip(a[:4], ref[:4]):
+        if x is not None:
+            np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-9, atol=1e-9)
+
+
 @pytest.mark.parametrize("S,N,cam,shared,rf,rk,mode", [(60, 3000, "SIMPLE_RADIAL", True, True, True, 1), (40, 2500, "SIMPLE_PINHOLE", True, True, True, 1),
                                                        (24, 1500, "SIMPLE_RADIAL", True, True, False, 2), (90, 2500, "SIMPLE_RADIAL", False, False, False, 1),
                                                        (200, 12000, "SIMPLE_RADIAL", True, True, True, 2)])

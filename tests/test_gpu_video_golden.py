@@ -9,5 +9,6 @@ from tests.video_golden_driver import run_against_golden
 pytestmark = pytest.mark.gpu
 
 
-def test_video_geometry_reproduces_the_reference_loop():
-    run_against_golden("radial_t60", "cuda")
+@pytest.mark.parametrize("case", ["radial_t60", "pinhole_t160"])
+def test_video_geometry_reproduces_the_reference_loop(case):
+    run_against_golden(case, "cuda")

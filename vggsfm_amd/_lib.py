@@ -65,7 +65,7 @@ EXPORTED = ["vgg_build_arch", "vgg_abi_version", "vgg_abi_sizeof", "vgg_project_
             "vgg_ba_begin", "vgg_ba_phase", "vgg_ba_reduce_buffer", "vgg_ba_finish", "vgg_cholesky_solve",
             "vgg_ba_profile", "vgg_ba_profile_read", "vgg_cholesky_workspace_bytes", "vgg_pose_refine",
             "vgg_p3p_ransac_workspace_bytes", "vgg_p3p_ransac", "vgg_fmat_seven_point", "vgg_fmat_score",
-            "vgg_fmat_eight_point", "vgg_fmat_residuals", "vgg_cholesky_solve_split", "vgg_ba_poll_done", "vgg_ba_tuning", "vgg_cholesky_solve_envelope", "vgg_ba_set_tile_rhs", "vgg_ba_set_step_from_factors", "vgg_triangulate_tracks_chunks_enqueue"]
+            "vgg_fmat_eight_point", "vgg_fmat_residuals", "vgg_cholesky_solve_split", "vgg_ba_poll_done", "vgg_ba_tuning", "vgg_cholesky_solve_envelope", "vgg_ba_set_tile_rhs", "vgg_ba_set_step_from_factors", "vgg_triangulate_tracks_chunks_enqueue", "vgg_ba_set_tile_dma"]
 
 _lib = None
 

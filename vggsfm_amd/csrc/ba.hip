@@ -136,6 +136,10 @@ struct Ws {  // device workspace carve-up (pointers into the caller's buffer)
   double* rz;                 // [ceil(C / 16)][96 x 3] rz_part summed over the chunks of a group's diagonal tile (tile_reduce_kernel)
   int tile_rhs;               // 1: cam_pass<RHS> is not launched, its sums come from the diagonal tile launch + point_pass
   int step_from_factors;      // 1: point_step_kernel takes E^T F dy from the compressed Schur factors (no Jacobian sweep)
+  // round-6 A/B (vgg_ba_set_tile_dma): the off-diagonal tile launch stages by LDS-DMA from the EXPANDED image of the segments
+  double* Yx;                 // [num_segments + 1][3][96]: a segment as the tile kernels hold it in LDS (component-major rows)
+  size_t yx_bytes;
+  int tile_dma;
   size_t lin_count, sys_count, total_bytes;
 };
 
@@ -155,6 +159,13 @@ static Dims make_dims(const vgg_ba_problem* pb) {
   d.loss = pb->loss; d.loss_scale = pb->loss_scale;
   return d;
 }
+
+// overrides of the automatic launch choices (vgg_ba_tuning; the environment variables seed them): 0 / -1 = automatic
+struct Tuning { int lpp, longt, cam_wgs, point_wgs, tile_rhs, step_factors, tile_dma; };
+static Tuning g_tuning = [] {
+  auto env = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+  return Tuning{env("VGG_LPP", 0), env("VGG_PP_LONGT", -1), env("VGG_CAM_WGS", 0), env("VGG_POINT_WGS", 0), env("VGG_TILE_RHS", 1), env("VGG_STEP_FACTORS", 0), env("VGG_TILE_DMA", 0)};
+}();
 
 static Ws carve(const Dims& d, int max_iters, int num_chunks, int num_segments, void* base) {
   Ws w;
@@ -192,6 +203,9 @@ static Ws carve(const Dims& d, int max_iters, int num_chunks, int num_segments, 
   // + one all-zero segment behind the last real one (target of the tile kernel's loads past the end of a list)
   w.y_bytes = 8ull * ((size_t)(num_segments > 0 ? num_segments : 0) + 1) * kGroup * y_slot_doubles(d);
   w.Y = (double*)take(w.y_bytes);
+  w.yx_bytes = (g_tuning.tile_dma && (d.shared || d.kd == 0)) ? 8ull * ((size_t)(num_segments > 0 ? num_segments : 0) + 1) * kGroup * 18 : 0;
+  w.Yx = w.yx_bytes ? (double*)take(w.yx_bytes) : nullptr;
+  w.tile_dma = 0;
   w.chol_inv = (double*)take(cholesky_workspace_bytes(d.n_red));
   {
     const size_t bdt = d.shared ? 6 : d.BDp;
@@ -614,12 +628,6 @@ __global__ __launch_bounds__(256) void prep_kernel(DevProblem pb, Ws w, vgg_ba_o
 // its serial work (reductions, 3 x 3 factorisation), which outweighs the sweeps over its observations up to ~70 of them:
 // measured per LM iteration, point_pass + point_step -- c2 (mean 12.5 observations) 64: 0.112, 32: 0.075, 16: 0.065,
 // 8: 0.059 ms; c3 (mean 50) 64: 0.674, 32: 0.549, 16: 0.499, 8: 0.535 ms; one c4 shard (mean 100) 32: 0.509, 16: 0.544 ms.
-// overrides of the automatic launch choices (vgg_ba_tuning; the environment variables seed them): 0 / -1 = automatic
-struct Tuning { int lpp, longt, cam_wgs, point_wgs, tile_rhs, step_factors; };
-static Tuning g_tuning = [] {
-  auto env = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
-  return Tuning{env("VGG_LPP", 0), env("VGG_PP_LONGT", -1), env("VGG_CAM_WGS", 0), env("VGG_POINT_WGS", 0), env("VGG_TILE_RHS", 1), env("VGG_STEP_FACTORS", 0)};
-}();
 static int lanes_per_point(int P, int O) {
   const int forced = g_tuning.lpp;
   if (forced == 8 || forced == 16 || forced == 32 || forced == 64) return forced;
@@ -1709,6 +1717,219 @@ __global__ __launch_bounds__(256, (BD == 6 ? VGG_OFFDIAG_OCC : 2)) void schur_ti
   else schur_tile_body<BD, false>(w, chunk_desc, entries, chunk, zero_seg, ops);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Round-6 A/B (vgg_ba_set_tile_dma): the off-diagonal launch of 6 x 6 tiles with LDS-DMA staging in
+// today's three-workgroups-per-CU shape.  The segments are read from their EXPANDED image Yx[seg][component][96 rows] -- what
+// schur_tile_body rebuilds from the compressed records on the way into LDS (12 DPP moves, 18 fp64 operations, 19 selects and six
+// ds_writes per lane and batch) -- by global_load_lds_dwordx4: 1 KB per wavefront instruction, straight into the LDS image, no
+// staging registers, no write phase.  The XOR swizzle of the odd entries sits on the SOURCE address (the destination of an
+// LDS-DMA instruction is lane-linear), the operand reads are those of schur_tile_body.
+// Two LDS buffers (three would not fit three workgroups per CU: 3 x 18 KB each), so the image of batch b + 1 is requested
+// behind barrier(b - 1) and has ONE matrix phase to land; mode 2 adds a touch of batch b + 2's lines (one dword load per 128
+// bytes) so that the DMA finds them in the L2.  For the measurement the expanded image is produced by a kernel of its own from
+// the compressed records (expand_segments_kernel, timed apart); in a product form point_pass would write it.
+// MEASURED, NOT ADOPTED (profiles/r06_ab_tile_ldsdma_c3.jsonl, configs[2], same box, two rounds, sums bit-identical to the
+// register-staged launch at equal chunking): register staging 0.528-0.532 ms; LDS-DMA at three workgroups per CU 0.559-0.565;
+// at FOUR per CU (the kernel needs 114 registers and 36 KB: it fits) 0.516-0.525; with the touch 0.66-0.72; with the last K step
+// behind the barrier (-DVGG_DMA_PIPE) 2.3.  The write phase is gone, but six DMA instructions per wavefront and batch cost
+// their own issue time (the guide: 60-185 cycles a piece next to matrix instructions) and the image has one matrix phase to land
+// in front of a vmcnt(0) + barrier; the -1..2 % of the best variant is less than the 0.24 GB per iteration the expanded image
+// would add to point_pass' writes (0.33 ms for the stand-alone expansion).  Closed.
+__global__ __launch_bounds__(256) void expand_segments_kernel(Ws w, int num_segments) {
+  if (w.ctl->done) return;
+  const size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x;            // (segment, camera slot)
+  if (slot >= ((size_t)num_segments + 1) * kGroup) return;
+  const size_t seg = slot / kGroup;
+  const int sl = (int)(slot - seg * kGroup);
+  const double* rec = w.Y + slot * kYc;                                 // N (3 x 3, row-major), 2 a
+  double m[kYc];
+#pragma unroll
+  for (int i = 0; i < kYc; ++i) m[i] = rec[i];
+  double* dst = w.Yx + seg * (kGroup * 18) + 6 * sl;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double n0 = m[k], n1 = m[3 + k], n2 = m[6 + k];
+    // rows 0..2 = (2 a) x N[:, k] with the operations of schur_tile_body's rebuild, rows 3..5 = N[:, k]
+    dst[k * 96 + 0] = m[10] * n2 - m[11] * n1;
+    dst[k * 96 + 1] = m[11] * n0 - m[9] * n2;
+    dst[k * 96 + 2] = m[9] * n1 - m[10] * n0;
+    dst[k * 96 + 3] = n0; dst[k * 96 + 4] = n1; dst[k * 96 + 5] = n2;
+  }
+}
+
+#ifndef VGG_DMA_PIPE
+#define VGG_DMA_PIPE 0               // 1: the last K step of a batch behind its barrier, as schur_tile_body's pipelined order
+#endif
+template <int MODE>
+__global__ __launch_bounds__(256, VGG_OFFDIAG_OCC) void schur_tile_dma_kernel(Ws w, const int32_t* __restrict__ chunk_desc,
+                                                                              const int32_t* __restrict__ entries, int chunk0, int zero_seg) {
+  constexpr int BD = 6, R = kGroup * BD, SEG = 3 * R, NT = R / 16, NH = (NT + 1) / 2, SWZ = 16;
+  static_assert((SEG * 8) % 256 == 0, "swizzle");
+  __shared__ __attribute__((aligned(16))) double ops[2 * 2 * 4 * SEG];
+  if (w.ctl->done) return;
+  const int chunk = chunk0 + blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int e0 = chunk_desc[6 * chunk + 2], e1 = chunk_desc[6 * chunk + 3];
+  const int cj = chunk_desc[6 * chunk + 4], cJ = chunk_desc[6 * chunk + 5];
+  constexpr int BPS = kSub / 4;
+  const int nsub = (e1 - e0 + kSub - 1) / kSub;
+  const int nb = ((nsub - cj + cJ - 1) / cJ) * BPS;
+  auto ebase = [&](int b) -> int { return e0 + ((b / BPS) * cJ + cj) * kSub + (b % BPS) * 4; };
+  f64x4_t acc[NH][NH];
+#pragma unroll
+  for (int i = 0; i < NH; ++i)
+#pragma unroll
+    for (int j = 0; j < NH; ++j) acc[i][j] = (f64x4_t){0.0, 0.0, 0.0, 0.0};
+  // wavefront `wave` brings in the two segments of entry `wave` of a batch: 144 sixteen-byte pieces each = two full
+  // instructions + one of 16 lanes.  Piece y of the LDS image holds piece y ^ 8 of the segment when the entry is odd.
+  const char* Yx = reinterpret_cast<const char*>(w.Yx);
+  const int lane_off = ((lane ^ ((wave & 1) * (SWZ / 2))) * 16);
+  auto seg_of = [&](int b, int side) -> int {
+    const int e = ebase(b) + wave;
+    return (e < e1) ? entries[4 * (size_t)e + 1 + side] : zero_seg;
+  };
+  // (the segment indices of a batch are scalar loads issued one batch ahead: no round trip in front of the DMA)
+  int seg_nextA = seg_of(0, 0), seg_nextB = seg_of(0, 1);
+  auto issue_dma = [&](int b, int buf) __attribute__((always_inline)) {
+    const int segs[2] = {seg_nextA, seg_nextB};
+    seg_nextA = seg_of(b + 1, 0); seg_nextB = seg_of(b + 1, 1);
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      const char* src = Yx + (size_t)segs[side] * (SEG * 8) + lane_off;
+      double* dst = ops + (size_t)((buf * 2 + side) * 4 + wave) * SEG;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 1024),
+                                       (__attribute__((address_space(3))) void*)(dst + 128), 16, 0, 0);
+      // the 16-lane tail: NOT behind a lane condition -- the compiler duplicates the neighbouring DMA statements into the two arms
+      // of such a branch and merges their tails with the LDS destination as a per-lane value (its readfirstlane then serves one
+      // arm: batch 0 of every chunk got side B's pieces from the wrong place).  All lanes run the statement; the execution mask
+      // is narrowed inside it (M0 = the wave-uniform LDS byte address, written in the statement that reads it).
+      {
+        const unsigned lds_tail = (unsigned)__builtin_amdgcn_readfirstlane((int)(uintptr_t)(__attribute__((address_space(3))) void*)(dst + 256));
+        const char* gtail = src + 2048;
+        unsigned long long keep;
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 0xffff\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\ts_mov_b64 exec, %0"
+                     : "=&s"(keep) : "v"(gtail), "s"(lds_tail) : "memory");
+      }
+    }
+  };
+  // (mode 2) one dword of every 128-byte line of the two segments of batch b: lanes 0..17 side A, 32..49 side B
+  auto touch = [&](int b) -> int {
+    int v = 0;
+    if constexpr (MODE == 2) {
+      const int sub = lane & 31;
+      if (sub < 18) {
+        const char* src = Yx + (size_t)seg_of(b, lane >> 5) * (SEG * 8) + sub * 128;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(src) : "memory");
+      }
+    }
+    return v;
+  };
+  const int li = lane & 15, lk = lane >> 4;
+  const int kbase = lk * SEG, swz = (lk & 1) * SWZ;
+  auto load_quad_mask = [&](int eb) -> uint32_t { return (uint32_t)entries[4 * (size_t)min(eb, e1 - 1) + 3]; };
+  const int wr = wave >> 1, wc = wave & 1;
+  int rowoffA[NH], rowoffB[NH];
+  uint32_t bitsA[NH], bitsB[NH];
+#pragma unroll
+  for (int i = 0; i < NH; ++i) {
+    rowoffA[i] = kbase + ((16 * min(wr + 2 * i, NT - 1) + li) ^ swz);
+    rowoffB[i] = kbase + ((16 * min(wc + 2 * i, NT - 1) + li) ^ swz);
+    bitsA[i] = block_slot_bits<BD>(wr + 2 * i);
+    bitsB[i] = block_slot_bits<BD>(wc + 2 * i) << 16;
+  }
+  double a[2][NH], bq[2][NH];
+  auto fetch = [&](int set, int buf, int ks) __attribute__((always_inline)) {
+    const double* As = ops + (size_t)(buf * 2) * 4 * SEG;
+    const double* Bs = ops + (size_t)(buf * 2 + 1) * 4 * SEG;
+#pragma unroll
+    for (int i = 0; i < NH; ++i) { a[set][i] = As[rowoffA[i] + ks * R]; bq[set][i] = Bs[rowoffB[i] + ks * R]; }
+  };
+  auto pin = [&](int set) __attribute__((always_inline)) {
+    static_assert(NH == 3, "operand sets");
+    asm volatile("" : "+v"(a[set][0]), "+v"(a[set][1]), "+v"(a[set][2]), "+v"(bq[set][0]), "+v"(bq[set][1]), "+v"(bq[set][2]));
+  };
+  uint32_t on = 0u;
+  auto skip_bits = [&](uint32_t qm) -> uint32_t {
+    uint32_t colm = 0u, o = 0u;
+#pragma unroll
+    for (int j = 0; j < NH; ++j) colm |= ((qm & bitsB[j]) != 0 ? 1u : 0u) << j;
+#pragma unroll
+    for (int i = 0; i < NH; ++i) o |= ((qm & bitsA[i]) != 0 ? colm : 0u) << (NH * i);
+    return VGG_NO_SKIP ? 0xFFFFFFFFu : (uint32_t)__builtin_amdgcn_readfirstlane((int)o);
+  };
+  auto group = [&](int set) __attribute__((always_inline)) {
+    uint32_t m = on;
+    asm volatile("" : "+s"(m));
+#pragma unroll
+    for (int i = 0; i < NH; ++i)
+#pragma unroll
+      for (int j = 0; j < NH; ++j)
+        if (m & (1u << (NH * i + j))) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[set][i], bq[set][j], acc[i][j], 0, 0, 0);
+  };
+  uint32_t qmask = load_quad_mask(ebase(0)), qmask_next = load_quad_mask(ebase(1));
+  issue_dma(0, 0);
+  int tv = touch(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                  // (the compiler puts the vmcnt(0) of the LDS-DMA in front of it)
+  asm volatile("" :: "v"(tv));
+#if VGG_DMA_PIPE
+  fetch(0, 0, 0);
+#endif
+  for (int b = 0; b < nb; ++b) {
+    const int buf = b & 1;
+    issue_dma(b + 1, buf ^ 1);                      // buffer buf^1: its last readers (batch b - 1) finished in front of barrier(b - 1)
+    tv = touch(b + 2);
+    on = skip_bits(qmask);
+#if VGG_DMA_PIPE
+    // (operand set P = b & 1 holds K step 0 of batch b; the sets alternate roles from batch to batch -- but the set index must be
+    //  a compile-time constant, so the loop body is written for both parities)
+    if (buf == 0) {
+      fetch(1, buf, 1); pin(0); group(0);
+      fetch(0, buf, 2); pin(1); group(1);
+      pin(0);
+      qmask = qmask_next; qmask_next = load_quad_mask(ebase(b + 2));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the tail pieces are asm statements: not in the compiler's count)
+      __syncthreads();
+      asm volatile("" :: "v"(tv));
+      fetch(1, buf ^ 1, 0);
+      pin(0); group(0);
+    } else {
+      fetch(0, buf, 1); pin(1); group(1);
+      fetch(1, buf, 2); pin(0); group(0);
+      pin(1);
+      qmask = qmask_next; qmask_next = load_quad_mask(ebase(b + 2));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the tail pieces are asm statements: not in the compiler's count)
+      __syncthreads();
+      asm volatile("" :: "v"(tv));
+      fetch(0, buf ^ 1, 0);
+      pin(1); group(1);
+    }
+#else
+    fetch(0, buf, 0);
+    fetch(1, buf, 1); pin(0); group(0);
+    fetch(0, buf, 2); pin(1); group(1);
+    pin(0); group(0);
+    qmask = qmask_next; qmask_next = load_quad_mask(ebase(b + 2));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    asm volatile("" :: "v"(tv));
+#endif
+  }
+  double* part = w.tile_part + (size_t)chunk * R * R;
+#pragma unroll
+  for (int i = 0; i < NH; ++i)
+#pragma unroll
+    for (int j = 0; j < NH; ++j)
+      if (wr + 2 * i < NT && wc + 2 * j < NT) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) part[(size_t)(16 * (wr + 2 * i) + lk + 4 * reg) * R + 16 * (wc + 2 * j) + li] = acc[i][j][reg];
+      }
+}
+
 // S[(cI,a,i),(cJ,b,j)] = - sum over the chunks of tile (gI,gJ) of the partial tiles (plain stores: every
 // element of S outside the per-camera diagonal terms belongs to exactly one (tile, element)).
 // grid = (R*R/256, num_tiles): one element per thread, chunks summed in order.
@@ -2332,8 +2553,18 @@ static void launch_schur_batch(const Launch& L, int batch, hipStream_t st, doubl
     ProfScope ps(kProfSchurTile, st);
     schur_tile_merged_kernel<BD><<<c1 - c0, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, c0, L.num_segments);
   } else if (cm > c0) {
-    ProfScope ps(kProfSchurTile, st);
-    schur_tile_kernel<BD, false><<<cm - c0, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, c0, L.num_segments);
+    if (BD == 6 && L.w.tile_dma) {                 // round-6 A/B: LDS-DMA staging from the expanded segment image
+      {
+        ProfScope ps(kProfCamRhs, st);              // (the slot of cam_pass<RHS>, which tile_rhs leaves empty: the expansion, timed apart)
+        expand_segments_kernel<<<div_up((L.num_segments + 1) * kGroup, 256), 256, 0, st>>>(L.w, L.num_segments);
+      }
+      ProfScope ps(kProfSchurTile, st);
+      if (L.w.tile_dma == 2) schur_tile_dma_kernel<2><<<cm - c0, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, c0, L.num_segments);
+      else schur_tile_dma_kernel<1><<<cm - c0, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, c0, L.num_segments);
+    } else {
+      ProfScope ps(kProfSchurTile, st);
+      schur_tile_kernel<BD, false><<<cm - c0, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, c0, L.num_segments);
+    }
   }
   if (!L.merged_tile_launch && c1 > cm) {
     ProfScope ps(kProfSchurTileDiag, st);
@@ -2567,6 +2798,7 @@ static int make_launch(const vgg_ba_problem* pb, const vgg_ba_options* opt, void
   // constant intrinsics), one tile batch (the overlap mode needs the right-hand side before its later batches have run)
   L->w.tile_rhs = (g_tuning.tile_rhs && (L->d.shared || L->d.kd == 0) && pb->num_chunks > 0 && pb->num_tile_batches == 1) ? 1 : 0;
   L->w.step_from_factors = (L->d.shared || L->d.kd == 0) ? g_tuning.step_factors : 0;      // (compressed factors in the segment buffer)
+  L->w.tile_dma = (L->w.Yx && !pb->merged_tile_launch && pb->num_tile_batches == 1) ? g_tuning.tile_dma : 0;
   L->cam_q = pb->cam_q; L->cam_t = pb->cam_t; L->intr = pb->intr; L->pts = pb->pts;
   return VGG_OK;
 }
@@ -2623,12 +2855,18 @@ int vgg_ba_tuning(int lanes_per_point, int long_tracks, int cam_workgroups, int 
   if (!(lanes_per_point == 0 || lanes_per_point == 8 || lanes_per_point == 16 || lanes_per_point == 32 || lanes_per_point == 64))
     return VGG_ERR_INVALID_ARGUMENT;
   vgg::g_tuning = vgg::Tuning{lanes_per_point, long_tracks < 0 ? -1 : (long_tracks ? 1 : 0), cam_workgroups > 0 ? cam_workgroups : 0,
-                              point_workgroups > 0 ? point_workgroups : 0, vgg::g_tuning.tile_rhs, vgg::g_tuning.step_factors};
+                              point_workgroups > 0 ? point_workgroups : 0, vgg::g_tuning.tile_rhs, vgg::g_tuning.step_factors,
+                              vgg::g_tuning.tile_dma};
   return VGG_OK;
 }
 
 int vgg_ba_set_tile_rhs(int enable) {
   vgg::g_tuning.tile_rhs = enable ? 1 : 0;
+  return VGG_OK;
+}
+
+int vgg_ba_set_tile_dma(int mode) {
+  vgg::g_tuning.tile_dma = (mode >= 0 && mode <= 2) ? mode : 0;
   return VGG_OK;
 }
 

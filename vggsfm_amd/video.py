@@ -14,6 +14,8 @@
 
 All kernels underneath are the ones of the batch path (pose.hip, geometry.hip, triangulate.hip, ba.hip).
 """
+import random
+
 import torch
 
 from . import _lib
@@ -196,6 +198,7 @@ class VideoGeometry:
         self.camera_type = camera_type
         self.max_query_pts = int(max_query_pts)
         self.generator = generator
+        self._vis_order = {}
         self.table = TrackTable(self.device)
 
     # ------------------------------------------------------------------ state
@@ -204,14 +207,37 @@ class VideoGeometry:
         self.table.add_window_prediction(pred, start_idx, end_idx)
 
     def select_existing_points(self, frame_idx, max_ratio=1):
-        """video_runner.py:1062-1084: the points visible in `frame_idx`, at most max_query_pts * max_ratio of them
-        (uniform subset, ids ascending), with their 3D position and their pixel in that frame."""
+        """video_runner.py:1062-1084: the points visible in `frame_idx`, at most max_query_pts * max_ratio of them, with their
+        3D position and their pixel in that frame -- IN THE ORDER OF THE REFERENCE'S LIST ``frame_dict[f]["visible_points"]``,
+        which is what its draw acts on: over the cap it takes ``sorted(random.sample(list, cap))`` from PYTHON's global
+        ``random`` (:1068-1071; demo.py seeds it with cfg.seed) -- ``random.sample`` picks POSITIONS --, under the cap it keeps
+        the list as it stands, and the order of this window's carried-over points is the order in which they are appended to the
+        lists of the window's frames.  A frame's list: the points that were new in the window that registered it (``move_window``
+        adds them first, :866), ascending, then that window's carried-over points in THEIR order (:893-903); every joint BA
+        rebuilds all lists in plain id order (``reconstruction_to_dicts``).  `_vis_order[frame]` holds that order for the
+        frames registered since the last joint BA (absent: id order).  The same global ``random`` state then gives the same
+        subset (tests/golden/video_pinhole_t160.npz: the reference's default 1024-point cap is hit in every window).  Not
+        reproduced: after a step-back the reference's list of a RE-registered frame holds its carried-over points twice
+        (:454) and a draw from that frame could return a point twice; the table keeps a point once.  With a ``generator``
+        (constructor) the subset comes from ``torch.randperm`` on it instead, in id order."""
         t = self.table
-        sel = torch.nonzero(t.obs_frame == frame_idx).squeeze(1)
+        sel = torch.nonzero(t.obs_frame == frame_idx).squeeze(1)                 # (observations are sorted by point id)
         cap = self.max_query_pts * max_ratio
-        if sel.numel() > cap:
-            pick = torch.randperm(sel.numel(), device=self.device, generator=self.generator)[:cap]
-            sel = sel[torch.sort(pick).values]                                   # (observations are sorted by point id)
+        n = int(sel.numel())
+        order = self._vis_order.get(int(frame_idx)) if self.generator is None else None
+        if order is not None:
+            ids_sorted = t.obs_point[sel]
+            where = torch.searchsorted(ids_sorted, order)
+            if order.numel() == n and bool((ids_sorted[where.clamp(max=n - 1)] == order).all()):
+                sel = sel[where]                                                  # the list's order
+            # (else: the list and the table disagree -- a re-registered frame; id order)
+        if n > cap:
+            if self.generator is None:
+                pick = torch.as_tensor(random.sample(range(n), cap), dtype=torch.long, device=sel.device)
+                sel = sel[pick]
+                sel = sel[torch.argsort(t.obs_point[sel])]                        # sorted(...) of the drawn ids
+            else:
+                sel = sel[torch.sort(torch.randperm(n, device=self.device, generator=self.generator)[:cap]).values]
         ids = t.obs_point[sel]
         return ids, t.xyz[ids], t.obs_uv[sel]
 
@@ -283,6 +309,7 @@ class VideoGeometry:
         pred = {"extrinsics_opencv": ext_opt[1:], "pred_track": ntr[1:], "pred_vis": vis_nf[:, nkeep][1:],
                 "valid_2D_mask": nm[1:], "valid_tracks": torch.ones(int(nkeep.sum()), dtype=torch.bool, device=self.device),
                 "points3D": npts, "points3D_rgb": None}
+        first_new = int(t.num_points)
         t.add_window_prediction(pred, start_idx, end_idx)
         # the carried-over points keep xyz / id and gain the observations of this window (video_runner.py:868-903)
         _, etr, em, ekeep = filter_points_and_compute_masks(pts_opt[:ne], tr_all[:, :ne], ext_opt, K, ep, min_valid_track_length)
@@ -292,6 +319,10 @@ class VideoGeometry:
             mapping = torch.zeros(t.num_points, dtype=torch.long, device=self.device)
             mapping[eids] = torch.arange(eids.numel(), device=self.device)
             t.update_points(start_idx, end_idx, em[1:], etr[1:], evis[1:], eids, mapping)
+        # the reference's per-frame lists of this window's frames (select_existing_points): new points, then carried-over ones
+        new_ids = first_new + torch.arange(int(nkeep.sum()), device=self.device)
+        for fi, f in enumerate(range(start_idx, end_idx)):
+            self._vis_order[f] = torch.cat([new_ids[nm[1 + fi].bool()], eids[em[1 + fi].bool()]])
         return start_idx, end_idx, True
 
     # ------------------------------------------------------------------ joint BA
@@ -308,6 +339,7 @@ class VideoGeometry:
         vi = summ["valid_idx"]
         rgb = t.rgb[vi] if t.rgb.shape[0] == xyz.shape[0] else None
         t.reset_from_tensors(pts, e, tracks[:, vi], inl, keep, rgb, start_idx)
+        self._vis_order.clear()                                      # (every list rebuilt in id order)
         return summ
 
     # ------------------------------------------------------------------ the loop of VideoRunner.run

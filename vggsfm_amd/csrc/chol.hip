@@ -1289,15 +1289,19 @@ struct DfShared {
 // subtraction from A and the factorisation -- per element the operations the two workgroups performed before, in the
 // same order.  The diagonal tile's own workgroup returns at once.  A column that starts a decoupled block (camera split, envelope) keeps
 // its own workgroup, so the side-by-side chains remain.
-// Workgroups per CU the kernel is compiled for.  The CHAINED form (up to kDfOrderMax block columns) is a latency chain: a second
-// workgroup on the CU slows the chain's wavefront down -- its matrix instructions share the fp64 pipe (round 6, scripts/ubench/
-// chol_bench with -DVGG_DF_OCC=2, chain wavefronts at priority 3 over 1: n = 1202 0.282 -> 0.310 ms, n = 3200 0.92 -> 1.00).
-// The plain form (more block columns than that: the joint problem of a long video) is bound by how many tiles are RESIDENT ahead
-// of the pivot column: two per CU, n = 6002 dense 2.85 -> 2.44 ms.
+// Workgroups per CU the kernel is compiled for (round 6: with the tile's own values loaded late both forms fit 256 registers;
+// -DVGG_DF_OCC=2 / 1 force both, profiles/r06_ab_factor16_variants.jsonl + r06_ab_chol_occupancy_c5.jsonl).  ONE, for both forms:
+//   * the CHAINED form (up to kDfOrderMax block columns) is a latency chain: a second workgroup on the CU slows the chain's
+//     wavefront down -- its matrix instructions share the fp64 pipe (chain wavefronts at priority 3 over 1 all the same):
+//     n = 1202 0.282 -> 0.310 ms, n = 3200 0.92 -> 1.00;
+//   * the plain form gains where the launch is bound by how many tiles are resident ahead of the pivot column -- a DENSE
+//     n = 6002: 2.85 -> 2.44 ms -- but the large systems of the product are the k-way ordered joint problems of a long video
+//     (row envelope, depth-ordered launch), and there two per CU lose 1.5 % (configs[4] final joint problem, n = 6002, same box,
+//     interleaved: 1.038 / 1.026 against 1.014 / 1.011 ms).
 #ifndef VGG_DF_OCC
-#define VGG_DF_OCC 0                          // 0: 1 for the chained form, 2 for the plain one; 1 / 2: both (measurements)
+#define VGG_DF_OCC 1
 #endif
-constexpr int df_occupancy(bool chain) { return VGG_DF_OCC ? VGG_DF_OCC : (chain ? 1 : 2); }
+constexpr int df_occupancy(bool chain) { (void)chain; return VGG_DF_OCC; }
 template <bool OVERLAP, bool CHAIN>
 __global__ __launch_bounds__(256, df_occupancy(CHAIN)) void chol_dataflow_kernel(double* __restrict__ A, int n, int nbk, double* __restrict__ Tinv,
                                                             int32_t* __restrict__ flags, int32_t* fail, const int32_t* skip,

@@ -112,6 +112,29 @@ __device__ __forceinline__ void smallest_eigvec4(const Sym4& m, double* v) {
 // Up to kInvRounds factorisations; what is still moving after that (lambda_1 = lambda_2 to rounding: no parallax at all)
 // goes to the Jacobi.  `live` = the lane's result is used (a dead lane must not send its wavefront into the fallback).
 constexpr int kInvIt = 6, kInvRounds = 6;
+#ifndef VGG_TRI_FASTDIV
+#define VGG_TRI_FASTDIV 1    // 1 = the pivot reciprocals and the normalisation of the inverse iteration from the hardware estimates +
+#endif                       //     Newton steps (1 ulp) instead of IEEE divisions / sqrt + division: the iteration converges to the same
+                             //     vector (its tolerance is 1e-14), four divisions and one per step are ~200 instructions per solve
+__device__ __forceinline__ double tri_rcp(double x) {
+#if VGG_TRI_FASTDIV
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+#else
+  return 1.0 / x;
+#endif
+}
+__device__ __forceinline__ double tri_rsqrt(double x) {
+#if VGG_TRI_FASTDIV
+  double r = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  r = r * __builtin_fma(-h * r, r, 1.5);
+  return r * __builtin_fma(-h * r, r, 1.5);
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
 __device__ __forceinline__ bool smallest_eigvec4_invit(const Sym4& m, double* v, bool live) {
   const double tr = m.a[0] + m.a[4] + m.a[7] + m.a[9];
   bool ok = (tr > 0.0) && (tr <= 1.7976931348623157e308);
@@ -122,15 +145,15 @@ __device__ __forceinline__ bool smallest_eigvec4_invit(const Sym4& m, double* v,
 #pragma unroll 1
   for (int round = 0; round < kInvRounds; ++round) {
     // L D L^T of A - sig I (unit lower L: l10 l20 l30 l21 l31 l32; reciprocal pivots r0..r3)
-    const double d0 = m.a[0] - sig, r0 = 1.0 / d0;
+    const double d0 = m.a[0] - sig, r0 = tri_rcp(d0);
     const double l10 = m.a[1] * r0, l20 = m.a[2] * r0, l30 = m.a[3] * r0;
-    const double d1 = (m.a[4] - sig) - l10 * m.a[1], r1 = 1.0 / d1;
+    const double d1 = (m.a[4] - sig) - l10 * m.a[1], r1 = tri_rcp(d1);
     const double u21 = m.a[5] - l20 * m.a[1], u31 = m.a[6] - l30 * m.a[1];
     const double l21 = u21 * r1, l31 = u31 * r1;
-    const double d2 = ((m.a[7] - sig) - l20 * m.a[2]) - l21 * u21, r2 = 1.0 / d2;
+    const double d2 = ((m.a[7] - sig) - l20 * m.a[2]) - l21 * u21, r2 = tri_rcp(d2);
     const double u32 = (m.a[8] - l30 * m.a[2]) - l31 * u21;
     const double l32 = u32 * r2;
-    const double d3 = (((m.a[9] - sig) - l30 * m.a[3]) - l31 * u31) - l32 * u32, r3 = 1.0 / d3;
+    const double d3 = (((m.a[9] - sig) - l30 * m.a[3]) - l31 * u31) - l32 * u32, r3 = tri_rcp(d3);
     ok = ok && (d0 > 0.0) && (d1 > 0.0) && (d2 > 0.0) && (d3 > 0.0);
 #pragma unroll 1
     for (int it = 0; it < kInvIt; ++it) {
@@ -139,7 +162,7 @@ __device__ __forceinline__ bool smallest_eigvec4_invit(const Sym4& m, double* v,
       const double y3 = w3 * r3, y2 = w2 * r2 - l32 * y3, y1 = (w1 * r1 - l21 * y2) - l31 * y3,
                    y0 = ((w0 * r0 - l10 * y1) - l20 * y2) - l30 * y3;
       const double n2 = (y0 * y0 + y1 * y1) + (y2 * y2 + y3 * y3);
-      double rn = 1.0 / sqrt(n2);
+      double rn = tri_rsqrt(n2);
       if (x0 * y0 + x1 * y1 + x2 * y2 + x3 * y3 < 0.0) rn = -rn;     // (successive iterates point the same way)
       const double n0 = y0 * rn, n1 = y1 * rn, nn2 = y2 * rn, n3 = y3 * rn;
       const double dlt = fmax(fmax(fabs(n0 - x0), fabs(n1 - x1)), fmax(fabs(nn2 - x2), fabs(n3 - x3)));
@@ -229,7 +252,7 @@ __device__ __forceinline__ void view_dlt_matrix_r(const double* __restrict__ P, 
 }
 
 // angular error of X against view s (calculate_normalized_angular_error_batched); `cand` = err can be <= max_rad
-__device__ __forceinline__ double view_error(const double* __restrict__ P, const double* tab, double X0, double X1,
+__device__ __forceinline__ double view_error(const double* __restrict__ P, double ray0, double ray1, double ray2, double X0, double X1,
                                              double X2, double cos_gate, bool& is_nan, double& depth) {
   const double y0 = P[0] * X0 + P[1] * X1 + P[2] * X2 + P[3];
   const double y1 = P[4] * X0 + P[5] * X1 + P[6] * X2 + P[7];
@@ -240,10 +263,10 @@ __device__ __forceinline__ double view_error(const double* __restrict__ P, const
   // angle of a candidate inlier by ~5e-15 rad -- a decision changes only where |error - threshold| is below that (the goldens
   // compare every mask bit).  (max(|y|, 1e-12) of the reference = max(|y|^2, 1e-24) under the root.)
   const double rn = rsqrt(fmax(y0 * y0 + y1 * y1 + y2 * y2, 1e-24));
-  double c = (tab[0] * (y0 * rn) + tab[1] * (y1 * rn)) + tab[2] * (y2 * rn);
+  double c = (ray0 * (y0 * rn) + ray1 * (y1 * rn)) + ray2 * (y2 * rn);
 #else
   const double n = fmax(sqrt(y0 * y0 + y1 * y1 + y2 * y2), 1e-12);
-  double c = (tab[0] * (y0 / n) + tab[1] * (y1 / n)) + tab[2] * (y2 / n);
+  double c = (ray0 * (y0 / n) + ray1 * (y1 / n)) + ray2 * (y2 / n);
 #endif
   is_nan = (c != c);
   c = fmin(fmax(c, -1.0), 1.0);
@@ -276,6 +299,86 @@ __device__ __forceinline__ bool any_pair_angle(const double* __restrict__ center
   return found;
 }
 
+// Walk over the visible views of a track; the body gets the projection matrix (scalar registers), the unit ray, the view and
+// its position in the list.  -DVGG_TRI_PIPE=1 (round 6, MEASURED SLOWER, off): the matrix of the NEXT view already requested
+// while the body runs.  The view loops are wave-uniform -- the index comes out of LDS (v_readfirstlane), the matrix through
+// scalar loads: a dependent chain of an LDS round trip and a scalar-memory round trip in front of every view, which the
+// compiler cannot move across the loop's back edge, and 38 % of a wavefront's resident time is s_waitcnt
+// (profiles/r05_pmc_sq_tri.json).  With two NAMED matrix sets per trip (no copies between stages, which is what sank the
+// round-4 attempt), the index and the ray fetched one step further ahead and ONE wait per view placed behind the body (LDS
+// reads and scalar loads share lgkmcnt and scalar loads return out of order: any wait for LDS data waits for every scalar load
+// in flight) the kernel takes 13.3 ms against 11.85 at configs[2] and 1.38 against 1.34 at configs[1]
+// (profiles/r06_ab_tri_c3.jsonl; masks and points identical): the extra vector registers (rays and index of two views in
+// flight: 52 B of scratch at four hypotheses per lane) and the serialising waits cost more than the chain they hide -- the
+// second resident wavefront covers it already.
+// body(const double (&P)[12], double ray0, double ray1, double ray2, int s, int k)
+#ifndef VGG_TRI_PIPE
+#define VGG_TRI_PIPE 0
+#endif
+template <class F>
+__device__ __forceinline__ void for_each_view(const double* __restrict__ ext, const double* tab, const int* vlist, int nv, F&& body) {
+#if VGG_TRI_PIPE
+  if (nv <= 0) return;
+  double pa[12], pb[12];
+  auto request = [&](double (&p)[12], int s) __attribute__((always_inline)) {
+    const double* P = ext + 12 * s;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) p[i] = P[i];
+  };
+  // LDS reads and scalar loads share one counter (lgkmcnt) and scalar loads return out of order, so ANY wait for LDS data also
+  // waits for every scalar load in flight.  The schedule per view k (matrix set A; set B = view k + 1 is in flight):
+  //   [index of view k + 2 -> scalar; LDS reads of its ray and of the index of view k + 3 issued]  [body(k): no memory access]
+  //   [ONE wait: the ray, the index, set B -- all requested a whole body ago]  [set A requested for view k + 2]
+  // and the same with the sets swapped: a matrix has the body of the view in between to arrive, the two LDS round trips
+  // (index, then ray) are hidden behind a body as well, and the body gets the ray as values.
+  struct Ray { double r0, r1, r2; };
+  auto clampk = [&](int k) { return min(k, nv - 1); };
+  auto ray_of = [&](int sv) __attribute__((always_inline)) -> Ray {
+    const double* t = tab + sv * kTab;
+    Ray r; r.r0 = t[0]; r.r1 = t[1]; r.r2 = t[2];
+    return r;
+  };
+  // prologue: views 0 and 1
+  int sa = __builtin_amdgcn_readfirstlane(vlist[0]), sb = __builtin_amdgcn_readfirstlane(vlist[clampk(1)]);
+  Ray ra = ray_of(sa), rb = ray_of(sb);
+  int idx_next = vlist[clampk(2)];                      // (vector register; becomes a scalar one step later)
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra.r0), "+v"(ra.r1), "+v"(ra.r2), "+v"(rb.r0), "+v"(rb.r1), "+v"(rb.r2), "+v"(idx_next) : : "memory");
+  request(pa, sa);
+  request(pb, sb);
+  int k = 0;
+  for (; k + 1 < nv; k += 2) {
+    {
+      const int s2 = __builtin_amdgcn_readfirstlane(idx_next);
+      Ray r2 = ray_of(s2);
+      int idx3 = vlist[clampk(k + 3)];
+      body(pa, ra.r0, ra.r1, ra.r2, sa, k);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r2.r0), "+v"(r2.r1), "+v"(r2.r2), "+v"(idx3) : : "memory");
+      request(pa, s2);
+      sa = s2; ra = r2; idx_next = idx3;
+    }
+    {
+      const int s3 = __builtin_amdgcn_readfirstlane(idx_next);
+      Ray r3 = ray_of(s3);
+      int idx4 = vlist[clampk(k + 4)];
+      body(pb, rb.r0, rb.r1, rb.r2, sb, k + 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r3.r0), "+v"(r3.r1), "+v"(r3.r2), "+v"(idx4) : : "memory");
+      request(pb, s3);
+      sb = s3; rb = r3; idx_next = idx4;
+    }
+  }
+  if (k < nv) body(pa, ra.r0, ra.r1, ra.r2, sa, k);
+#else
+  for (int k = 0; k < nv; ++k) {
+    const int s = __builtin_amdgcn_readfirstlane(vlist[k]);
+    double p[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) p[i] = ext[12 * s + i];
+    const double* t = tab + s * kTab;
+    body(p, t[0], t[1], t[2], s, k);
+  }
+#endif
+}
+
 struct Cand { double e; int n; };   // mean inlier error (or 2*pi) and inlier count of one hypothesis
 
 // Evaluate hypothesis X against all views.  ACC: also accumulate the DLT matrix of its inlier views.
@@ -306,18 +409,15 @@ __device__ __forceinline__ Cand eval_views(const double* __restrict__ ext, const
       if (y2 <= 0.0) behind = true;
     }
   }
-  for (int k = 0; k < ((VGG_TRI_ABLATE & 2) ? 0 : nv); ++k) {
-    // (the view index is the same in every lane -- it comes out of LDS, which the compiler cannot know: as a scalar the
-    //  projection matrix is fetched by scalar loads into scalar registers instead of 12 vector loads into 24 VGPRs.
-    //  A hand-written two-stage pipeline of this loop -- index two views ahead, matrix and ray one ahead -- was SLOWER,
-    //  21.9 against 19.2 ms at configs[2]: the copies between the stages cost more than the latency they hide; walking the
-    //  tracks in the order of their first visible view, so that the wavefronts resident together share their views'
-    //  matrices in the scalar cache, changed nothing: 16.60 against 16.69 ms)
-    const int s = __builtin_amdgcn_readfirstlane(vlist[k]);
-    const double* t = tab + s * kTab;
+  // (the view index is the same in every lane -- it comes out of LDS, which the compiler cannot know: as a scalar the projection
+  //  matrix is fetched by scalar loads into scalar registers instead of 12 vector loads into 24 VGPRs.  Walking the tracks in the
+  //  order of their first visible view, so that the wavefronts resident together share their views' matrices in the scalar
+  //  cache, changed nothing: 16.60 against 16.69 ms)
+  for_each_view(ext, tab, vlist, (VGG_TRI_ABLATE & 2) ? 0 : nv, [&](const double (&P)[12], double t0, double t1, double t2, int s, int k) __attribute__((always_inline)) {
+    (void)s;
     bool isn;
     double depth;
-    const double err = view_error(ext + 12 * s, t, X0, X1, X2, cos_gate, isn, depth);
+    const double err = view_error(P, t0, t1, t2, X0, X1, X2, cos_gate, isn, depth);
     if (isn && ransac_nan) poisoned = true;
     const bool inl = live && !invalid && !isn && (err <= max_rad);
     if (inl) {
@@ -330,13 +430,13 @@ __device__ __forceinline__ Cand eval_views(const double* __restrict__ ext, const
           for (int k2 = 0; k2 < 10; ++k2) acc->a[k2] += gv[k * 10 + k2];
         } else {
           Sym4 mv;
-          view_dlt_matrix_r(ext + 12 * s, t[0], t[1], t[2], mv);
+          view_dlt_matrix_r(P, t0, t1, t2, mv);
 #pragma unroll
           for (int k2 = 0; k2 < 10; ++k2) acc->a[k2] += mv.a[k2];
         }
       }
     }
-  }
+  });
   if (any_behind) *any_behind = behind;
   Cand c;
   c.n = cnt;
@@ -381,7 +481,7 @@ __device__ __forceinline__ Cand eval_views_grouped(const double* __restrict__ ex
     const double* t = tab + sc * kTab;
     bool isn;
     double depth;
-    const double err = view_error(ext + 12 * sc, t, X0, X1, X2, cos_gate, isn, depth);
+    const double err = view_error(ext + 12 * sc, t[0], t[1], t[2], X0, X1, X2, cos_gate, isn, depth);
     if (has && isn && ransac_nan) poisoned = true;
     const bool inl = has && live && !invalid && !isn && (err <= max_rad);
     Sym4 mv;
@@ -529,19 +629,16 @@ __global__ __launch_bounds__(64, VGG_TRI_OCC) void triangulate_kernel(   // (rou
 #pragma unroll
     for (int j = 0; j < HJ; ++j) { cnt[j] = 0; sum[j] = 0.0; pois[j] = bad_ray; }
     // (visible views only: see eval_views)
-    for (int k = 0; k < ((VGG_TRI_ABLATE & 1) ? 0 : nv); ++k) {
-      const int s = __builtin_amdgcn_readfirstlane(vlist[k]);
-      const double* t = tab + s * kTab;
-      const double* P = ext + 12 * s;
+    for_each_view(ext, tab, vlist, (VGG_TRI_ABLATE & 1) ? 0 : nv, [&](const double (&P)[12], double t0, double t1, double t2, int, int) __attribute__((always_inline)) {
 #pragma unroll
       for (int j = 0; j < HJ; ++j) {
         bool isn;
         double depth;
-        const double err = view_error(P, t, X[j][0], X[j][1], X[j][2], cos_gate, isn, depth);
+        const double err = view_error(P, t0, t1, t2, X[j][0], X[j][1], X[j][2], cos_gate, isn, depth);
         if (isn) pois[j] = true;
         if (live[j] && !inv[j] && !isn && err <= max_rad) { ++cnt[j]; sum[j] += err; }
       }
-    }
+    });
     Cand best;                      // running first-maximum of the residual indicator, candidate order
     best.e = 0.0; best.n = -1;      //   [RANSAC 0..H-1 | LO1 0..lo1-1 | LO2 0..lo2-1]
     double best_ind = -1.0;
@@ -695,7 +792,7 @@ __global__ __launch_bounds__(64, VGG_TRI_OCC) void triangulate_kernel(   // (rou
       const double* t = tab + s * kTab;
       bool isn;
       double depth;
-      const double err = view_error(ext + 12 * s, t, W0, W1, W2, cos_gate, isn, depth);
+      const double err = view_error(ext + 12 * s, t[0], t[1], t[2], W0, W1, W2, cos_gate, isn, depth);
       out_mask[(size_t)n * S + s] = (!w_inv && t[3] == 0.0 && !isn && err <= max_rad) ? 1 : 0;
     }
   }

@@ -770,32 +770,3 @@ def test_ba_partial_intrinsics_refinement_matches_oracle(shared, rf, rk):
     np.testing.assert_allclose(ext.cpu().numpy(), eo, atol=5e-6)
     np.testing.assert_allclose(K.cpu().numpy()[:, 0, 0], Ko[:, 0, 0], rtol=1e-6)
     np.testing.assert_allclose(extra.cpu().numpy(), xo, atol=1e-6)
-
-
-@pytest.mark.parametrize("S,N,cam,shared,window", [(17, 1500, "SIMPLE_RADIAL", True, True), (33, 2500, "SIMPLE_PINHOLE", True, False),
-                                                   (70, 3000, "SIMPLE_RADIAL", False, False)])
-def test_ba_host_compiled_problem_is_the_device_compiled_one(S, N, cam, shared, window, monkeypatch):
-    """Round 6: for a small problem `bundle_adjustment` builds the index structures on HOST copies of the inputs (~550 tiny
-    launches and ~70 host reads otherwise: 6 ms in front of a 1.5 ms window solve); the depth test of the negative-depth filter is
-    still evaluated on the device.  Same DeviceProblem, hence the same solve, bit for bit -- with points behind cameras and a
-    point past the coordinate cap in the scene."""
-    sc = make_scene(S, N, cam, shared_camera=shared, seed=53)
-    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=53)
-    pts0[5] = [0, 0, -2.0]
-    pts0[6, 0] = 4000.0
-    pts0[9] = -pts0[9]
-    opt = BundleAdjustmentOptions()
-    opt.solver_options.max_num_iterations = 6
-
-    def solve():
-        if window:
-            return BA.window_bundle_adjustment(D(pts0), D(ext0), D(K0), D(sc.tracks), D(sc.mask), 200, D(extra0), shared, cam, opt)
-        return BA.bundle_adjustment(D(pts0), D(ext0), D(K0), D(sc.tracks), D(sc.mask), None, D(extra0), shared, cam, opt)
-    assert sc.mask.size <= BA.HOST_COMPILE_MAX_GRID
-    a = solve()
-    monkeypatch.setattr(BA, "HOST_COMPILE_MAX_GRID", 0)
-    b = solve()
-    for x, y in zip(a[:4], b[:4]):
-        assert x is None or torch.equal(x, y)
-    assert torch.equal(a[4]["valid_idx"], b[4]["valid_idx"]) and torch.equal(a[4]["deleted"], b[4]["deleted"])
-    assert [it["cost"] for it in a[4]["iterations"]] == [it["cost"] for it in b[4]["iterations"]]

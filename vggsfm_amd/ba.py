@@ -517,7 +517,6 @@ TILE_BACKFILL = None               # (off-diagonal, diagonal) workgroups per CU 
 TILE_WGS_PER_CU = (3, 4)           # resident schur_tile workgroups per CU with 6 x 6 blocks: (off-diagonal, diagonal) launch
 SPARSE_GRID_DENSITY = 0.05        # compile_problem: below this fill of the (frames x tracks) grid work on the observation list
 MERGED_TILE_MAX_OBS = 1_000_000   # below: off-diagonal and diagonal tiles share one launch
-HOST_COMPILE_MAX_GRID = 1 << 20   # bundle_adjustment: (frames x tracks) cells up to which compile_problem runs on the host
 CAMERA_SPLIT_MIN_STEPS = 2    # shared 64-column factorisation steps below which re-ordering the cameras is not worth it
 
 
@@ -647,7 +646,7 @@ def envelope_blocks(first_group, num_cams, n_reduced, group=GROUP, block=64):
 def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_params=None, shared_camera=False,
                     camera_type="SIMPLE_PINHOLE", max_points3D_val=3000, filter_negative_depth=True,
                     gauge="colmap", overlap=None, camera_split=False, adjacency_reduce=None, refine_focal_length=True,
-                    refine_extra_params=True, sort_points=False, neg_depth_bad=None, device_cus=None):
+                    refine_extra_params=True, sort_points=False):
     """tensors (reference layout, on the GPU) -> DeviceProblem + bookkeeping.
     Returns (problem, valid_idx (P',) long, deleted (P',) bool).
     overlap: cut the Schur tiles into TILE_BATCHES batches so that a single-GPU solve can factorise beside the later
@@ -662,12 +661,7 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
     track order -- `valid_idx` is then not monotonic.  The point passes give 16 (32) lanes to a point and 4 (2) points to a
     wavefront, which walks the longest of its tracks: with neighbours of equal length no lane waits for another point's
     observations.  Nothing else depends on the numbering (the tile work list is ordered by sweep position, the camera-major
-    list by camera).
-    neg_depth_bad / device_cus (round 6, the small-problem path of `bundle_adjustment`): the function is device agnostic, and
-    for a small problem -- a video window: ~550 tiny launches and ~70 host reads, 6 ms on the GPU in front of a solve of
-    1.5 ms -- it runs on HOST copies of the inputs.  The one piece of floating-point arithmetic in it, the depth test of the
-    negative-depth filter, is then handed in as the (S, N) bool the DEVICE computed over the input tracks (``masks & ~(z >=
-    eps)``), and the CU count of the device that will run the solve as a number."""
+    list by camera)."""
     if camera_type not in MODEL_ID:
         raise ValueError(f"Camera type {camera_type} is not supported yet")
     dev = tracks.device
@@ -718,11 +712,8 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
             # ObservationManager::FilterObservationsWithNegativeDepth, vectorised: observations are visited
             # image by image; one is deleted when its depth < eps, and the whole point goes once a deletion
             # meets a track of length <= 2  <=>  (initial length - number of bad observations) <= 1.
-            if neg_depth_bad is not None:
-                bad = neg_depth_bad[f0, valid_idx[p]]
-            else:
-                z = (ext[fs, 2, :3] * pts[p]).sum(-1) + ext[fs, 2, 3]
-                bad = ~(z >= torch.finfo(torch.float64).eps)
+            z = (ext[fs, 2, :3] * pts[p]).sum(-1) + ext[fs, 2, 3]
+            bad = ~(z >= torch.finfo(torch.float64).eps)
             nbad = torch.bincount(p[bad], minlength=P)
             deleted = (nbad >= 1) & ((torch.bincount(p, minlength=P) - nbad) <= 1)
             ok = ~bad & ~deleted[p]
@@ -758,12 +749,8 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
             # ObservationManager::FilterObservationsWithNegativeDepth, vectorised: observations are visited
             # image by image; one is deleted when its depth < eps, and the whole point goes once a deletion
             # meets a track of length <= 2  <=>  (initial length - number of bad observations) <= 1.
-            if neg_depth_bad is not None:
-                nb_ = neg_depth_bad if cam_perm is None else neg_depth_bad[cam_perm]
-                bad = m & nb_[:, valid_idx]
-            else:
-                z = torch.einsum("sj,pj->sp", ext[:, 2, :3], pts) + ext[:, 2, 3][:, None]
-                bad = m & ~(z >= torch.finfo(torch.float64).eps)
+            z = torch.einsum("sj,pj->sp", ext[:, 2, :3], pts) + ext[:, 2, 3][:, None]
+            bad = m & ~(z >= torch.finfo(torch.float64).eps)
             nbad = bad.sum(0)
             deleted = (nbad >= 1) & ((m.sum(0) - nbad) <= 1)
             m = m & ~bad
@@ -796,7 +783,7 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
         cam_const[0] = 1                            # SetConstantCamPose(first registered image)
         if S > 1:
             cam_const[1] = 2                        # SetConstantCamPositions(second image, {0})
-    cus = device_cus or (torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == "cuda" else 256)
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == "cuda" else 256
     # resident schur_tile workgroups per CU (occupancy of the kernel variant): off-diagonal launch 3 (BD = 6) or 2,
     # diagonal launch 4 or 2 -- one full round each
     kd = int(bool(refine_focal_length)) + int(bool(refine_extra_params) and camera_type == "SIMPLE_RADIAL")
@@ -947,30 +934,11 @@ def bundle_adjustment(points3d, extrinsics, intrinsics, tracks, masks, image_siz
     _lib.require_gpu(points3d, extrinsics, intrinsics, tracks, masks)
     options = options or BundleAdjustmentOptions()
     sort_points = _hook("VGGSFM_SORT_POINTS", "1" if SORT_POINTS else "0") != "0"
-    dev = tracks.device
-    ckw = dict(filter_negative_depth=filter_negative_depth, gauge="colmap" if constant_pose_frames is None else "config",
-               camera_split=True, refine_focal_length=options.refine_focal_length,
-               refine_extra_params=options.refine_extra_params, sort_points=sort_points)
-    if masks.numel() <= HOST_COMPILE_MAX_GRID and dev.type == "cuda":
-        # SMALL problem (video windows, small scenes): the index structures are built on the host (compile_problem, round 6)
-        bad = None
-        if filter_negative_depth:                       # (the filter's arithmetic stays on the device: same expression as there)
-            e64, p64 = extrinsics.to(torch.float64), points3d.to(torch.float64)
-            z = torch.einsum("sj,pj->sp", e64[:, 2, :3], p64) + e64[:, 2, 3][:, None]
-            bad = (masks.bool() & ~(z >= torch.finfo(torch.float64).eps)).cpu()
-        H = lambda t: None if t is None else t.detach().cpu()
-        prob, valid_idx, deleted = compile_problem(H(points3d), H(extrinsics), H(intrinsics), H(tracks), H(masks), H(extra_params),
-                                                   shared_camera, camera_type, neg_depth_bad=bad,
-                                                   device_cus=torch.cuda.get_device_properties(dev).multi_processor_count, **ckw)
-        for name in ("cam_q", "cam_t", "intr", "pts", "row_ptr", "obs_cam", "obs_uv", "col_ptr", "cobs_pt", "cobs_uv", "chunk_desc",
-                     "entries", "tile_desc", "obs_slot", "cam_const", "cam_perm", "chol_first_blk"):
-            t = getattr(prob, name)
-            if t is not None:
-                setattr(prob, name, t.to(dev, non_blocking=True))
-        valid_idx, deleted = valid_idx.to(dev, non_blocking=True), deleted.to(dev, non_blocking=True)
-    else:
-        prob, valid_idx, deleted = compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_params,
-                                                   shared_camera, camera_type, **ckw)
+    prob, valid_idx, deleted = compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_params,
+                                               shared_camera, camera_type, filter_negative_depth=filter_negative_depth,
+                                               gauge="colmap" if constant_pose_frames is None else "config",
+                                               camera_split=True, refine_focal_length=options.refine_focal_length,
+                                               refine_extra_params=options.refine_extra_params, sort_points=sort_points)
     S = extrinsics.shape[0]
     inv_perm = None
     if prob.cam_perm is not None:

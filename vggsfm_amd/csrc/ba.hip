@@ -1930,174 +1930,10 @@ __global__ __launch_bounds__(256, VGG_OFFDIAG_OCC) void schur_tile_dma_kernel(Ws
       }
 }
 
-// Round 6, second formulation of the same measurement (vgg_ba_set_tile_dma 3 / 4): WAVE SPECIALISATION.  In schur_tile_dma_kernel
-// every wavefront still pays for six DMA instructions per batch between its matrix instructions (60-185 cycles of issue each).
-// Here a workgroup has FIVE wavefronts: four consumers that do nothing but [operand reads, matrix instructions, barrier], and
-// one PRODUCER that issues the whole LDS image of the next batch -- 18 KB = exactly 18 full 1 KB pieces, no partial ones; a
-// piece spans at most two segments, chosen per lane by a select -- waits for it, and meets the consumers at the batch's
-// barrier.  Mode 4: the producer also touches the lines of the batch after next (one dword per 128 bytes), so that its DMA
-// finds them in the L2.  Same LDS image, same operand reads, same sums.
-template <int MODE>
-__global__ __launch_bounds__(320, VGG_OFFDIAG_OCC) void schur_tile_pc_kernel(Ws w, const int32_t* __restrict__ chunk_desc,
-                                                                             const int32_t* __restrict__ entries, int chunk0, int zero_seg) {
-  constexpr int BD = 6, R = kGroup * BD, SEG = 3 * R, NT = R / 16, NH = (NT + 1) / 2, SWZ = 16;
-  constexpr int PIECES = 2 * 4 * SEG * 8 / 1024;       // 18
-  static_assert(2 * 4 * SEG * 8 == PIECES * 1024, "the image of a batch is a whole number of 1 KB pieces");
-  __shared__ __attribute__((aligned(16))) double ops[2 * 2 * 4 * SEG];
-  if (w.ctl->done) return;
-  const int chunk = chunk0 + blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int e0 = chunk_desc[6 * chunk + 2], e1 = chunk_desc[6 * chunk + 3];
-  const int cj = chunk_desc[6 * chunk + 4], cJ = chunk_desc[6 * chunk + 5];
-  constexpr int BPS = kSub / 4;
-  const int nsub = (e1 - e0 + kSub - 1) / kSub;
-  const int nb = ((nsub - cj + cJ - 1) / cJ) * BPS;
-  auto ebase = [&](int b) -> int { return e0 + ((b / BPS) * cJ + cj) * kSub + (b % BPS) * 4; };
-  const char* Yx = reinterpret_cast<const char*>(w.Yx);
-
-  if (wave == 4) {
-    // ---------------------------------------------------------------- producer
-    // slot = side * 4 + entry; the segment ids of a batch are eight scalar values, fetched one batch ahead
-    int seg_next[8];
-    auto load_segs = [&](int b, int (&sg)[8]) __attribute__((always_inline)) {
-      const int eb = ebase(b);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const bool valid = eb + e < e1;
-        const size_t row = 4 * (size_t)min(eb + e, e1 - 1);
-        const int sa = entries[row + 1], sb = entries[row + 2];
-        sg[e] = valid ? sa : zero_seg;
-        sg[4 + e] = valid ? sb : zero_seg;
-      }
-    };
-    auto issue = [&](const int (&sg)[8], int buf) __attribute__((always_inline)) {
-      char* dst = reinterpret_cast<char*>(ops + (size_t)buf * 2 * 4 * SEG);
-#pragma unroll
-      for (int p = 0; p < PIECES; ++p) {
-        // piece p = the 16-byte pieces 64 p .. 64 p + 63 of the image; 144 of them per segment
-        constexpr int PPS = SEG * 8 / 16;              // 144
-        const int slot_lo = (64 * p) / PPS;            // (compile-time after unrolling)
-        const int split = PPS * (slot_lo + 1) - 64 * p;   // first lane of the next segment (>= 64: none)
-        const bool hi = split < 64 && lane >= split;
-        const int slot_par_lo = slot_lo & 1, slot_par_hi = (slot_lo + 1) & 1;   // entry parity = slot parity (4 entries per side)
-        const int wloc = hi ? lane - split : 64 * p + lane - PPS * slot_lo;      // piece index inside its segment
-        const int par = hi ? slot_par_hi : slot_par_lo;
-        const int seg = hi ? sg[min(slot_lo + 1, 7)] : sg[slot_lo];
-        const char* src = Yx + (size_t)seg * (SEG * 8) + (size_t)((wloc ^ (par * (SWZ / 2))) * 16);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(dst + 1024 * p), 16, 0, 0);
-      }
-    };
-    auto touch = [&](const int (&sg)[8]) -> int {
-      int v = 0;
-      if constexpr (MODE == 4) {
-        // 8 segments x 18 lines of 128 bytes = 144 lines: lanes 0..17 of three statements cover slots (3 s .. 3 s + 2)?  Simpler:
-        // lane l of statement t touches line (64 t + l) of the 144
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-          const int line = 64 * t + lane;
-          const int slot = min(line / 18, 7), within = line - 18 * (line / 18);
-          int seg = sg[0];
-#pragma unroll
-          for (int q = 1; q < 8; ++q) seg = (slot == q) ? sg[q] : seg;
-          const char* src = Yx + (size_t)seg * (SEG * 8) + within * 128;
-          int tmp;
-          if (line < 144) { asm volatile("global_load_dword %0, %1, off" : "=v"(tmp) : "v"(src) : "memory"); v ^= tmp; }
-        }
-      }
-      return v;
-    };
-    int cur[8];
-    load_segs(0, cur);
-    issue(cur, 0);
-    load_segs(1, seg_next);
-    int tv = 0;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int b = 0; b < nb; ++b) {
-      const int buf = b & 1;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) cur[q] = seg_next[q];
-      load_segs(b + 2, seg_next);
-      issue(cur, buf ^ 1);                            // batch b + 1 (the zero segment past the end of the list)
-      if constexpr (MODE == 4) { tv = touch(seg_next); }
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(tv) : : "memory");
-      __syncthreads();
-    }
-    return;
-  }
-  // ------------------------------------------------------------------ consumers (the 2 x 2 grid of schur_tile_body)
-  f64x4_t acc[NH][NH];
-#pragma unroll
-  for (int i = 0; i < NH; ++i)
-#pragma unroll
-    for (int j = 0; j < NH; ++j) acc[i][j] = (f64x4_t){0.0, 0.0, 0.0, 0.0};
-  const int li = lane & 15, lk = lane >> 4;
-  const int kbase = lk * SEG, swz = (lk & 1) * SWZ;
-  auto load_quad_mask = [&](int eb) -> uint32_t { return (uint32_t)entries[4 * (size_t)min(eb, e1 - 1) + 3]; };
-  const int wr = wave >> 1, wc = wave & 1;
-  int rowoffA[NH], rowoffB[NH];
-  uint32_t bitsA[NH], bitsB[NH];
-#pragma unroll
-  for (int i = 0; i < NH; ++i) {
-    rowoffA[i] = kbase + ((16 * min(wr + 2 * i, NT - 1) + li) ^ swz);
-    rowoffB[i] = kbase + ((16 * min(wc + 2 * i, NT - 1) + li) ^ swz);
-    bitsA[i] = block_slot_bits<BD>(wr + 2 * i);
-    bitsB[i] = block_slot_bits<BD>(wc + 2 * i) << 16;
-  }
-  double a[2][NH], bq[2][NH];
-  auto fetch = [&](int set, int buf, int ks) __attribute__((always_inline)) {
-    const double* As = ops + (size_t)(buf * 2) * 4 * SEG;
-    const double* Bs = ops + (size_t)(buf * 2 + 1) * 4 * SEG;
-#pragma unroll
-    for (int i = 0; i < NH; ++i) { a[set][i] = As[rowoffA[i] + ks * R]; bq[set][i] = Bs[rowoffB[i] + ks * R]; }
-  };
-  auto pin = [&](int set) __attribute__((always_inline)) {
-    static_assert(NH == 3, "operand sets");
-    asm volatile("" : "+v"(a[set][0]), "+v"(a[set][1]), "+v"(a[set][2]), "+v"(bq[set][0]), "+v"(bq[set][1]), "+v"(bq[set][2]));
-  };
-  uint32_t on = 0u;
-  auto skip_bits = [&](uint32_t qm) -> uint32_t {
-    uint32_t colm = 0u, o = 0u;
-#pragma unroll
-    for (int j = 0; j < NH; ++j) colm |= ((qm & bitsB[j]) != 0 ? 1u : 0u) << j;
-#pragma unroll
-    for (int i = 0; i < NH; ++i) o |= ((qm & bitsA[i]) != 0 ? colm : 0u) << (NH * i);
-    return VGG_NO_SKIP ? 0xFFFFFFFFu : (uint32_t)__builtin_amdgcn_readfirstlane((int)o);
-  };
-  auto group = [&](int set) __attribute__((always_inline)) {
-    uint32_t m = on;
-    asm volatile("" : "+s"(m));
-#pragma unroll
-    for (int i = 0; i < NH; ++i)
-#pragma unroll
-      for (int j = 0; j < NH; ++j)
-        if (m & (1u << (NH * i + j))) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[set][i], bq[set][j], acc[i][j], 0, 0, 0);
-  };
-  uint32_t qmask = load_quad_mask(ebase(0)), qmask_next = load_quad_mask(ebase(1));
-  __syncthreads();                                  // (the producer's image of batch 0)
-  for (int b = 0; b < nb; ++b) {
-    const int buf = b & 1;
-    on = skip_bits(qmask);
-    fetch(0, buf, 0);
-    fetch(1, buf, 1); pin(0); group(0);
-    fetch(0, buf, 2); pin(1); group(1);
-    pin(0); group(0);
-    qmask = qmask_next; qmask_next = load_quad_mask(ebase(b + 2));
-    __syncthreads();
-  }
-  double* part = w.tile_part + (size_t)chunk * R * R;
-#pragma unroll
-  for (int i = 0; i < NH; ++i)
-#pragma unroll
-    for (int j = 0; j < NH; ++j)
-      if (wr + 2 * i < NT && wc + 2 * j < NT) {
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) part[(size_t)(16 * (wr + 2 * i) + lk + 4 * reg) * R + 16 * (wc + 2 * j) + li] = acc[i][j][reg];
-      }
-}
-
+// (Second formulation, commit a638f73, taken out again: WAVE SPECIALISATION -- five wavefronts per workgroup, four consumers that do
+//  nothing but [operand reads, matrix instructions, barrier] and one producer that issues the 18 one-KB DMA pieces of the next
+//  batch: sums bit-identical, 0.956 ms against 0.529 -- one producer cannot feed four consumers through two LDS buffers, and a
+//  third buffer does not fit three workgroups per CU.  profiles/r06_ab_tile_ldsdma_c3.jsonl.)
 // S[(cI,a,i),(cJ,b,j)] = - sum over the chunks of tile (gI,gJ) of the partial tiles (plain stores: every
 // element of S outside the per-camera diagonal terms belongs to exactly one (tile, element)).
 // grid = (R*R/256, num_tiles): one element per thread, chunks summed in order.
@@ -2727,9 +2563,7 @@ static void launch_schur_batch(const Launch& L, int batch, hipStream_t st, doubl
         expand_segments_kernel<<<div_up((L.num_segments + 1) * kGroup, 256), 256, 0, st>>>(L.w, L.num_segments);
       }
       ProfScope ps(kProfSchurTile, st);
-      if (L.w.tile_dma == 3) schur_tile_pc_kernel<3><<<cm - c0, 320, 0, st>>>(L.w, L.chunk_desc, L.entries, c0, L.num_segments);
-      else if (L.w.tile_dma == 4) schur_tile_pc_kernel<4><<<cm - c0, 320, 0, st>>>(L.w, L.chunk_desc, L.entries, c0, L.num_segments);
-      else if (L.w.tile_dma == 2) schur_tile_dma_kernel<2><<<cm - c0, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, c0, L.num_segments);
+      if (L.w.tile_dma == 2) schur_tile_dma_kernel<2><<<cm - c0, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, c0, L.num_segments);
       else schur_tile_dma_kernel<1><<<cm - c0, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, c0, L.num_segments);
     } else {
       ProfScope ps(kProfSchurTile, st);
@@ -3036,7 +2870,7 @@ int vgg_ba_set_tile_rhs(int enable) {
 }
 
 int vgg_ba_set_tile_dma(int mode) {
-  vgg::g_tuning.tile_dma = (mode >= 0 && mode <= 4) ? mode : 0;
+  vgg::g_tuning.tile_dma = (mode >= 0 && mode <= 2) ? mode : 0;
   return VGG_OK;
 }
 

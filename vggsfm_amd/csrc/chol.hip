@@ -1462,22 +1462,60 @@ __global__ __launch_bounds__(256, df_occupancy(CHAIN)) void chol_dataflow_kernel
   }
   if (nupd <= 0) load_a0();
   // left-looking updates: acc += L[r][k] L[c][k]^T  (merged: and accd += L[r][k] L[r][k]^T)
-  for (int t = 0; t < nupd; ++t) {
-    const int k = by_depth ? sh.order[t] : kstart + t;
-    const bool do_tile = k >= kfirst;
-    df_wait(&ready[(size_t)r * nbk + k], fail);
-    if (!diag && do_tile) df_wait(&ready[(size_t)c * nbk + k], fail);
-    const int k0 = DFB * k;
-    // stage the two operand tiles through LDS: coalesced row reads (one 512-byte row per wavefront instruction)
+  // -DVGG_DF_PREFETCH=1 (round 6, MEASURED, off): the operand tiles of update t + 1 requested BEFORE the matrix instructions of
+  // update t whenever their flags are already up (a relaxed look, no wait; every wavefront decides for itself -- it stages its own
+  // rows -- and waits alone where it has to), written to LDS behind them.  The idea: at n = 3200 a block column takes 18-21 us
+  // against the 14 us of the pivot chain, and a tile works through ~40 updates of 3.2 us (round trip + matrix instructions) with
+  // ~5 block columns resident ahead.  scripts/ubench/chol_bench, same box, two rounds: n = 3200 0.926 -> 0.913 ms, with the
+  // configs[3] camera split 0.826 -> 0.818, n = 1202 unchanged, n = 6002 dense 2.41 -> 2.63 (the extra loads in flight cost more
+  // than they hide there): the update queues are not what sets the step.  Same sums in the same order either way.
+#ifndef VGG_DF_PREFETCH
+#define VGG_DF_PREFETCH 0
+#endif
+  {
     double* bufA = sh.D;
     double* bufB = diag ? sh.D : sh.T;
-    {
-      double va[16], vb[16];
+    double va[16], vb[16];
+    auto upd_k = [&](int t) { return by_depth ? sh.order[t] : kstart + t; };
+    auto request = [&](int k) __attribute__((always_inline)) {
+      const int k0 = DFB * k;
+      const bool do_tile = k >= kfirst;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = (tid >> 6) + 4 * q, col = lane;
         va[q] = (row < vr) ? ld_agent(&A[(size_t)(r0 + row) * n + k0 + col]) : 0.0;
         if (!diag) vb[q] = (do_tile && row < vc) ? ld_agent(&A[(size_t)(c0 + row) * n + k0 + col]) : 0.0;
+      }
+    };
+    // are the operand tiles of update column k final?  (wave-uniform: lane 0 looks, everybody gets its answer)
+    auto flags_up = [&](int k) -> bool {
+      int up = 0;
+      if (lane == 0) {
+        up = __hip_atomic_load(&ready[(size_t)r * nbk + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 1;
+        if (up && !diag && k >= kfirst) up = __hip_atomic_load(&ready[(size_t)c * nbk + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 1;
+      }
+      return __builtin_amdgcn_readfirstlane(up) != 0;
+    };
+    // wait of ONE wavefront (lane 0 polls; bounded like df_wait_ge)
+    auto wave_wait = [&](const int32_t* flag) {
+      if (lane == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 1) {
+          __builtin_amdgcn_s_sleep(4);
+          ++spins;
+          const bool lost = fail && (spins & 1023) == 0 && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2;
+          if (spins > kSpinLimit || lost) { if (fail) __hip_atomic_store(fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+      }
+    };
+    bool have = false;                                   // this wavefront's registers hold the operands of the next update
+    for (int t = 0; t < nupd; ++t) {
+      const int k = upd_k(t);
+      const bool do_tile = k >= kfirst;
+      if (!have) {                                       // (not requested ahead: wait for the flags, this wavefront alone -- it
+        wave_wait(&ready[(size_t)r * nbk + k]);          //  stages its own rows, and the barrier behind the LDS writes is the one
+        if (!diag && do_tile) wave_wait(&ready[(size_t)c * nbk + k]);   // all four meet at)
+        request(k);
       }
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
@@ -1485,12 +1523,17 @@ __global__ __launch_bounds__(256, df_occupancy(CHAIN)) void chol_dataflow_kernel
         bufA[row * LD + col] = va[q];
         if (!diag) bufB[row * LD + col] = vb[q];
       }
+      __syncthreads();
+      have = false;
+      if (VGG_DF_PREFETCH && t + 1 < nupd) {
+        const int kn = upd_k(t + 1);
+        if (flags_up(kn)) { request(kn); have = true; }
+      }
+      if (t == nupd - 1) load_a0();                      // (in flight behind the matrix instructions below)
+      if (do_tile) multiply_staged(bufA, bufB, acc);
+      if (merged) multiply_staged(bufA, bufA, accd);
+      __syncthreads();                                   // operands consumed: the buffers may be refilled
     }
-    __syncthreads();
-    if (t == nupd - 1) load_a0();                        // (in flight behind the matrix instructions below)
-    if (do_tile) multiply_staged(bufA, bufB, acc);
-    if (merged) multiply_staged(bufA, bufA, accd);
-    __syncthreads();                                     // operands consumed: the buffers may be refilled
   }
 
   DF_STAMP(1);                                           // all updates applied

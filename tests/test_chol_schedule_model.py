@@ -2,9 +2,13 @@
 host: which workgroup waits for which flag and who raises it, for the role assignment of the CHAINED form (the workgroup of
 the sub-diagonal tile (c+1, c) also finishes the diagonal tile (c+1, c+1)) and for the plain one.  The kernel's claim is
 that a workgroup only ever waits for workgroups EARLIER in launch order (dispatch is in order, so the earliest unfinished
-workgroup is always resident and can run to completion).  Checked here for dense matrices, the camera split and k-way /
-banded envelopes: every awaited flag is raised by exactly one earlier workgroup, no flag is raised twice, and the
-depth order of the left-looking updates is a permutation that equals the ascending one when the matrix is dense.
+workgroup is always resident and can run to completion) -- with ONE exception since round 6: the merged workgroup of tile
+(r, r - 1) waits for `dready[r]`, raised by the diagonal tile's own workgroup (r, r), which applies that tile's earlier
+updates and sits a few positions LATER in the launch.  That workgroup itself waits only for earlier ones, and everything
+between the two in launch order can finish without it, so a bounded window of resident workgroups still drains: checked
+below by simulating in-order dispatch into windows of 2 .. 256 slots.  Checked for dense matrices, the camera split and
+k-way / banded envelopes: every awaited flag is raised by exactly one workgroup, earlier except for dready, no flag is raised
+twice, and the depth order of the left-looking updates is a permutation that equals the ascending one when the matrix is dense.
 (This is a model of the kernel's control flow, kept next to the envelope builders it is exercised with; the numerics are
 covered by tests/test_gpu_ba.py::test_cholesky_*.)"""
 import numpy as np
@@ -28,19 +32,20 @@ def first_of_factory(nbk, first_blk=None, split=(0, 0)):
     return first_of
 
 
-def depth_order(first_of, kstart, c):
+def depth_order(first_of, kstart, c, kend=None):
     depth = []
     for k in range(c):
         f = first_of(k)
         depth.append(1 + max([depth[j] for j in range(f, k)], default=0))
-    ks = list(range(kstart, c))
+    ks = list(range(kstart, c if kend is None else kend))
     return sorted(ks, key=lambda k: (depth[k], k))
 
 
 def tile_map(nbk, first_of, chain):
     """df_tile_map_kernel restated: the launch order used with a row envelope -- columns by dependency depth (the merged
-    workgroup of tile (c + 1, c) also takes the updates of row c + 1), then by index; tiles outside the envelope and the
-    diagonal tiles finished by a merged workgroup are left out.  -> list of (c, r)"""
+    workgroup of tile (c + 1, c) also takes the updates of row c + 1: kept from round 5, harmless), then by index; tiles
+    outside the envelope are left out (round 6: the diagonal tiles a merged workgroup finishes are IN -- their own workgroup
+    applies their earlier updates).  -> list of (c, r)"""
     def chained(x):
         return chain and 1 <= x < nbk and first_of(x) <= x - 1
     dep = []
@@ -50,7 +55,7 @@ def tile_map(nbk, first_of, chain):
             lo = min(lo, first_of(c + 1))
         dep.append(1 + max([dep[k] for k in range(lo, c)], default=0))
     cols = sorted(range(nbk), key=lambda c: (dep[c], c))
-    return [(c, r) for c in cols for r in range(c, nbk + 1) if first_of(r) <= c and not (r == c and chained(c))]
+    return [(c, r) for c in cols for r in range(c, nbk + 1) if first_of(r) <= c]
 
 
 def schedule(nbk, first_of, chain, order=None):
@@ -65,21 +70,26 @@ def schedule(nbk, first_of, chain, order=None):
             if c < first_of(r):
                 continue                                             # structurally zero tile
             diag = r == c
-            if diag and chained(c):
-                continue                                             # finished by the workgroup of tile (c, c - 1)
+            prep = diag and chained(c)                               # finished by the workgroup of tile (c, c - 1): early updates here
             merged = (not diag) and r == c + 1 and chained(r)
             kfirst = max(first_of(r), first_of(c))
-            kstart = first_of(r) if merged else kfirst
-            order = depth_order(first_of, kstart, c) if (chain and c - kstart >= 2) else list(range(kstart, c))
-            assert sorted(order) == list(range(kstart, c))
+            kstart, kend = kfirst, (c - 1 if prep else c)
+            n_upd = max(kend - kstart, 0)
+            order = depth_order(first_of, kstart, c, kend) if (chain and n_upd >= 2) else list(range(kstart, kend))
+            assert sorted(order) == list(range(kstart, kend))
             for k in order:
                 wg["waits"].append(("ready", r, k))
                 if not diag and k >= kfirst:
                     wg["waits"].append(("ready", c, k))
+            if prep:
+                wg["raises"].append(("dready", c))
+                continue
             if diag:
                 wg["raises"].append(("tready", c))
                 continue
             wg["waits"].append(("tready", c))
+            if merged:
+                wg["waits"].append(("dready", r))                    # (in front of the last slab: before anything is raised)
             wg["raises"].append(("ready", r, c))
             if merged:
                 wg["raises"].append(("tready", r))
@@ -96,10 +106,27 @@ def check(nbk, first_of, chain, order=None):
     for i, wg in enumerate(wgs):
         for f in wg["waits"]:
             assert f in raised_by, f"workgroup {wg['tile']} waits for {f}, which nobody raises"
-            assert raised_by[f] < i, f"workgroup {wg['tile']} (launch position {i}) waits for a later one ({raised_by[f]})"
+            if f[0] != "dready":
+                assert raised_by[f] < i, f"workgroup {wg['tile']} (launch position {i}) waits for a later one ({raised_by[f]})"
     # every block column that has tiles below its diagonal gets its T published
     for c in range(nbk):
         assert ("tready", c) in raised_by
+    # in-order dispatch into a bounded window of resident workgroups drains (the dready waits point FORWARD in the launch: one
+    # merged workgroup per pivot chain can sit waiting for a later one, so the window must hold the chains + one that works --
+    # 256 CUs against the handful of chains of a k-way camera order)
+    chains = sum(1 for c in range(nbk) if not (chain and c >= 1 and first_of(c) <= c - 1))
+    for window in (chains + 1, chains + 8, 256):
+        up, done, resident, nxt = set(), 0, [], 0
+        while done < len(wgs):
+            while len(resident) < window and nxt < len(wgs):
+                resident.append(nxt)
+                nxt += 1
+            ready = [i for i in resident if all(f in up for f in wgs[i]["waits"])]
+            assert ready, f"window {window}: resident workgroups {[wgs[i]['tile'] for i in resident]} all wait"
+            for i in ready:
+                up.update(wgs[i]["raises"])
+                resident.remove(i)
+                done += 1
     return wgs
 
 

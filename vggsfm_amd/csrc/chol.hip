@@ -1269,6 +1269,17 @@ __device__ __forceinline__ void factor64_blocked(double* D, double* Tl, double* 
 }
 
 constexpr int kDfOrderMax = 64;               // block columns up to which the chain and the update order below are used
+// Round 6: the diagonal tile's EARLIER updates off the merged workgroup.  The workgroup of tile (c+1, c) that finishes the diagonal
+// tile (c+1, c+1) used to carry that tile's whole update queue beside its own -- two 64 x 64 x 64 products per column, 6.2 us --
+// and a tile is dispatched only ~256 / (tiles per column) block columns ahead of the pivot column: at n = 3200 the queue of the
+// merged tile (c updates) is longer than its lead over the chain for c = 15 .. 35, and the block column there takes 16-28 us
+// instead of 14 (trace: scripts/ubench/chol_bench built -DVGG_CHOL_TRACE, n = 3200).  Now the diagonal tile's OWN workgroup --
+// which used to return at once -- applies the updates k <= c - 1 of tile (c+1, c+1), leaves the partial tile in place and raises
+// dready[c+1]; the merged workgroup adds only X X^T (k = c) and factors.  The sums are associated differently (the partial
+// tile first, X X^T last): results move in the last bits against round 5; a solve stays bit-reproducible.
+#ifndef VGG_DF_SPLIT_DIAG
+#define VGG_DF_SPLIT_DIAG 1
+#endif
 
 struct DfShared {
   double D[DFB * (DFB + 1)];
@@ -1336,14 +1347,17 @@ __global__ __launch_bounds__(256, df_occupancy(CHAIN)) void chol_dataflow_kernel
   const bool diag = (r == c);
   // the diagonal tile of column x is finished by the workgroup of tile (x, x - 1)
   auto chained = [&](int x) { return CHAIN && x >= 1 && x < nbk && first_of(x) <= x - 1; };
-  if (diag && chained(c)) return;
+  const bool prep = VGG_DF_SPLIT_DIAG && diag && chained(c);      // diagonal tile finished elsewhere: this workgroup applies its early updates
+  if (!VGG_DF_SPLIT_DIAG && diag && chained(c)) return;
   const bool merged = CHAIN && !diag && r == c + 1 && chained(r);
   // (two workgroups per CU: the ones on the pivot chain -- diagonal tiles and the merged first sub-diagonal ones -- go first)
   if (df_occupancy(CHAIN) > 1 && (diag || merged)) __builtin_amdgcn_s_setprio(3);
   const int kfirst = max(first_of(r), first_of(c));
-  const int kstart = merged ? first_of(r) : kfirst;     // (the diagonal tile (r,r) starts at the row's own envelope)
+  const int kstart = (merged && !VGG_DF_SPLIT_DIAG) ? first_of(r) : kfirst;     // (the diagonal tile (r,r) starts at the row's own envelope)
+  const int kend = prep ? c - 1 : c;                    // (a prepared diagonal tile leaves update k = c - 1 = X X^T to the merged workgroup)
   int32_t* ready = flags;
   int32_t* tready = flags + (size_t)(nbk + 1) * nbk;
+  int32_t* dready = tready + 2 * (size_t)nbk;           // [nbk] behind tready and xready: partial diagonal tile c is in place
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wy = wave >> 1, wx = wave & 1, li = lane & 15, lk = lane >> 4;
@@ -1399,7 +1413,10 @@ __global__ __launch_bounds__(256, df_occupancy(CHAIN)) void chol_dataflow_kernel
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const int i = 32 * wy + 16 * m + lk + 4 * reg, j = 32 * wx + 16 * q + li;
-          a0d[m][q][reg] = (merged && i < vr && j < vr && j <= i) ? A[(size_t)(r0 + i) * n + r0 + j] : 0.0;
+          if (VGG_DF_SPLIT_DIAG)                        // (written by the diagonal tile's workgroup during this launch)
+            a0d[m][q][reg] = (merged && i < vr && j < vr && j <= i) ? ld_agent(&A[(size_t)(r0 + i) * n + r0 + j]) : 0.0;
+          else
+            a0d[m][q][reg] = (merged && i < vr && j < vr && j <= i) ? A[(size_t)(r0 + i) * n + r0 + j] : 0.0;
         }
   };
 
@@ -1438,7 +1455,7 @@ __global__ __launch_bounds__(256, df_occupancy(CHAIN)) void chol_dataflow_kernel
   // (~3 us at 50 block columns, hidden behind its first wait); past kDfOrderMax block columns the launch is bound by the
   // number of resident workgroups and those microseconds would add up (c5, 94 block columns: +6 %), so the order stays
   // ascending there.
-  const int nupd = c - kstart;
+  const int nupd = max(kend - kstart, 0);
   const bool by_depth = CHAIN && nupd >= 2 && nbk <= kDfOrderMax;
   if (by_depth) {
     if (wave == 0) {
@@ -1454,7 +1471,7 @@ __global__ __launch_bounds__(256, df_occupancy(CHAIN)) void chol_dataflow_kernel
       for (int idx = lane; idx < nupd; idx += 64) {
         const int k = kstart + idx, dk = dep[k];
         int rank = 0;
-        for (int k2 = kstart; k2 < c; ++k2) { const int d2 = dep[k2]; rank += (d2 < dk) || (d2 == dk && k2 < k); }
+        for (int k2 = kstart; k2 < kend; ++k2) { const int d2 = dep[k2]; rank += (d2 < dk) || (d2 == dk && k2 < k); }
         sh.order[rank] = k;
       }
     }
@@ -1531,12 +1548,28 @@ __global__ __launch_bounds__(256, df_occupancy(CHAIN)) void chol_dataflow_kernel
       }
       if (t == nupd - 1) load_a0();                      // (in flight behind the matrix instructions below)
       if (do_tile) multiply_staged(bufA, bufB, acc);
-      if (merged) multiply_staged(bufA, bufA, accd);
+      if (merged && !VGG_DF_SPLIT_DIAG) multiply_staged(bufA, bufA, accd);
       __syncthreads();                                   // operands consumed: the buffers may be refilled
     }
   }
 
   DF_STAMP(1);                                           // all updates applied
+  if (prep) {
+    // partial diagonal tile (updates k <= c - 2) back in place, then the flag the merged workgroup of tile (c, c - 1) waits for
+    if (nupd > 0) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int i = 32 * wy + 16 * m + lk + 4 * reg, j = 32 * wx + 16 * q + li;
+            if (i < vr && j < vc && j <= i) st_agent(&A[(size_t)(r0 + i) * n + c0 + j], a0[m][q][reg] - acc[m][q][reg]);
+          }
+    }
+    df_publish(&dready[c]);
+    return;
+  }
   // tile value = A - sum: into LDS, row-major (the diagonal tile factors there; the others need it as an MFMA operand)
 #pragma unroll
   for (int m = 0; m < 2; ++m)
@@ -1607,7 +1640,10 @@ __global__ __launch_bounds__(256, df_occupancy(CHAIN)) void chol_dataflow_kernel
   const double* Tc = Tinv + (size_t)c * DFB * DFB;
 #pragma unroll
   for (int kb = 0; kb < 4; ++kb) {
-    if (kb == 3 && merged) load_a0d();                   // (the diagonal tile's own values: needed behind the last slab)
+    if (kb == 3 && merged) {                             // (the diagonal tile's values: needed behind the last slab)
+      if (VGG_DF_SPLIT_DIAG) df_wait(&dready[r], fail);    // (raised long ago: its last operand is a tile of column c - 1)
+      load_a0d();
+    }
     df_wait_ge(&tready[c], kb + 1, fail);
     if (kb == 3) DF_STAMP(2);                            // the last columns of T arrived
     const int ns = 4 * (kb + 1);
@@ -1774,7 +1810,7 @@ __global__ __launch_bounds__(256) void df_tile_map_kernel(const int32_t* __restr
   __syncthreads();
   for (int c = tid; c < nbk; c += 256) {
     int n = 0;
-    for (int r = c; r <= nbk; ++r) n += (fo[r] <= c) && !(r == c && chained(c));
+    for (int r = c; r <= nbk; ++r) n += (fo[r] <= c) && (VGG_DF_SPLIT_DIAG || !(r == c && chained(c)));
     cnt[c] = n;
   }
   __syncthreads();
@@ -1788,14 +1824,21 @@ __global__ __launch_bounds__(256) void df_tile_map_kernel(const int32_t* __restr
   for (int c = tid; c < nbk; c += 256) {
     int o = off[c];
     for (int r = c; r <= nbk; ++r)
-      if ((fo[r] <= c) && !(r == c && chained(c))) map[1 + o++] = c | (r << 16);
+      if ((fo[r] <= c) && (VGG_DF_SPLIT_DIAG || !(r == c && chained(c)))) map[1 + o++] = c | (r << 16);
   }
   if (tid == 0) { int tot = 0; for (int c = 0; c < nbk; ++c) tot += cnt[c]; map[0] = tot; }
 }
 
+// LDS request of the dataflow kernel: what it uses, or -- compiled for ONE workgroup per CU -- more than half a CU's 160 KB, so
+// that the hardware cannot place a second one beside a pivot chain whatever the register count of the day allows (round 6: the
+// plain form fits 256 registers since the tile values are loaded late, and two per CU measured slower on the product's systems)
+static size_t df_lds_bytes() {
+  const size_t need = sizeof(DfShared), half = 82 * 1024;
+  return (VGG_DF_OCC == 1 && need < half) ? half : need;
+}
 static size_t dataflow_flag_count(int n) {
   const int nbk = div_up(n, DFB);
-  return (size_t)(nbk + 1) * nbk + 2 * (size_t)nbk;        // ready[(nbk + 1) nbk], tready[nbk], xready[nbk]
+  return (size_t)(nbk + 1) * nbk + 3 * (size_t)nbk;        // ready[(nbk + 1) nbk], tready[nbk], xready[nbk], dready[nbk]
 }
 static size_t dataflow_tile_count(int n) {
   const size_t nbk = div_up(n, DFB);
@@ -1851,7 +1894,7 @@ static int enqueue_dataflow(double* A, double* b, int n, double* ws, int32_t* de
                               reinterpret_cast<const void*>(&chol_dataflow_kernel<false, true>),
                               reinterpret_cast<const void*>(&chol_dataflow_kernel<true, false>)};
     for (const void* k : kernels)
-      if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DfShared)) != hipSuccess) return VGG_ERR_HIP;
+      if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)df_lds_bytes()) != hipSuccess) return VGG_ERR_HIP;
     attr_set = true;
   }
   if (!(split_a >= DFB && split_b >= DFB && split_a % DFB == 0 && split_a + split_b <= n)) split_a = split_b = 0;
@@ -1868,9 +1911,9 @@ static int enqueue_dataflow(double* A, double* b, int n, double* ws, int32_t* de
     ov.S2 = overlap->S2; ov.flags = overlap->dev_flags; ov.first_col = overlap->first_col; ov.num_waits = overlap->num_waits;
     for (int k = 0; k < overlap->num_waits && k < 8; ++k) ov.wait_col[k] = overlap->wait_col[k];
   }
-  if (ov.S2) chol_dataflow_kernel<true, false><<<tiles, 256, sizeof(DfShared), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b, first_blk, ov, tile_map);
-  else if (chain) chol_dataflow_kernel<false, true><<<tiles, 256, sizeof(DfShared), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b, first_blk, ov, tile_map);
-  else chol_dataflow_kernel<false, false><<<tiles, 256, sizeof(DfShared), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b, first_blk, ov, tile_map);
+  if (ov.S2) chol_dataflow_kernel<true, false><<<tiles, 256, df_lds_bytes(), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b, first_blk, ov, tile_map);
+  else if (chain) chol_dataflow_kernel<false, true><<<tiles, 256, df_lds_bytes(), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b, first_blk, ov, tile_map);
+  else chol_dataflow_kernel<false, false><<<tiles, 256, df_lds_bytes(), st>>>(A, n, nbk, Tinv, flags, device_fail, skip, split_a, split_b, first_blk, ov, tile_map);
   int32_t* xready = flags + (size_t)(nbk + 1) * nbk + nbk;
   chol_backward_dataflow_kernel<<<nbk, 256, 0, st>>>(A, b, n, nbk, Tinv, xready, device_fail, skip, split_a, split_b, first_blk);
   if (hipGetLastError() != hipSuccess) return VGG_ERR_HIP;

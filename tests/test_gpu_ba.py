@@ -147,7 +147,7 @@ def test_cholesky_envelope_matches_lapack(n, band, arrow):
     # workspace) is the host model's, whose wait graph tests/test_chol_schedule_model.py checks
     from tests.test_chol_schedule_model import first_of_factory, tile_map
     words = ws.cpu().numpy().view(np.int32)
-    base = nbk * 64 * 64 * 2 + (nbk + 1) * nbk + 2 * nbk
+    base = nbk * 64 * 64 * 2 + (nbk + 1) * nbk + 3 * nbk               # T blocks | ready, tready, xready, dready | map
     chain = nbk <= 64                                                # (enqueue_dataflow: chained up to 64 block columns)
     want = tile_map(nbk, first_of_factory(nbk, first_blk), chain)
     assert int(words[base]) == len(want)

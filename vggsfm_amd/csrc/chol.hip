@@ -1232,6 +1232,9 @@ __device__ __forceinline__ void factor64_blocked(double* D, double* Tl, double* 
           ++t;
         }
     }
+    // (kb == 0: every global store this wavefront issued before the factorisation has left the CU -- free here, 2 us after
+    //  the last of them; the caller's `slab(0)` may then publish what they wrote: VGG_DF_LATE_XFLAG)
+    if (kb == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                 // L_kk, T_kk and every update of step kb - 1 are in LDS
     // panels: L[ib][kb] = D[ib][kb] T_kk (ib > kb), E[ib][kb] = E[ib][kb] T_kk (ib < kb): three products.
     // Wavefront 0 has the block under the diagonal, the one the next diagonal block waits for: it forms the product
@@ -1588,7 +1591,7 @@ __global__ __launch_bounds__(256, df_occupancy(CHAIN)) void chol_dataflow_kernel
   // (which nobody waits for: it only matters through T_b and as output)
   // T is handed on in four slabs of 16 columns, tready[bc] = number of slabs out: the tiles of the column multiply by the
   // first three while the factorisation is still running (columns 16 kb .. of T are final after step kb)
-  auto factor_and_publish = [&](int bc, int b0, int vb, int trace_tile) __attribute__((always_inline)) {
+  auto factor_and_publish = [&](int bc, int b0, int vb, int trace_tile, int32_t* late_flag) __attribute__((always_inline)) {
     (void)trace_tile;
     double* Tg = Tinv + (size_t)bc * DFB * DFB;
 #ifdef VGG_CHOL_PAIRS                              // A/B: the round-2 form, two 32 x 32 blocks, T in one piece
@@ -1600,6 +1603,8 @@ __global__ __launch_bounds__(256, df_occupancy(CHAIN)) void chol_dataflow_kernel
     }
 #else
     factor64_blocked(sh.D, sh.T, sh.scr, fail, [&](int kb) {
+      // (the flag of the merged workgroup's sub-diagonal tile: its stores were drained in front of the first barrier inside)
+      if (kb == 0 && late_flag && lane == 0) __hip_atomic_store(late_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // one wavefront: 64 rows x 16 columns (rows below the diagonal block are zero), its own drain, then the count
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
@@ -1628,7 +1633,7 @@ __global__ __launch_bounds__(256, df_occupancy(CHAIN)) void chol_dataflow_kernel
     // (ready[b][b] is never waited for: L_bb only matters through T_b)
   };
   if (diag) {
-    factor_and_publish(c, c0, vc, nat_tile);
+    factor_and_publish(c, c0, vc, nat_tile, nullptr);
     return;
   }
 
@@ -1702,15 +1707,20 @@ __global__ __launch_bounds__(256, df_occupancy(CHAIN)) void chol_dataflow_kernel
         if (i >= vr || j >= vr) v = (i == j) ? 1.0 : 0.0;
         sh.D[i * LD + j] = v;
       }
-  // (Round 4, measured and rejected: raising this flag from inside the factorisation, behind its first 16 x 16 step, where the
-  //  drain of the X stores is free -- 0.7 us off the factor path, but the flag is 2 us late for tile (r+1, r), whose last
-  //  update + first three slab products are a second chain of the same length per block column (T_c out -> tile (c+2,c) 3.2 us
-  //  -> last update of tile (c+2,c+1) 5.9 us -> its slabs 0..2 4.7 us = the 13.9 us of the factor path): n = 1202 0.273 ->
-  //  0.294 ms.  Either chain alone no longer sets the step.)
-  df_publish(&ready[(size_t)r * nbk + c]);               // (+ the barrier between the reads of X in sh.T and the factorisation)
+  // -DVGG_DF_LATE_XFLAG=1 (measured twice, off): the flag of tile (r, c) = X raised from INSIDE the factorisation, behind its
+  // first 16 x 16 step, where the drain of the X stores is free -- 0.7 us off the factor path, but the flag is ~2.4 us late for
+  // tile (r+1, r), whose wait for it + last update + first three slab products are a second chain per block column.  Round 4:
+  // 0.273 -> 0.294 ms at n = 1202.  Round 6, with that tile's workgroup relieved of the diagonal tile's update queue
+  // (VGG_DF_SPLIT_DIAG: its chain ~11.5 us against the 14.3 of the factor path): 0.260 -> 0.286 ms at n = 1202, 0.797 -> 0.868
+  // at n = 3200 -- the block column goes to 16 us: 11.5 + 2.4 + the slab it then waits for is past the factor path again.
+#ifndef VGG_DF_LATE_XFLAG
+#define VGG_DF_LATE_XFLAG 0
+#endif
+  if (VGG_DF_LATE_XFLAG) lds_barrier();                   // (the reads of X in sh.T are through; the diagonal tile's value is in sh.D)
+  else df_publish(&ready[(size_t)r * nbk + c]);
   DF_STAMP(3);
   DF_STAMP_AT(dtile, 1);                                 // diagonal tile r: updates applied
-  factor_and_publish(r, r0, vr, dtile);
+  factor_and_publish(r, r0, vr, dtile, VGG_DF_LATE_XFLAG ? &ready[(size_t)r * nbk + c] : nullptr);
 }
 
 // Backward substitution L^T x = z in dataflow form: one workgroup per 64-column block c (launched last block first, so

@@ -32,4 +32,4 @@ python scripts/run_c1_kitchen.py --stage run --out $OUT/${TAG}_c1_kitchen.json >
 bash $ROOT/scripts/prof/timeline.sh > $OUT/timeline.log 2>&1
 cp $ROOT/gpurun_out/timeline/timeline_summary.json $OUT/${TAG}_timeline_c3.json
 bash $ROOT/scripts/prof/pmc_sq_tri.sh > $OUT/pmc_sq_tri.log 2>&1
-cp $ROOT/gpurun_out/pmc/r05_pmc_sq_tri.json $OUT/${TAG}_pmc_sq_tri.json
+cp $(ls $ROOT/gpurun_out/pmc/*pmc_sq_tri.json | head -1) $OUT/${TAG}_pmc_sq_tri.json

@@ -193,6 +193,7 @@ def test_ba_camera_split_matches_unsplit(monkeypatch, shared, N, density_cut):
     ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=13)
     assert BA.find_camera_split(D(sc.mask))[0] is not None
     monkeypatch.setattr(BA, "SPARSE_GRID_DENSITY", density_cut)
+    monkeypatch.setattr(BA, "SMALL_GRID_CELLS", 0)
     opt = BundleAdjustmentOptions()
     opt.solver_options.max_num_iterations = 12
 

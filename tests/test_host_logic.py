@@ -16,6 +16,13 @@ from vggsfm_amd.scene import make_scene, perturb_for_ba
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.fixture(autouse=True)
+def _full_work_list(monkeypatch):
+    """The scenes of this file are small; the scheduling invariants they check are those of the FULL work-list construction
+    (density order, pattern grouping, cost model).  `test_simple_work_list_*` switches the small-problem path back on."""
+    monkeypatch.setattr(BA, "SIMPLE_WORKLIST_MAX_OBS", 0)
+
+
 def T(x):
     return None if x is None else torch.from_numpy(np.ascontiguousarray(x))
 
@@ -183,6 +190,7 @@ def _block_pattern(mask, bd=6, group=16):
 @pytest.mark.parametrize("S,N", [(5, 40), (40, 300), (70, 150)])
 def test_compile_problem_matches_oracle_construction(S, N, density_cut, monkeypatch):
     monkeypatch.setattr(BA, "SPARSE_GRID_DENSITY", density_cut)
+    monkeypatch.setattr(BA, "SMALL_GRID_CELLS", 0)            # (small grids skip the fill test: these scenes are small)
     sc = make_scene(S, N, "SIMPLE_RADIAL", shared_camera=True, seed=S)
     ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=S)
     masks = sc.mask.copy()
@@ -211,6 +219,7 @@ def test_compile_problem_sorted_points_is_the_same_problem_renumbered(S, N, dens
     flags per track, and per point the same (camera, pixel) list in camera order; per camera the same SET of (point, pixel)
     -- the order inside a camera is the list's, not ascending by point, and nothing needs it to be."""
     monkeypatch.setattr(BA, "SPARSE_GRID_DENSITY", density_cut)
+    monkeypatch.setattr(BA, "SMALL_GRID_CELLS", 0)            # (small grids skip the fill test: these scenes are small)
     sc = make_scene(S, N, "SIMPLE_RADIAL", shared_camera=True, seed=S)
     ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=S)
     masks = sc.mask.copy()
@@ -289,6 +298,7 @@ def test_compile_problem_on_irregular_visibility(S, N, density, seed, density_cu
     that see nothing, points seen by exactly two cameras of different groups, frame counts around the 16-camera group
     size, per-frame intrinsics."""
     monkeypatch.setattr(BA, "SPARSE_GRID_DENSITY", density_cut)
+    monkeypatch.setattr(BA, "SMALL_GRID_CELLS", 0)            # (small grids skip the fill test: these scenes are small)
     rng = np.random.default_rng(seed)
     sc = make_scene(S, N, "SIMPLE_RADIAL", shared_camera=False, seed=seed)
     ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=seed)
@@ -472,3 +482,25 @@ def test_environment_switches_are_inert_without_the_debug_gate(monkeypatch):
     sc = make_scene(20, 60, "SIMPLE_RADIAL", shared_camera=True, seed=3)
     ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=3)
     BA.compile_problem(T(pts0), T(ext0), T(K0), T(sc.tracks), T(sc.mask), T(extra0), True, "SIMPLE_RADIAL")
+
+
+@pytest.mark.parametrize("S,N,cam,shared", [(17, 900, "SIMPLE_RADIAL", True), (40, 300, "SIMPLE_PINHOLE", True), (70, 400, "SIMPLE_RADIAL", False)])
+def test_simple_work_list_covers_the_same_pairs(S, N, cam, shared, monkeypatch):
+    """Round 6: below SIMPLE_WORKLIST_MAX_OBS observations (video windows) build_schur_tiles skips the density order of the
+    tiles, the pattern grouping inside a tile and the cost model -- ~850 fewer operator calls per compile.  Same segments,
+    same entries per tile (every co-observing camera-group pair of every point exactly once), plain sweep order inside a
+    tile, one resident round."""
+    sc = make_scene(S, N, cam, shared_camera=shared, seed=S)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=S)
+    args = (T(pts0), T(ext0), T(K0), T(sc.tracks), T(sc.mask), T(extra0), shared, cam)
+    full, vf, _ = BA.compile_problem(*args)
+    monkeypatch.setattr(BA, "SIMPLE_WORKLIST_MAX_OBS", 10 ** 9)
+    monkeypatch.setattr(BA, "QUAD_SORT_WINDOW", 0)          # (what the checker reads: plain sweep order inside a tile)
+    simp, vs, _ = BA.compile_problem(*args)
+    vi, row_ptr, obs_cam, _, _ = OB.build_observations(pts0, ext0, sc.tracks, sc.mask)
+    _check_views_and_work_list(simp, S, vi, row_ptr, obs_cam)
+    assert simp.num_segments == full.num_segments and np.array_equal(simp.obs_slot.numpy(), full.obs_slot.numpy())
+    key = lambda p: sorted(map(tuple, p.entries.numpy()[:, :3].tolist()))
+    assert key(simp) == key(full)                           # the same (point, segment, segment) triples
+    tiles = lambda p: sorted((int(a), int(b)) for a, b in p.tile_desc.numpy()[:, :2])
+    assert tiles(simp) == tiles(full)

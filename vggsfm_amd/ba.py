@@ -229,7 +229,7 @@ def _entry_cost(qmask, diag, bd, group=GROUP):
 
 
 def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=None, num_batches=1, later_scale=1.0,
-                      merged_slots=None, block_rows=6):
+                      merged_slots=None, block_rows=6, simple=False, num_cams=None):
     """Block-sparse Schur work list (device, torch ops; structure is fixed for the whole solve).
 
     A *segment* is the run of one point's observations that falls into one group of `group`
@@ -256,7 +256,13 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     of the tile blocks (6, or 6 + refined intrinsics when they are per camera).
 
     `merged_slots`: the off-diagonal and the diagonal chunks will run in ONE launch (vgg_ba_problem.merged_tile_launch) with
-    that many resident workgroups in all; the split between the two kinds follows their entry counts."""
+    that many resident workgroups in all; the split between the two kinds follows their entry counts.
+
+    `simple` (round 6; compile_problem sets it below SIMPLE_WORKLIST_MAX_OBS observations -- video windows): the launch of a
+    small problem takes ~30 us whatever its schedule, while this function is ~400 torch launches and ~35 host reads; the simple
+    list keeps the (gI, gJ) tile order and the plain sweep order inside a tile, hands out workgroups by entry count and reads
+    the per-tile tables back in one copy each.  Same tiles, same entries per tile, same sums up to their order.
+    `num_cams`: the number of cameras (saves the two host reads that derive it from `obs_cam`)."""
     dev = obs_cam.device
     O = obs_cam.shape[0]
     P = row_ptr.shape[0] - 1
@@ -276,7 +282,8 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     seg_mask = torch.zeros(nseg, dtype=torch.long, device=dev).index_add_(0, seg_id, 1 << (obs_cam.long() % group))
     seg_pt = obs_pt[seg_begin]
     seg_grp = grp[seg_begin]
-    ngroups = int((obs_cam.max().item() // group) + 1)
+    ncam = int(num_cams) if num_cams is not None else int(obs_cam.max().item()) + 1
+    ngroups = (ncam - 1) // group + 1
     pseg_ptr = torch.zeros(P + 1, dtype=torch.long, device=dev)
     pseg_ptr[1:] = torch.cumsum(torch.bincount(seg_pt, minlength=P), 0)
     idx = torch.arange(nseg, device=dev)
@@ -290,7 +297,6 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     # sweep position of a point: all tiles walk the points in the order (first camera, last camera), so that the four
     # entries a workgroup packs along K (a "quad") have about the same presence pattern (the tile kernels skip the 16-row
     # blocks in which none of the four has a camera) and every tile still meets a given point at about the same time
-    ncam = int(obs_cam.max().item()) + 1
     has = counts > 0
     first_cam = torch.where(has, obs_cam.long()[row_ptr[:-1].long().clamp(max=O - 1)], torch.zeros_like(counts))
     last_cam = torch.where(has, obs_cam.long()[(row_ptr[1:].long() - 1).clamp(min=0)], torch.zeros_like(counts))
@@ -310,7 +316,7 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     emask = seg_mask[A] | (seg_mask[B] << 16)
     ukeys, kcounts = torch.unique_consecutive(key, return_counts=True)              # chunking unit = tile
     tile_start = torch.cumsum(kcounts, 0) - kcounts
-    order_mode = _hook("VGGSFM_TILE_ORDER", TILE_ORDER)
+    order_mode = "plain" if simple else _hook("VGGSFM_TILE_ORDER", TILE_ORDER)
     if order_mode not in TILE_ORDERS + TILE_ORDERS_EXPERIMENTAL:
         raise ValueError(f"tile order {order_mode!r}: expected one of {TILE_ORDERS + TILE_ORDERS_EXPERIMENTAL}")
     if order_mode != "plain" and nb == 1 and ukeys.shape[0] > 2:
@@ -364,8 +370,8 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
         A, B, key, epos, emask = A[inv], B[inv], key[inv], epos[inv], emask[inv]
         ukeys, kcounts = ukeys[perm_units], kc_p
         tile_start = torch.cumsum(kcounts, 0) - kcounts
-    quad_window = int(_hook("VGGSFM_QUAD_SORT_WINDOW", QUAD_SORT_WINDOW))
-    top_up = _hook("VGGSFM_TILE_TOP_UP", "1" if TILE_TOP_UP else "0") != "0"
+    quad_window = 0 if simple else int(_hook("VGGSFM_QUAD_SORT_WINDOW", QUAD_SORT_WINDOW))
+    top_up = (not simple) and _hook("VGGSFM_TILE_TOP_UP", "1" if TILE_TOP_UP else "0") != "0"
     if quad_window > 0:
         # Inside windows of QUAD_SORT_WINDOW consecutive entries of a tile, entries with the same pattern of 16-row blocks
         # (what the tile kernel can skip) are put next to each other: a quad's union is then the pattern of each of its four
@@ -395,18 +401,21 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     tbatch = ukeys // (2 * nn)
     is_diag = (ukeys % (2 * nn)) >= nn
     ukeys = ukeys % nn
-    # cost-weighted entry count of every tile (relative to the mean entry of its launch kind)
-    ecost = _entry_cost(qm[quad], is_diag[unit_of_entry], block_rows, group)
-    # (per-tile sums of a list that is sorted by tile: differences of a running sum -- index_add_ with 5 M double atomics
-    #  cost 2.4 ms of a 10 ms compile at configs[2])
-    csum = torch.cumsum(ecost, 0)
-    tend = tile_start + kcounts - 1
-    tcost = csum[tend] - torch.where(tile_start > 0, csum[(tile_start - 1).clamp(min=0)], torch.zeros_like(csum[tend]))
-    kweight = torch.ones_like(tcost)
-    for sel in (is_diag, ~is_diag):
-        if bool(sel.any()):
-            kweight[sel] = (tcost[sel] / kcounts[sel].double()) / (tcost[sel].sum() / kcounts[sel].sum().double())
-    kw = kcounts.double() * kweight
+    if simple:
+        kw = kcounts.double()                               # workgroups by entry count
+    else:
+        # cost-weighted entry count of every tile (relative to the mean entry of its launch kind)
+        ecost = _entry_cost(qm[quad], is_diag[unit_of_entry], block_rows, group)
+        # (per-tile sums of a list that is sorted by tile: differences of a running sum -- index_add_ with 5 M double atomics
+        #  cost 2.4 ms of a 10 ms compile at configs[2])
+        csum = torch.cumsum(ecost, 0)
+        tend = tile_start + kcounts - 1
+        tcost = csum[tend] - torch.where(tile_start > 0, csum[(tile_start - 1).clamp(min=0)], torch.zeros_like(csum[tend]))
+        kweight = torch.ones_like(tcost)
+        for sel in (is_diag, ~is_diag):
+            if bool(sel.any()):
+                kweight[sel] = (tcost[sel] / kcounts[sel].double()) / (tcost[sel].sum() / kcounts[sel].sum().double())
+        kw = kcounts.double() * kweight
     # (upper bound of a tile's workgroups: at least MIN_CHUNK entries each -- one sub-chunk at the very least)
     nsub_t = torch.clamp(torch.minimum((kcounts + SUB - 1) // SUB, (kcounts + MIN_CHUNK - 1) // MIN_CHUNK), min=1)
 
@@ -420,13 +429,14 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
             if merged_slots is not None:
                 # ONE launch for both kinds of tiles (small problems): its resident slots are shared in proportion to the
                 # staged bytes (two segments per off-diagonal entry, one per diagonal entry)
-                kc0, dg0 = kcounts.cpu(), is_diag.cpu()
+                kc0, dg0 = host_tables[0].long(), host_tables[1] != 0
                 e_off, e_diag = float(kc0[~dg0].sum()), float(kc0[dg0].sum())
                 n_off = int(round(merged_slots * 2.0 * e_off / max(2.0 * e_off + e_diag, 1.0)))
                 n_off = min(max(n_off, 1 if e_off else 0), merged_slots - (1 if e_diag else 0))
                 caps = (max(n_off, 1), max(merged_slots - n_off, 1))
             # (the search runs on host copies of the per-tile counts: one synchronisation instead of one per probe)
-            kc_h, diag_h, tb_h, kw_h, ns_h = kcounts.cpu(), is_diag.cpu(), tbatch.cpu(), kw.cpu(), nsub_t.cpu()
+            kc_h, diag_h, tb_h, ns_h = host_tables[0].long(), host_tables[1] != 0, host_tables[2].long(), host_tables[3].long()
+            kw_h = kw.cpu() if kw is not kw_first else host_tables[4]
             csize_h = torch.full_like(kc_h, chunk)
             topup_h = torch.zeros_like(kc_h)
             for b in range(nb):
@@ -461,13 +471,16 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
             nchunks = torch.where(topup_h.to(dev) > 0, topup_h.to(dev), nchunks)
         return nchunks
 
+    # (the per-tile tables the search reads: ONE copy to the host -- they are exact in float64)
+    kw_first = kw
+    host_tables = torch.stack([kcounts.double(), is_diag.double(), tbatch.double(), nsub_t.double(), kw]).cpu()
     nchunks = size_chunks(kw)
     # POSITION weight (round 5): the workgroups of a launch are all resident at once, three (four) to a CU, and the SIMDs
     # arbitrate oldest-first -- the workgroup that was dispatched LAST onto a CU gets the issue slots its elders leave.  Per-tile
     # phase trace at configs[2] (scripts/prof/tile_cost_fit.py): 4450 cycles per batch in the first third of the launch, 4800
     # in the second, 5180 in the third, for the same matrix instructions per batch.  So a tile's cost grows with the position
     # of its workgroups in the launch: second pass with kw (1 + TILE_POSITION_WEIGHT x position fraction within its launch).
-    pw = float(_hook("VGGSFM_TILE_POS_WEIGHT", TILE_POSITION_WEIGHT))
+    pw = 0.0 if simple else float(_hook("VGGSFM_TILE_POS_WEIGHT", TILE_POSITION_WEIGHT))
     if pw != 0.0 and max_chunks is not None and kcounts.shape[0] > 1:
         launch_key = tbatch * 2 + is_diag.long()                   # (units are sorted by batch, off-diagonal first)
         cum = torch.cumsum(nchunks, 0).double()
@@ -493,8 +506,8 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     obs_slot = (seg_id * group + obs_cam.long() % group).to(torch.int32)
     # host-side batch table (per tile)
     tbatch, is_diag, ukeys = tbatch[tfirst_unit], is_diag[tfirst_unit], ukeys[tfirst_unit]
-    tb, td, tn, tf = tbatch.cpu(), is_diag.cpu(), t_chunks.cpu(), t_cfirst.cpu()
-    tg = (ukeys // ngroups).cpu()
+    tt = torch.stack([tbatch, is_diag.long(), t_chunks, t_cfirst, ukeys // ngroups]).cpu()      # (one copy)
+    tb, td, tn, tf, tg = tt[0], tt[1] != 0, tt[2], tt[3], tt[4]
     batch_desc = torch.zeros((nb, 6), dtype=torch.int32)
     for b in range(nb):
         ids = torch.nonzero(tb == b).squeeze(1)
@@ -517,6 +530,8 @@ TILE_BACKFILL = None               # (off-diagonal, diagonal) workgroups per CU 
 TILE_WGS_PER_CU = (3, 4)           # resident schur_tile workgroups per CU with 6 x 6 blocks: (off-diagonal, diagonal) launch
 SPARSE_GRID_DENSITY = 0.05        # compile_problem: below this fill of the (frames x tracks) grid work on the observation list
 MERGED_TILE_MAX_OBS = 1_000_000   # below: off-diagonal and diagonal tiles share one launch
+SMALL_GRID_CELLS = 1 << 20        # compile_problem: (frames x tracks) cells up to which the grid path is taken without looking at its fill
+SIMPLE_WORKLIST_MAX_OBS = 100_000 # below: build_schur_tiles(simple=True) -- no density order, pattern grouping or cost model (video windows)
 CAMERA_SPLIT_MIN_STEPS = 2    # shared 64-column factorisation steps below which re-ordering the cameras is not worth it
 
 
@@ -678,7 +693,8 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
     # 4.7 M observations, 2 % -- is turned into the LIST of its observations first and everything works on that (a dozen
     # passes over the grid, the depth of every slot alone 2 GB, cost more than the solve they prepare: configs[4] 3.5 -> 3.2 s);
     # a well-filled grid (batch configs: 25 %) is cheaper to filter in place (c3: 5.6 ms against 8 ms for the list).
-    if float(masks.sum().item()) < SPARSE_GRID_DENSITY * masks.numel():
+    # (a small grid is filtered in place whatever its fill: no host read for the decision)
+    if masks.numel() > SMALL_GRID_CELLS and float(masks.sum().item()) < SPARSE_GRID_DENSITY * masks.numel():
         f0, n0 = torch.nonzero(masks, as_tuple=True)                   # input frame, input track; frame-major
         if cam_perm is not None:                        # (frames 0 and 1 -- the default gauge -- stay first: A is a prefix)
             ext, K = ext[cam_perm], K[cam_perm]
@@ -812,7 +828,7 @@ def compile_problem(points3d, extrinsics, intrinsics, tracks, masks, extra_param
         slots = (max(1, int(cus * backfill[0])), max(1, int(cus * backfill[1])))
     chunk_desc, entries, tile_desc, obs_slot, nseg, batch_desc = build_schur_tiles(
         row_ptr, obs_cam, max_chunks=slots, num_batches=nb, later_scale=(cus - CHOL_CUS) / cus,
-        merged_slots=merged_slots, block_rows=block_rows)
+        merged_slots=merged_slots, block_rows=block_rows, simple=int(obs_cam.shape[0]) < SIMPLE_WORKLIST_MAX_OBS, num_cams=S)
     prob = DeviceProblem(cam_q, cam_t, intr, pts, row_ptr, obs_cam, obs_uv, col_ptr, cobs_pt, cobs_uv, chunk_desc,
                          entries, tile_desc, obs_slot, nseg, MODEL_ID[camera_type], cam_const=cam_const,
                          batch_desc=batch_desc, chol_split=chol_split, cam_perm=cam_perm, merged_tile_launch=merged,

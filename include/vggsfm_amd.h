@@ -327,11 +327,14 @@ int vgg_fmat_residuals(const double* points1, const double* points2, const uint8
  * Jacobians; cam_workgroups / point_workgroups (0 = automatic) -- total workgroups of the camera / point passes.  Every
  * combination computes the same iteration up to the order of its sums. */
 int vgg_ba_tuning(int lanes_per_point, int long_tracks, int cam_workgroups, int point_workgroups);
-/* Where F^T (r - E h) and the shared-intrinsics border of the reduced system come from when the tile blocks are 6 x 6 (shared
- * or constant intrinsics): 1 (default; VGG_TILE_RHS in the environment seeds it) = from the diagonal Schur tile launch, whose
- * staged segments are multiplied by a 3 x 3 per-point block on the side, + per-point sums of the point pass -- no second
- * camera-major evaluation of the projections per iteration; 0 = the camera pass cam_pass<RHS> (always used with 7 x 7 / 8 x 8
- * blocks).  Both compute the same system up to the order of its sums.  Requires entries[e][0] = the entry's point. */
+/* Where F^T (r - E h) (and, with a shared camera, the intrinsics border of the reduced system) come from: 2 (default;
+ * VGG_TILE_RHS in the environment seeds it) = from the diagonal Schur tile launch for every block shape -- 6 x 6 blocks
+ * (shared or constant intrinsics, compressed factors): two wavefronts of a diagonal-tile workgroup multiply the staged segments
+ * by a 3 x 3 per-point block on the side, + per-point sums of the point pass; 7 x 7 / 8 x 8 blocks (per-camera intrinsics, full
+ * factors; round 6): every thread adds one tile row's products for two of a batch's entries -- no second camera-major evaluation
+ * of the projections per iteration; 1 = the tile launch for 6 x 6 blocks only, the camera pass cam_pass<RHS> for the others (the
+ * round-4/5 behaviour); 0 = the camera pass always.  All compute the same system up to the order of its sums.  Requires
+ * entries[e][0] = the entry's point. */
 int vgg_ba_set_tile_rhs(int enable);
 /* Where the back-substitution of the points (point_step_kernel) takes E^T F dy from, again with 6 x 6 tile blocks: 0 (default;
  * VGG_STEP_FACTORS seeds it) = a second evaluation of every projection and its Jacobians; 1 = from the compressed Schur

@@ -55,7 +55,7 @@ def main():
             os.environ.clear()
             os.environ.update(base_env)
             os.environ["VGGSFM_AMD_DEBUG_HOOKS"] = "1"       # (the product path reads the VGGSFM_* switches only behind this gate)
-            L.vgg_ba_set_tile_rhs(1)
+            L.vgg_ba_set_tile_rhs(2)
             L.vgg_ba_set_step_from_factors(0)
             L.vgg_ba_set_tile_dma(0)
             coll = None

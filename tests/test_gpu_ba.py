@@ -263,13 +263,49 @@ def test_ba_tile_rhs_matches_camera_pass(S, N, cam, shared, rf, rk):
         assert L.vgg_ba_set_tile_rhs(1) == 0
         a, b = solve(), solve()
     finally:
-        L.vgg_ba_set_tile_rhs(1)
+        L.vgg_ba_set_tile_rhs(2)
     for x, y in zip(a[:4], b[:4]):                       # bit-reproducible
         assert x is None or torch.equal(x, y)
     assert a[4]["num_iterations"] == ref[4]["num_iterations"]
     for ia, ib in zip(a[4]["iterations"], ref[4]["iterations"]):
         assert ia["successful"] == ib["successful"] and abs(ia["cost"] - ib["cost"]) <= 1e-10 * ib["cost"], (ia, ib)
         assert abs(ia["radius"] - ib["radius"]) <= 1e-5 * ib["radius"]      # (the radius update amplifies the step quality's last bits)
+    for x, y in zip(a[:4], ref[:4]):
+        if x is not None:
+            np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-8, atol=1e-8)
+
+
+@pytest.mark.parametrize("S,N,cam,rf,rk,merged", [(90, 2500, "SIMPLE_RADIAL", True, True, True), (90, 2500, "SIMPLE_RADIAL", True, True, False),
+                                                  (60, 3000, "SIMPLE_PINHOLE", True, False, False), (40, 2000, "SIMPLE_RADIAL", False, True, False),
+                                                  (200, 8000, "SIMPLE_RADIAL", True, True, False)])
+def test_ba_tile_rhs_with_per_camera_intrinsics_matches_camera_pass(S, N, cam, rf, rk, merged, monkeypatch):
+    """Round 6: with PER-CAMERA intrinsics (7 x 7 / 8 x 8 tile blocks, full Schur factors) the reduced right-hand side comes out
+    of the diagonal tile launch as well (vgg_ba_set_tile_rhs(2)): every thread adds the products of one tile row for two of a
+    batch's four entries once the batch is in LDS; cam_pass<RHS> is not launched.  Same system up to the order of its sums:
+    same LM trajectory as the camera pass, with both tile launches and with the merged one."""
+    if not merged:
+        monkeypatch.setattr(BA, "MERGED_TILE_MAX_OBS", 0)
+    sc = make_scene(S, N, cam, shared_camera=False, seed=59)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=59)
+    opt = BundleAdjustmentOptions()
+    opt.refine_focal_length, opt.refine_extra_params = rf, rk
+    opt.solver_options.max_num_iterations = 10
+    L = _lib.lib()
+
+    def solve():
+        return BA.bundle_adjustment(D(pts0), D(ext0), D(K0), D(sc.tracks), D(sc.mask), None, D(extra0), False, cam, opt)
+    try:
+        assert L.vgg_ba_set_tile_rhs(0) == 0
+        ref = solve()
+        assert L.vgg_ba_set_tile_rhs(2) == 0
+        a, b = solve(), solve()
+    finally:
+        L.vgg_ba_set_tile_rhs(2)
+    for x, y in zip(a[:4], b[:4]):                       # bit-reproducible
+        assert x is None or torch.equal(x, y)
+    assert a[4]["num_iterations"] == ref[4]["num_iterations"]
+    for ia, ib in zip(a[4]["iterations"], ref[4]["iterations"]):
+        assert ia["successful"] == ib["successful"] and abs(ia["cost"] - ib["cost"]) <= 1e-10 * ib["cost"], (ia, ib)
     for x, y in zip(a[:4], ref[:4]):
         if x is not None:
             np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-8, atol=1e-8)

@@ -164,7 +164,7 @@ static Dims make_dims(const vgg_ba_problem* pb) {
 struct Tuning { int lpp, longt, cam_wgs, point_wgs, tile_rhs, step_factors, tile_dma; };
 static Tuning g_tuning = [] {
   auto env = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
-  return Tuning{env("VGG_LPP", 0), env("VGG_PP_LONGT", -1), env("VGG_CAM_WGS", 0), env("VGG_POINT_WGS", 0), env("VGG_TILE_RHS", 1), env("VGG_STEP_FACTORS", 0), env("VGG_TILE_DMA", 0)};
+  return Tuning{env("VGG_LPP", 0), env("VGG_PP_LONGT", -1), env("VGG_CAM_WGS", 0), env("VGG_POINT_WGS", 0), env("VGG_TILE_RHS", 2), env("VGG_STEP_FACTORS", 0), env("VGG_TILE_DMA", 0)};
 }();
 
 static Ws carve(const Dims& d, int max_iters, int num_chunks, int num_segments, void* base) {
@@ -1206,6 +1206,14 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
   constexpr bool TR = CY && DIAG;
   constexpr bool INTERLEAVE = VGG_TILE_INTERLEAVE && !CY;
   const bool trhs = TR && w.tile_rhs != 0;
+  // tile_rhs with FULL factors (7 x 7 / 8 x 8 blocks: per-camera intrinsics, round 6).  All four wavefronts stage here, so
+  // there are no helpers: once a batch is in LDS, thread t adds the products of tile row t % R for two of the batch's four
+  // entries (t / R picks the pair) -- six LDS reads and six multiply-adds per batch beside 48 matrix instructions per wavefront.
+  // Only z is needed (column 0 of Z: without a shared camera the intrinsics border has no per-point terms), and the factors
+  // carry their Jacobi scales and constant-parameter masks: the sums go into the right-hand side as they are.  The 12
+  // doubles of a batch's four z come in through threads 0..11 with the staging's own two-stage prefetch.
+  constexpr bool TRF = !CY && DIAG;
+  const bool trf = TRF && w.tile_rhs != 0;
   constexpr int ZS = 12;                              // doubles per entry of the Z image (9 used; 16-byte aligned rows)
   double* zs = ops + 2 * (DIAG ? 1 : 2) * 4 * SEG;    // [buffer][entry][col][k]
   auto run = [&](auto role) __attribute__((always_inline)) {
@@ -1222,6 +1230,15 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
   // iteration earlier) is written to LDS -- twice the bytes in flight per workgroup for NV more double2 registers
   constexpr int DEPTH = (CY && !DIAG) ? 3 : 2;   // staging register sets = batches in flight ahead of the one being multiplied
   double2 sv[DEPTH][NV];
+  // (full-factor tile_rhs) thread tid < 12 carries component tid % 3 of z of entry tid / 3
+  const bool zt = TRF && trf && tid < 12;
+  const int zte = (tid < 12) ? tid / 3 : 0, ztc = tid % 3;
+  auto z_point = [&](int eb) -> int { return entries[4 * (size_t)min(eb + zte, e1 - 1)]; };
+  auto z_valid = [&](int eb) -> bool { return eb + zte < e1; };
+  double zv[DEPTH];
+  int zpt_next = 0;
+  bool zvalid_next = false;
+  double rfull = 0.0;
   // compressed staging: the lane's two LDS targets inside a staged segment (see write_lds)
   const bool cy_top = (l32 & 1) != 0;
   const int cy_sw = (se & 1) * SWZ, cy_r0 = 6 * (l32 >> 1);
@@ -1295,6 +1312,12 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
   for (int u = 0; u < DEPTH; ++u) issue_loads(sv[u], load_seg_index(ebase(u)), seg_valid(ebase(u)));
   int seg_next = load_seg_index(ebase(DEPTH));
   bool valid_next = seg_valid(ebase(DEPTH));
+  if constexpr (TRF) {
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) zv[u] = (zt && z_valid(ebase(u))) ? w.Zp[9 * (size_t)z_point(ebase(u)) + ztc] : 0.0;
+    if (zt) { zpt_next = z_point(ebase(DEPTH)); zvalid_next = z_valid(ebase(DEPTH)); }
+    if (zt) zs[(0 * 4 + zte) * ZS + ztc] = zv[0];
+  }
   uint32_t qmask = load_quad_mask(ebase(0)), qmask_next = load_quad_mask(ebase(1));
   write_lds(sv[0], 0);
   __syncthreads();
@@ -1307,7 +1330,7 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
 #else
 #define VGG_TT(var)
 #endif
-    auto step = [&](int b, int buf, double2 (&sv_load)[NV], const double2 (&sv_write)[NV]) __attribute__((always_inline)) {
+    auto step = [&](int b, int buf, double2 (&sv_load)[NV], const double2 (&sv_write)[NV], double& zv_load, const double& zv_write) __attribute__((always_inline)) {
 #if VGG_TILE_TRACE
       long long tr_last = __builtin_amdgcn_s_memtime();
 #endif
@@ -1318,6 +1341,14 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
       issue_loads(sv_load, seg_next, valid_next); // batch b+DEPTH (the zero segment past the end of the tile's list)
       seg_next = seg_after;
       valid_next = seg_valid(ebase(b + DEPTH + 1));
+      if constexpr (TRF) {
+        if (zt) {
+          const int zpt_after = z_point(ebase(b + DEPTH + 1));
+          zv_load = zvalid_next ? w.Zp[9 * (size_t)zpt_next + ztc] : 0.0;
+          zpt_next = zpt_after;
+          zvalid_next = z_valid(ebase(b + DEPTH + 1));
+        }
+      }
 #endif
       VGG_TT(tr_issue)
 #if VGG_ABLATE != 1
@@ -1334,8 +1365,21 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
       mfma_batch(buf, qmask, [&](const int k) __attribute__((always_inline)) {
 #if VGG_ABLATE != 5
         if constexpr (INTERLEAVE) write_lds_k(sv_write, buf ^ 1, k);
+        if constexpr (INTERLEAVE && TRF) { if (k == 0 && zt) zs[((buf ^ 1) * 4 + zte) * ZS + ztc] = zv_write; }
 #endif
       });
+      if constexpr (TRF) {
+        if (trf && tid < 2 * R) {
+          const int rrow = tid % R, half = tid / R;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int e = 2 * half + q;
+            const double* zz = zs + (buf * 4 + e) * ZS;
+            const double* op = ops + (size_t)(buf * 4 + e) * SEG + (rrow ^ ((e & 1) * SWZ));
+            rfull += op[0] * zz[0] + op[R] * zz[1] + op[2 * R] * zz[2];
+          }
+        }
+      }
       if constexpr (TR && HELPER) {
         if (trhs) {
           const int rrow = tid & 127;                 // (wavefront 2: tile rows 0..63, wavefront 3: 64..95)
@@ -1366,6 +1410,7 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
       qmask_next = load_quad_mask(ebase(b + 2));
 #if VGG_ABLATE != 5                               // (profiling build: 5 = no LDS writes)
       if constexpr (!INTERLEAVE) write_lds(sv_write, buf ^ 1);   // batch b+1, in flight for two steps
+      if constexpr (!INTERLEAVE && TRF) { if (zt) zs[((buf ^ 1) * 4 + zte) * ZS + ztc] = zv_write; }
 #endif
       VGG_TT(tr_write)
 #if VGG_ABLATE != 3
@@ -1378,11 +1423,11 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
     int b = 0;
     for (; b + TRIP - 1 < nb; b += TRIP) {
 #pragma unroll
-      for (int u = 0; u < TRIP; ++u) step(b + u, u & 1, sv[u % DEPTH], sv[(u + 1) % DEPTH]);
+      for (int u = 0; u < TRIP; ++u) step(b + u, u & 1, sv[u % DEPTH], sv[(u + 1) % DEPTH], zv[u % DEPTH], zv[(u + 1) % DEPTH]);
     }
 #pragma unroll
     for (int u = 0; u < TRIP - 1; ++u)
-      if (b + u < nb) step(b + u, u & 1, sv[u % DEPTH], sv[(u + 1) % DEPTH]);
+      if (b + u < nb) step(b + u, u & 1, sv[u % DEPTH], sv[(u + 1) % DEPTH], zv[u % DEPTH], zv[(u + 1) % DEPTH]);
 #if VGG_TILE_TRACE
     if (!DIAG && lane == 0 && blockIdx.x < 2048) {
       long long* t = g_tile_trace + ((size_t)blockIdx.x * 4 + wave) * 8;
@@ -1687,6 +1732,9 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
         }
       }
     }
+    if constexpr (TRF) {                              // full factors: [chunk][pair of entries][tile row], 288 doubles per chunk
+      if (trf && tid < 2 * R) w.rz_part[(size_t)chunk * (kGroup * 18) + tid] = rfull;
+    }
   }
   };   // run
   if constexpr (TR) {
@@ -1700,7 +1748,7 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
 template <int BD, bool DIAG>
 __global__ __launch_bounds__(256, (BD == 6 ? (DIAG ? VGG_DIAG_OCC : VGG_OFFDIAG_OCC) : 2)) void schur_tile_kernel(Ws w, const int32_t* __restrict__ chunk_desc,
                                                          const int32_t* __restrict__ entries, int chunk0, int zero_seg) {
-  __shared__ __attribute__((aligned(16))) double ops[2 * (DIAG ? 1 : 2) * 4 * kGroup * BD * 3 + ((DIAG && BD == 6) ? 96 : 0)];
+  __shared__ __attribute__((aligned(16))) double ops[2 * (DIAG ? 1 : 2) * 4 * kGroup * BD * 3 + (DIAG ? 96 : 0)];
   if (w.ctl->done) return;
   const int chunk = chunk0 + blockIdx.x;
   schur_tile_body<BD, DIAG>(w, chunk_desc, entries, chunk, zero_seg, ops);
@@ -1972,6 +2020,30 @@ __global__ __launch_bounds__(256) void tile_reduce_kernel(Ws w, int n_red, int C
       return;
     }
   }
+  if constexpr (BD != 6) {
+    // tile_rhs with full factors: the chunks' [pair of entries][tile row] right-hand-side sums of a diagonal tile, in chunk order
+    const int nb2 = (R * R + 255) / 256;
+    if ((int)blockIdx.x >= nb2) {
+      if (gI != gJ || !w.tile_rhs) return;
+      const int e = ((int)blockIdx.x - nb2) * 256 + threadIdx.x;
+      if (e >= 2 * R) return;
+      double s0 = 0.0, s1 = 0.0;
+      int ch = c0;
+      const double* src = w.rz_part + e;
+      constexpr size_t STR = kGroup * 18;
+      for (; ch + 7 < c1; ch += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(ch + u) * STR];
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) { s0 += v[u]; s1 += v[u + 1]; }
+      }
+      for (; ch + 1 < c1; ch += 2) { s0 += src[(size_t)ch * STR]; s1 += src[(size_t)(ch + 1) * STR]; }
+      if (ch < c1) s0 += src[(size_t)ch * STR];
+      w.rz[(size_t)gI * STR + e] = s0 + s1;
+      return;
+    }
+  }
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= R * R) return;
   const int row = e / R, col = e - row * R;
@@ -2016,6 +2088,7 @@ __global__ __launch_bounds__(64) void assemble_kernel(DevProblem pb, Ws w, const
                                                       int point_parts) {
   constexpr int BD = 6 + KD;
   __shared__ double rz[6][3];
+  __shared__ double rzf[BD];                       // tile_rhs with full factors (per-camera intrinsics): BD rows, scaled and masked
   if (w.ctl->done) return;
   const int global_terms = (w.ctl->rank == 0);
   const Dims& d = pb.d;
@@ -2026,7 +2099,16 @@ __global__ __launch_bounds__(64) void assemble_kernel(DevProblem pb, Ws w, const
     const double* U = w.U + (size_t)c * BD * BD;
     const double* T = w.T + (size_t)c * BD * tw;
     const int ia = 6 * d.C + (d.shared ? 0 : KD * c);
-    if (trhs) {
+    const bool full = trhs && !d.shared && KD > 0;     // full factors: rz carries scales and masks, one column, BD rows
+    if (full) {
+      if (tid < BD) {
+        const int g = c / kGroup;
+        const bool has_tile = pb.col_ptr[min((g + 1) * kGroup, d.C)] > pb.col_ptr[g * kGroup];
+        const size_t base = (size_t)g * kGroup * 18 + (size_t)(c % kGroup) * BD + tid;
+        rzf[tid] = has_tile ? w.rz[base] + w.rz[base + kGroup * BD] : 0.0;      // (the two entry pairs of a batch)
+      }
+      __syncthreads();
+    } else if (trhs) {
       // (a group without observations has no diagonal tile: nothing was summed for it)
       if (tid < 18) {
         const int i = tid / 3, col = tid - 3 * i;
@@ -2049,7 +2131,7 @@ __global__ __launch_bounds__(64) void assemble_kernel(DevProblem pb, Ws w, const
       const int ri = (i < 6) ? 6 * c + i : ia + (i - 6), cj = (j < 6) ? 6 * c + j : ia + (j - 6);
       if (cj > ri) continue;
       if (d.shared && i >= 6 && j >= 6) continue;           // intr-intr of the shared block: extra workgroup
-      if (trhs && !d.shared && (i >= 6 || j >= 6)) continue;   // (tile_rhs without shared intrinsics: none are refined)
+      if (trhs && !full && !d.shared && (i >= 6 || j >= 6)) continue;   // (compressed tile_rhs without shared intrinsics: none are refined)
       double v = 0.0;
       if (global_terms) {
         v = w.scale_c[ri] * w.scale_c[cj] * U[i * BD + j];
@@ -2058,8 +2140,16 @@ __global__ __launch_bounds__(64) void assemble_kernel(DevProblem pb, Ws w, const
       if (d.shared && i >= 6) v += w.scale_c[cj] * Tc(j, 1 + (i - 6));   // -F_pose^T E M
       w.S[(size_t)ri * n + cj] += v;
     }
-    if (tid < 6) w.rhs[6 * c + tid] += w.scale_c[6 * c + tid] * Tc(tid, 0);
-    if (!trhs && !d.shared && tid >= 6 && tid < BD) w.rhs[ia + tid - 6] += w.scale_c[ia + tid - 6] * T[tid * tw];
+    if (full) {
+      if (tid < BD) {
+        const int ri = (tid < 6) ? 6 * c + tid : ia + (tid - 6);
+        const double v = (global_terms ? w.scale_c[ri] * w.g[(size_t)c * BD + tid] : 0.0) - rzf[tid];
+        w.rhs[ri] += w.active[ri] ? v : 0.0;
+      }
+    } else {
+      if (tid < 6) w.rhs[6 * c + tid] += w.scale_c[6 * c + tid] * Tc(tid, 0);
+      if (!trhs && !d.shared && tid >= 6 && tid < BD) w.rhs[ia + tid - 6] += w.scale_c[ia + tid - 6] * T[tid * tw];
+    }
   } else {
     if (trhs) {                                    // (rides along: max of the point passes' per-workgroup gradient norms,
       double m = 0;                                //  what cam_reduce_kernel<KD, 1> did)
@@ -2575,7 +2665,7 @@ static void launch_schur_batch(const Launch& L, int batch, hipStream_t st, doubl
     schur_tile_kernel<BD, true><<<c1 - cm, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, cm, L.num_segments);
   }
   if (t1 > t0)
-    tile_reduce_kernel<BD><<<dim3(div_up(kGroup * BD * kGroup * BD, 256) + ((BD == 6 && L.w.tile_rhs) ? div_up(kGroup * BD * 3, 256) : 0),
+    tile_reduce_kernel<BD><<<dim3(div_up(kGroup * BD * kGroup * BD, 256) + (L.w.tile_rhs ? (BD == 6 ? div_up(kGroup * BD * 3, 256) : div_up(2 * kGroup * BD, 256)) : 0),
                                   t1 - t0), 256, 0, st>>>(L.w, L.d.n_red, L.d.C, L.d.kd, L.tile_desc, t0, dst);
 }
 
@@ -2800,7 +2890,10 @@ static int make_launch(const vgg_ba_problem* pb, const vgg_ba_options* opt, void
   L->tile_desc = pb->tile_desc; L->num_tiles = pb->num_tiles;
   // reduced right-hand side from the diagonal tile launch instead of cam_pass<RHS>: compressed 6 x 6 tile blocks (shared or
   // constant intrinsics), one tile batch (the overlap mode needs the right-hand side before its later batches have run)
-  L->w.tile_rhs = (g_tuning.tile_rhs && (L->d.shared || L->d.kd == 0) && pb->num_chunks > 0 && pb->num_tile_batches == 1) ? 1 : 0;
+  // (round 6: also with per-camera intrinsics -- 7 x 7 / 8 x 8 blocks, full factors; g_tuning.tile_rhs == 1 keeps those on the
+  //  camera pass, 2 = everywhere)
+  L->w.tile_rhs = (g_tuning.tile_rhs && (L->d.shared || L->d.kd == 0 || g_tuning.tile_rhs >= 2) && pb->num_chunks > 0 &&
+                   pb->num_tile_batches == 1) ? 1 : 0;
   L->w.step_from_factors = (L->d.shared || L->d.kd == 0) ? g_tuning.step_factors : 0;      // (compressed factors in the segment buffer)
   L->w.tile_dma = (L->w.Yx && !pb->merged_tile_launch && pb->num_tile_batches == 1) ? g_tuning.tile_dma : 0;
   L->cam_q = pb->cam_q; L->cam_t = pb->cam_t; L->intr = pb->intr; L->pts = pb->pts;
@@ -2865,7 +2958,7 @@ int vgg_ba_tuning(int lanes_per_point, int long_tracks, int cam_workgroups, int 
 }
 
 int vgg_ba_set_tile_rhs(int enable) {
-  vgg::g_tuning.tile_rhs = enable ? 1 : 0;
+  vgg::g_tuning.tile_rhs = (enable >= 0 && enable <= 2) ? enable : 1;
   return VGG_OK;
 }
 

@@ -48,6 +48,18 @@ constexpr int kGroup = 16;       // cameras per Schur tile side
 #ifndef VGG_TILE_INTERLEAVE
 #define VGG_TILE_INTERLEAVE 1   // full-factor tiles: LDS writes of the next batch between the K steps of the current one
 #endif
+#ifndef VGG_DIAG_FULL_DEPTH
+#define VGG_DIAG_FULL_DEPTH 2   // staging register sets of the full-factor diagonal tile launch
+#endif
+#ifndef VGG_OFF_FULL_DEPTH
+#define VGG_OFF_FULL_DEPTH 2    // ... of the full-factor off-diagonal one
+#endif
+#ifndef VGG_TRF_ABLATE
+#define VGG_TRF_ABLATE 0      // profiling builds, bits: 1 = no row products, 2 = no z loads, 4 = no store of the sums
+#endif
+#ifndef VGG_TRF_EARLY
+#define VGG_TRF_EARLY 2   // full-factor tile_rhs: row products behind K step VGG_TRF_EARLY - 1 of the batch (0: behind the batch)
+#endif
 #ifndef VGG_PP_OCC_SPLIT
 #define VGG_PP_OCC_SPLIT 3   // point_pass without the Y sweep: 158 VGPRs
 #endif
@@ -867,7 +879,7 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
       if (trhs && sl == 0) {
         double* Z = w.Zp + 9 * (size_t)p;
         Z[0] = z0; Z[1] = z1; Z[2] = z2;
-        if (!(KD > 0 && kdsh)) { Z[3] = 0; Z[4] = 0; Z[5] = 0; Z[6] = 0; Z[7] = 0; Z[8] = 0; }
+        if (KD == 0) { Z[3] = 0; Z[4] = 0; Z[5] = 0; Z[6] = 0; Z[7] = 0; Z[8] = 0; }   // (KD > 0, per-camera intrinsics: the full-factor tiles read z only)
         if (KD == 1 && kdsh) { Z[6] = 0; Z[7] = 0; Z[8] = 0; }
       }
       z_written = true;
@@ -1190,7 +1202,6 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
   constexpr int TPS = CY ? 32 : (DIAG ? 64 : 32); // threads per segment
   constexpr int NV = CY ? 3 : (V + TPS - 1) / TPS; // double2 per thread per batch
   const int sseg = tid / TPS, l32 = tid % TPS;
-  const bool stager = !(CY && DIAG) || sseg < 4;  // (wave-uniform)
   const int se = DIAG ? (sseg & 3) : (sseg >> 1), sside = DIAG ? 0 : (sseg & 1);
   // tile_rhs (compressed diagonal tiles): every observation sits in exactly one segment and every segment is exactly one
   // diagonal entry, so  sum over the entries of a diagonal tile of  Y_seg (96 x 3) Z_p (3 x 3)  is, per camera, what
@@ -1228,16 +1239,21 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
   auto seg_valid = [&](int eb) -> bool { return eb + se < e1; };
   // two staging register sets: the loads of batch b + 2 are issued while batch b is multiplied and batch b + 1 (loaded an
   // iteration earlier) is written to LDS -- twice the bytes in flight per workgroup for NV more double2 registers
-  constexpr int DEPTH = (CY && !DIAG) ? 3 : 2;   // staging register sets = batches in flight ahead of the one being multiplied
+  constexpr int DEPTH = (CY && !DIAG) ? 3 : ((!CY && DIAG) ? VGG_DIAG_FULL_DEPTH : ((!CY && !DIAG) ? VGG_OFF_FULL_DEPTH : 2));   // staging register sets = batches in flight ahead of the one being multiplied
   double2 sv[DEPTH][NV];
-  // (full-factor tile_rhs) thread tid < 12 carries component tid % 3 of z of entry tid / 3
-  const bool zt = TRF && trf && tid < 12;
-  const int zte = (tid < 12) ? tid / 3 : 0, ztc = tid % 3;
+  // (full-factor tile_rhs) lane l of EVERY wavefront requests component l & 3 of z of entry (l >> 2) & 3 (16 distinct addresses
+  //  per wavefront, four of them padding), unconditionally and without a validity select: an entry past the end of the list
+  //  multiplies the all-zero segment, so any finite z will do there (the clamped last entry's).  The first formulation had
+  //  the twelve lanes of wavefront 0 do it inside `if (tid < 12)`: the loop-carried point index then went through a copy at
+  //  the join of that divergent region, which the compiler guards with s_waitcnt vmcnt(0) right behind the load -- wavefront 0
+  //  waited for every load in flight, every batch (rocprofv3, one configs[3] shard: diagonal launch 293 -> 345 us from the z
+  //  loads alone).  Threads 0..15 (minus the padding lanes) write the image to LDS.
+  constexpr bool ZLOAD = TRF && !(VGG_TRF_ABLATE & 2);
+  const int zte = (lane >> 2) & 3, ztc = lane & 3;
+  const bool zt = ZLOAD && trf && tid < 16 && ztc < 3;
   auto z_point = [&](int eb) -> int { return entries[4 * (size_t)min(eb + zte, e1 - 1)]; };
-  auto z_valid = [&](int eb) -> bool { return eb + zte < e1; };
   double zv[DEPTH];
   int zpt_next = 0;
-  bool zvalid_next = false;
   double rfull = 0.0;
   // compressed staging: the lane's two LDS targets inside a staged segment (see write_lds)
   const bool cy_top = (l32 & 1) != 0;
@@ -1246,13 +1262,17 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
   auto issue_loads = [&](double2 (&sv)[NV], int seg_index, bool valid) __attribute__((always_inline)) {
     if constexpr (CY) {
       if constexpr (!HELPER) {
-        if (stager) {
-          const double2* src = reinterpret_cast<const double2*>(w.Y) + (size_t)(valid ? seg_index : zero_seg) * (CSEG / 2) + 3 * l32;
+        // (no `if (stager)` here, and no `if (zthread)` / validity select around the helpers' load below: a load inside a
+        //  conditional region is one the compiler cannot count on, so every s_waitcnt vmcnt(n) behind it is computed as if
+        //  it had not been issued -- the stagers' wait for the batch loaded a step earlier came out as vmcnt(1) with four
+        //  younger loads in flight, i.e. it waited for most of THIS step's loads, every step.  The non-helper loop only
+        //  runs on staging wavefronts; a helper lane >= 9 fetches a ninth Z component nobody reads; an entry past the end
+        //  of the list multiplies the all-zero segment, so the clamped entry's finite Z does no harm.)
+        const double2* src = reinterpret_cast<const double2*>(w.Y) + (size_t)(valid ? seg_index : zero_seg) * (CSEG / 2) + 3 * l32;
 #pragma unroll
-          for (int i = 0; i < NV; ++i) sv[i] = src[i];
-        }
+        for (int i = 0; i < NV; ++i) sv[i] = src[i];
       } else {
-        if (zthread) sv[0].x = valid ? w.Zp[9 * (size_t)seg_index + l32] : 0.0;   // (seg_index = the entry's point here)
+        sv[0].x = w.Zp[9 * (size_t)seg_index + min(l32, 8)];   // (seg_index = the entry's point here)
       }
     } else {
       const double2* src = reinterpret_cast<const double2*>(w.Y) + (size_t)(valid ? seg_index : zero_seg) * V;
@@ -1265,7 +1285,7 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
     if constexpr (CY && HELPER) {
       if (k == 0 && zthread) zs[(buf * 4 + se) * ZS + l32] = sv[0].x;
     } else if constexpr (CY) {
-      if (stager) {
+      {
         // odd lane:  mine = (N20 N21 N22, 2a0 2a1 2a2), other = (N00 N01 N02, N10 N11 N12) -> rows 0..2 = (2 a) x N[:, k]:
         //            16 bytes at row 0, 8 at row 2
         // even lane: mine = (N00 N01 N02, N10 N11 N12), other = (N20 N21 N22, ...)         -> rows 3..5 = N[:, k]:
@@ -1312,10 +1332,10 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
   for (int u = 0; u < DEPTH; ++u) issue_loads(sv[u], load_seg_index(ebase(u)), seg_valid(ebase(u)));
   int seg_next = load_seg_index(ebase(DEPTH));
   bool valid_next = seg_valid(ebase(DEPTH));
-  if constexpr (TRF) {
+  if constexpr (ZLOAD) {
 #pragma unroll
-    for (int u = 0; u < DEPTH; ++u) zv[u] = (zt && z_valid(ebase(u))) ? w.Zp[9 * (size_t)z_point(ebase(u)) + ztc] : 0.0;
-    if (zt) { zpt_next = z_point(ebase(DEPTH)); zvalid_next = z_valid(ebase(DEPTH)); }
+    for (int u = 0; u < DEPTH; ++u) zv[u] = w.Zp[9 * (size_t)z_point(ebase(u)) + ztc];
+    zpt_next = z_point(ebase(DEPTH));
     if (zt) zs[(0 * 4 + zte) * ZS + ztc] = zv[0];
   }
   uint32_t qmask = load_quad_mask(ebase(0)), qmask_next = load_quad_mask(ebase(1));
@@ -1338,17 +1358,15 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
       // (the index of batch b+DEPTH+1 is requested BEFORE the data of batch b+DEPTH: waiting for it next time round then
       //  leaves the younger data loads in flight -- vmcnt(3), not vmcnt(0))
       const int seg_after = load_seg_index(ebase(b + DEPTH + 1));
+      // (full-factor tile_rhs: the point index and the z are requested IN FRONT of the segment data, like the segment index)
+      if constexpr (ZLOAD) {
+        const int zpt_after = z_point(ebase(b + DEPTH + 1));
+        zv_load = w.Zp[9 * (size_t)zpt_next + ztc];
+        zpt_next = zpt_after;
+      }
       issue_loads(sv_load, seg_next, valid_next); // batch b+DEPTH (the zero segment past the end of the tile's list)
       seg_next = seg_after;
       valid_next = seg_valid(ebase(b + DEPTH + 1));
-      if constexpr (TRF) {
-        if (zt) {
-          const int zpt_after = z_point(ebase(b + DEPTH + 1));
-          zv_load = zvalid_next ? w.Zp[9 * (size_t)zpt_next + ztc] : 0.0;
-          zpt_next = zpt_after;
-          zvalid_next = z_valid(ebase(b + DEPTH + 1));
-        }
-      }
 #endif
       VGG_TT(tr_issue)
 #if VGG_ABLATE != 1
@@ -1357,6 +1375,18 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
 #elif VGG_TILE_PRIO == 2                          // experiment: staging phases at raised wave priority
       __builtin_amdgcn_s_setprio(0);
 #endif
+      auto rhs_rows = [&](int buf) __attribute__((always_inline)) {
+        if (trf && tid < 2 * R && !(VGG_TRF_ABLATE & 1)) {
+          const int rrow = tid % R, half = tid / R;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int e = 2 * half + q;
+            const double* zz = zs + (buf * 4 + e) * ZS;
+            const double* op = ops + (size_t)(buf * 4 + e) * SEG + (rrow ^ ((e & 1) * SWZ));
+            rfull += op[0] * zz[0] + op[R] * zz[1] + op[2 * R] * zz[2];
+          }
+        }
+      };
       // INTERLEAVE (full factors, 7 x 7 / 8 x 8 blocks): the LDS image of batch b + 1 is written in three pieces BETWEEN
       // the K steps of batch b instead of in a phase of its own behind the last matrix instruction -- the ds_writes issue
       // while the matrix pipe works.  Same-box A/B (round 4): configs[3] whole, off-diagonal launch 13.66 -> 13.18 ms,
@@ -1367,19 +1397,11 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
         if constexpr (INTERLEAVE) write_lds_k(sv_write, buf ^ 1, k);
         if constexpr (INTERLEAVE && TRF) { if (k == 0 && zt) zs[((buf ^ 1) * 4 + zte) * ZS + ztc] = zv_write; }
 #endif
+        // (full-factor tile_rhs: the row's products are read and added BETWEEN K steps 1 and 2, under the matrix instructions
+        //  of the batch -- behind the last one they were a tail of twelve exposed LDS reads per wavefront in front of the barrier)
+        if constexpr (TRF && VGG_TRF_EARLY) { if (k == VGG_TRF_EARLY - 1) rhs_rows(buf); }
       });
-      if constexpr (TRF) {
-        if (trf && tid < 2 * R) {
-          const int rrow = tid % R, half = tid / R;
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            const int e = 2 * half + q;
-            const double* zz = zs + (buf * 4 + e) * ZS;
-            const double* op = ops + (size_t)(buf * 4 + e) * SEG + (rrow ^ ((e & 1) * SWZ));
-            rfull += op[0] * zz[0] + op[R] * zz[1] + op[2 * R] * zz[2];
-          }
-        }
-      }
+      if constexpr (TRF && !VGG_TRF_EARLY) rhs_rows(buf);
       if constexpr (TR && HELPER) {
         if (trhs) {
           const int rrow = tid & 127;                 // (wavefront 2: tile rows 0..63, wavefront 3: 64..95)
@@ -1733,7 +1755,7 @@ __device__ __forceinline__ void schur_tile_body(const Ws& w, const int32_t* __re
       }
     }
     if constexpr (TRF) {                              // full factors: [chunk][pair of entries][tile row], 288 doubles per chunk
-      if (trf && tid < 2 * R) w.rz_part[(size_t)chunk * (kGroup * 18) + tid] = rfull;
+      if (trf && tid < 2 * R && !(VGG_TRF_ABLATE & 4)) w.rz_part[(size_t)chunk * (kGroup * 18) + tid] = rfull;
     }
   }
   };   // run

@@ -387,6 +387,25 @@ __global__ void init_kernel(DevProblem pb, Ws w, vgg_ba_options opt, int rank, i
   }
 }
 
+// Zeroes the part of the reduced system S | rhs that anything reads: only the lower triangle is ever filled (tile_reduce_kernel
+// and assemble_kernel write S[hi][lo], the factorisation and pack_lower_kernel read it), so row i is cleared up to the end of
+// the 64-column block of its diagonal element and the upper triangle is left alone -- half the stores of a full clear (at the
+// 6002 x 6002 system of the final joint adjustment of configs[4]: 144 of 288 MB per iteration).  Workgroup `wg` of `nwg` takes
+// the rows wg, wg + nwg, ...; row n is the right-hand side.
+__device__ __forceinline__ void zero_system_lower(const Ws& w, int n, int wg, int nwg) {
+  const bool even = (n & 1) == 0;                 // (rows 16-byte aligned)
+  for (int row = wg; row <= n; row += nwg) {
+    const int len = (row < n) ? min(n, 64 * (row / 64 + 1)) : n;
+    double* dst = w.sys + (size_t)row * n;
+    if (even) {
+      double2* d2 = reinterpret_cast<double2*>(dst);
+      for (int c = threadIdx.x; c < (len + 1) / 2; c += 256) d2[c] = make_double2(0.0, 0.0);
+    } else {
+      for (int c = threadIdx.x; c < len; c += 256) dst[c] = 0.0;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // camera-major pass.  MODE 0: linearisation terms U_c, g_c, cost.  MODE 1: T_c = F^T [r - E hs | -E Ms].
 template <int KD, int MODE>
@@ -401,10 +420,7 @@ __global__ __launch_bounds__(256, (MODE == 1) ? VGG_CP_OCC_RHS : VGG_CP_OCC) voi
   if (MODE == 1) {
     // Zero the reduced system S | rhs for the tile sums and assemble_kernel that follow (nothing touches it in between, and
     // the previous iteration is done with it): a few 16-byte stores per thread here instead of a fill launch
-    const size_t me = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x, nth = (size_t)gridDim.x * gridDim.y * 256;
-    double2* z = reinterpret_cast<double2*>(w.sys);
-    for (size_t i = me; i < w.sys_count / 2; i += nth) z[i] = make_double2(0.0, 0.0);
-    if (me == 0 && (w.sys_count & 1)) w.sys[w.sys_count - 1] = 0.0;
+    zero_system_lower(w, pb.d.n_red, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
   }
   const Dims& d = pb.d;
   // grid (C, split): a camera's observations are cut into `split` contiguous slices, one workgroup each (one
@@ -679,10 +695,7 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
   if (trhs) {
     // (cam_pass<RHS> is not launched: its other job -- zeroing the reduced system S | rhs for the tile sums and
     //  assemble_kernel that follow -- is done here, a few 16-byte stores per thread)
-    const size_t me = (size_t)blockIdx.x * 256 + threadIdx.x, nth = (size_t)gridDim.x * 256;
-    double2* z = reinterpret_cast<double2*>(w.sys);
-    for (size_t i = me; i < w.sys_count / 2; i += nth) z[i] = make_double2(0.0, 0.0);
-    if (me == 0 && (w.sys_count & 1)) w.sys[w.sys_count - 1] = 0.0;
+    zero_system_lower(w, pb.d.n_red, (int)blockIdx.x, (int)gridDim.x);
   }
   // shared-intrinsics terms of the reduced system that cam_pass<RHS> summed per observation (tile_rhs): they are per-POINT
   // quantities -- sum_i Ji^T E_i hs_p = Wa_p hs_p, sum_i Ji^T E_i Ms_p = Wa_p Ms_p -- added up here, one lane per point

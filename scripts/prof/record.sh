@@ -24,6 +24,12 @@ cd /tmp && rm -rf /tmp/prof_c4
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c4 -o c4 -- python $ROOT/bench.py --workload c4full --no-cpu-baseline --no-strong-leg --no-pipeline --no-triangulation --steps 10 --warmup 3 > /dev/null 2>&1
 cp $(find /tmp/prof_c4 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_c4full_kernel_stats.csv
 cd $ROOT
+#   <tag>_bench_c4shard.json (+ _kernel_stats.csv)  one 8-GPU shard of configs[3] (37 500 of the 300 000 tracks): the T_shard of DESIGN.md section 8
+python bench.py --workload c4shard --no-cpu-baseline --no-strong-leg --no-pipeline --no-triangulation --steps 20 --warmup 5 > $OUT/${TAG}_bench_c4shard.json 2> $OUT/bench_c4shard.err
+cd /tmp && rm -rf /tmp/prof_c4s
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c4s -o c4s -- python $ROOT/bench.py --workload c4shard --no-cpu-baseline --no-strong-leg --no-pipeline --no-triangulation --steps 10 --warmup 3 > /dev/null 2>&1
+cp $(find /tmp/prof_c4s -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_c4shard_kernel_stats.csv
+cd $ROOT
 python scripts/prof/compile_profile.py > $OUT/compile_profile.txt 2>&1
 python scripts/run_c5_video.py --out $OUT/${TAG}_c5_video.json > $OUT/c5.log 2>&1
 python scripts/run_c1_kitchen.py --stage run --out $OUT/${TAG}_c1_kitchen.json > $OUT/c1.log 2>&1

@@ -449,11 +449,11 @@ __global__ __launch_bounds__(256, (MODE == 1) ? VGG_CP_OCC_RHS : VGG_CP_OCC) voi
   // (Without it the pass ran 5x off its instruction-issue bound at 3-4 wavefronts per SIMD; one stage less: 52 % of the
   // wave cycles still waiting.)
   constexpr int KM = (KD > 0) ? KD : 1;
-  struct Gathered { double X[3], h[3], M[3 * KM]; float2 uv; bool c; };
+  struct Gathered { double X[3], h[3], M[3 * KM]; float2 uv; int c; };   // (c: the constant-point flag as loaded, tested where it is used)
   auto gather = [&](Gathered& g, int p, float2 uv) __attribute__((always_inline)) {
     g.uv = uv;
     g.X[0] = pb.pts[3 * p]; g.X[1] = pb.pts[3 * p + 1]; g.X[2] = pb.pts[3 * p + 2];
-    g.c = pb.pt_const ? pb.pt_const[p] != 0 : false;
+    g.c = pb.pt_const ? (int)pb.pt_const[p] : 0;
     if (MODE == 1) {
       g.h[0] = w.hs[3 * p]; g.h[1] = w.hs[3 * p + 1]; g.h[2] = w.hs[3 * p + 2];
 #pragma unroll
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256, (MODE == 1) ? VGG_CP_OCC_RHS : VGG_CP_OCC) voi
     const Gathered cur = g1;
     const float2 uv = cur.uv;
     const double X[3] = {cur.X[0], cur.X[1], cur.X[2]};
-    const bool pt_c = cur.c;
+    const bool pt_c = cur.c != 0;
     const double h0 = cur.h[0], h1v = cur.h[1], h2 = cur.h[2];
     double Mc[3 * KM];
 #pragma unroll
@@ -739,22 +739,23 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
   int n_o0 = 0, n_o1 = 0;
   ObsPf<NPF> n_pf;
   double n_X0 = 0, n_X1 = 0, n_X2 = 0;
-  bool n_ptc = false;
+  int n_ptc = 0;                                // (constant-point flag as loaded: tested where it is used -- a test right
+                                                //  behind the load is a wait for it, and for every load issued before it)
   // (two stages: the row bounds / coordinates are loaded TWO points ahead, the observations ONE point ahead, so
   //  that the observation loads never wait for the row-bound load they depend on)
   int m_o0 = 0, m_o1 = 0;
   double m_X0 = 0, m_X1 = 0, m_X2 = 0;
-  bool m_ptc = false;
+  int m_ptc = 0;
   if (p < d.P) {
     n_o0 = pb.row_ptr[p]; n_o1 = pb.row_ptr[p + 1];
     n_X0 = pb.pts[3 * p]; n_X1 = pb.pts[3 * p + 1]; n_X2 = pb.pts[3 * p + 2];
-    n_ptc = pb.pt_const ? pb.pt_const[p] != 0 : false;
+    n_ptc = pb.pt_const ? (int)pb.pt_const[p] : 0;
     n_pf.template load<true>(pb.obs_cam, pb.obs_uv, pb.obs_slot, n_o0, n_o1, LPP, sl);
     if (p + nw < d.P) {
       const int pm = p + nw;
       m_o0 = pb.row_ptr[pm]; m_o1 = pb.row_ptr[pm + 1];
       m_X0 = pb.pts[3 * pm]; m_X1 = pb.pts[3 * pm + 1]; m_X2 = pb.pts[3 * pm + 2];
-      m_ptc = pb.pt_const ? pb.pt_const[pm] != 0 : false;
+      m_ptc = pb.pt_const ? (int)pb.pt_const[pm] : 0;
     }
   }
   // (compressed factors: the loop is WAVE-uniform -- the record flush below needs all 64 lanes; a lane group whose point index
@@ -763,7 +764,7 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
     const bool pvalid = p < d.P;
     const int o0 = pvalid ? n_o0 : 0, o1 = pvalid ? n_o1 : 0;
     const double X[3] = {n_X0, n_X1, n_X2};
-    const bool pt_c = n_ptc;
+    const bool pt_c = n_ptc != 0;
     const ObsPf<NPF> f_pf = n_pf;
     {
       // stage 1 -> current of the next iteration: observations of point p + nw (its bounds arrived an iteration ago)
@@ -774,7 +775,7 @@ __global__ __launch_bounds__(256, VGG_PP_OCC) void point_pass_kernel(DevProblem 
       if (pm < d.P) {
         m_o0 = pb.row_ptr[pm]; m_o1 = pb.row_ptr[pm + 1];
         m_X0 = pb.pts[3 * pm]; m_X1 = pb.pts[3 * pm + 1]; m_X2 = pb.pts[3 * pm + 2];
-        m_ptc = pb.pt_const ? pb.pt_const[pm] != 0 : false;
+        m_ptc = pb.pt_const ? (int)pb.pt_const[pm] : 0;
       }
     }
     double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0}, Wa[3 * (KD ? KD : 1)];
@@ -2368,28 +2369,29 @@ __global__ __launch_bounds__(256, FYM == 1 ? VGG_PS_OCC_FY : VGG_PS_OCC) void po
   int n_o0 = 0, n_o1 = 0;
   ObsPf<NPF> n_pf;
   double n_X0 = 0, n_X1 = 0, n_X2 = 0;
-  bool n_ptc = false;
+  int n_ptc = 0;                                // (constant-point flag as loaded: tested where it is used -- a test right
+                                                //  behind the load is a wait for it, and for every load issued before it)
   // (two stages: the row bounds / coordinates are loaded TWO points ahead, the observations ONE point ahead, so
   //  that the observation loads never wait for the row-bound load they depend on)
   int m_o0 = 0, m_o1 = 0;
   double m_X0 = 0, m_X1 = 0, m_X2 = 0;
-  bool m_ptc = false;
+  int m_ptc = 0;
   if (p < d.P) {
     n_o0 = pb.row_ptr[p]; n_o1 = pb.row_ptr[p + 1];
     n_X0 = pb.pts[3 * p]; n_X1 = pb.pts[3 * p + 1]; n_X2 = pb.pts[3 * p + 2];
-    n_ptc = pb.pt_const ? pb.pt_const[p] != 0 : false;
+    n_ptc = pb.pt_const ? (int)pb.pt_const[p] : 0;
     n_pf.template load<(FYM != 0)>(pb.obs_cam, pb.obs_uv, pb.obs_slot, n_o0, n_o1, LPP, sl);
     if (p + nw < d.P) {
       const int pm = p + nw;
       m_o0 = pb.row_ptr[pm]; m_o1 = pb.row_ptr[pm + 1];
       m_X0 = pb.pts[3 * pm]; m_X1 = pb.pts[3 * pm + 1]; m_X2 = pb.pts[3 * pm + 2];
-      m_ptc = pb.pt_const ? pb.pt_const[pm] != 0 : false;
+      m_ptc = pb.pt_const ? (int)pb.pt_const[pm] : 0;
     }
   }
   for (; p < d.P; p += nw) {
     const int o0 = n_o0, o1 = n_o1;
     const double X[3] = {n_X0, n_X1, n_X2};
-    const bool pt_c = n_ptc;
+    const bool pt_c = n_ptc != 0;
     const ObsPf<NPF> f_pf = n_pf;
     {
       // stage 1 -> current of the next iteration: observations of point p + nw (its bounds arrived an iteration ago)
@@ -2400,7 +2402,7 @@ __global__ __launch_bounds__(256, FYM == 1 ? VGG_PS_OCC_FY : VGG_PS_OCC) void po
       if (pm < d.P) {
         m_o0 = pb.row_ptr[pm]; m_o1 = pb.row_ptr[pm + 1];
         m_X0 = pb.pts[3 * pm]; m_X1 = pb.pts[3 * pm + 1]; m_X2 = pb.pts[3 * pm + 2];
-        m_ptc = pb.pt_const ? pb.pt_const[pm] != 0 : false;
+        m_ptc = pb.pt_const ? (int)pb.pt_const[pm] : 0;
       }
     }
     double t3[3] = {0, 0, 0};

@@ -504,3 +504,25 @@ def test_simple_work_list_covers_the_same_pairs(S, N, cam, shared, monkeypatch):
     assert key(simp) == key(full)                           # the same (point, segment, segment) triples
     tiles = lambda p: sorted((int(a), int(b)) for a, b in p.tile_desc.numpy()[:, :2])
     assert tiles(simp) == tiles(full)
+
+
+def test_group_adjacency_without_blas_matches_the_matrix_product():
+    """ba._group_adjacency packs the points' camera-group sets into 62-bit words and combines the distinct sets pairwise (no GEMM:
+    its first call costs a 160 ms library load); same (G, G) table as (V V^T) > 0, also beyond 62 groups and with a reduce hook."""
+    torch.manual_seed(0)
+    for S, P, dens in ((200, 5000, 0.25), (77, 300, 0.1), (1100, 3000, 0.01), (40, 10, 0.5), (1000, 20000, None)):
+        if dens is None:                                                   # banded (video-like) visibility
+            f = torch.arange(S)[:, None]
+            c = torch.randint(0, S, (P,))[None]
+            masks = (f - c).abs() < 20
+        else:
+            masks = torch.rand(S, P) < dens
+        G = (S + 15) // 16
+        pad = G * 16 - S
+        m = torch.cat([masks, masks.new_zeros((pad, P))]) if pad else masks
+        V = m.reshape(G, 16, -1).any(1).float()
+        ref = (V @ V.t()) > 0
+        assert torch.equal(BA._group_adjacency(masks, 16, None), ref)
+        seen = []
+        got = BA._group_adjacency(masks, 16, lambda t: (seen.append((t.dtype, tuple(t.shape))), t.fill_(1.0)))
+        assert seen == [(torch.float32, (G, G))] and bool(got.all())

@@ -548,13 +548,7 @@ def find_camera_split(masks, group=GROUP, adjacency_reduce=None):
     G = (S + group - 1) // group
     if G < 4:
         return None, (0, 0)
-    pad = G * group - S
-    m = torch.cat([masks, masks.new_zeros((pad, masks.shape[1]))]) if pad else masks
-    V = m.reshape(G, group, -1).any(1).to(torch.float32)
-    adj = ((V @ V.t()) > 0).to(torch.float32)
-    if adjacency_reduce is not None:
-        adjacency_reduce(adj)
-    adj = adj.cpu() > 0
+    adj = _group_adjacency(masks, group, adjacency_reduce)
     Gfull = S // group                              # B takes whole groups only: every group of the new order stays aligned
     best = (0, 0, 0)
     for a in range(2, Gfull - 1, 2):
@@ -575,15 +569,35 @@ def find_camera_split(masks, group=GROUP, adjacency_reduce=None):
 
 
 def _group_adjacency(masks, group, adjacency_reduce):
+    """(G, G) bool on the host: do camera groups g and h share a point?  Without a matrix product -- the first GEMM of a process
+    costs a 160 ms code-object load in the BLAS library (measured inside the second joint BA of the configs[4] loop, round 6),
+    more than every other launch of that call together.  The points' group sets are packed into 62-bit words, the DISTINCT sets
+    (a few thousand at most for video-like visibility) unpacked again and combined pairwise."""
     S = masks.shape[0]
     G = (S + group - 1) // group
     pad = G * group - S
+    dev = masks.device
     m = torch.cat([masks, masks.new_zeros((pad, masks.shape[1]))]) if pad else masks
-    V = m.reshape(G, group, -1).any(1).to(torch.float32)
-    adj = ((V @ V.t()) > 0).to(torch.float32)
+    V = m.reshape(G, group, -1).any(1)                                     # (G, P) bool
+    words = []
+    for w0 in range(0, G, 62):
+        Vw = V[w0:w0 + 62]
+        pow2 = (torch.ones((), dtype=torch.int64, device=dev) << torch.arange(Vw.shape[0], device=dev, dtype=torch.int64))[:, None]
+        words.append((Vw.to(torch.int64) * pow2).sum(0))                   # (P,)
+    uniq = torch.unique(words[0])[:, None] if len(words) == 1 else torch.unique(torch.stack(words, 1), dim=0)
+    bits = [((uniq[:, i:i + 1] >> torch.arange(min(62, G - 62 * i), device=dev, dtype=torch.int64)) & 1).bool()
+            for i in range(len(words))]
+    Vu = torch.cat(bits, 1)                                                # (U, G) the distinct group sets
+    adj = torch.zeros((G, G), dtype=torch.bool, device=dev)
+    step = max(1, (1 << 25) // (G * G))                                    # <= 32 MB of pairwise products at a time
+    for i in range(0, Vu.shape[0], step):
+        blk = Vu[i:i + step]
+        adj |= (blk[:, :, None] & blk[:, None, :]).any(0)
     if adjacency_reduce is not None:
-        adjacency_reduce(adj)
-    return adj.cpu() > 0
+        adj_f = adj.to(torch.float32)
+        adjacency_reduce(adj_f)
+        return adj_f.cpu() > 0
+    return adj.cpu()
 
 
 CAMERA_ORDER_MIN_GAIN = 0.8     # use the k-way order when its pivot chain is at most this fraction of the 2-way one

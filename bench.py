@@ -305,9 +305,15 @@ def main():
     ap.add_argument("--overlap", action="store_true",
                     help="opt-in: 3 Schur tile batches, factorisation on a CU-masked stream beside the later ones "
                          "(ba.OVERLAP_FACTORIZATION; measured slower in round 1, DESIGN.md section 7)")
+    ap.add_argument("--split-exchange", action="store_true",
+                    help="opt-in, N > 1: exchange the reduced system in two parts, the off-diagonal tile launch's share on the "
+                         "communicator's stream beside the diagonal launch (dist.SPLIT_EXCHANGE, DESIGN.md section 8)")
     args = ap.parse_args()
     if args.overlap:
         BA.OVERLAP_FACTORIZATION = True
+    if args.split_exchange:
+        from vggsfm_amd import dist as _dist_mod
+        _dist_mod.SPLIT_EXCHANGE = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

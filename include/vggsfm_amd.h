@@ -237,7 +237,20 @@ int vgg_ba_solve(const vgg_ba_problem* problem, const vgg_ba_options* options, v
  *                      element c of buffer 5 (c + 1 doubles: reduce-scatter output = all-gather input); buffer 6
  *                      (W (c + 1) doubles) is the all-gather output; phase 6 rebuilds S | rhs from its W slices and
  *                      takes the maximum of the W riding gradient norms (replaces the MAX reduce of buffer 2).  W <= 1024
- * vgg_ba_reduce_buffer returns the device address / element count (doubles) of each reduce buffer. */
+ *   phases 7..12     : the SPLIT exchange (round 6) -- phase 1 and the exchange of the system cut in two so that the first
+ *                      half of the payload travels while the diagonal tile launch computes the second:
+ *                      7 = phase 1 up to the sums of the OFF-DIAGONAL tiles; 8 = pack part A (the elements of the lower
+ *                      triangle whose row and column belong to cameras of different 16-camera groups -- all the off-diagonal
+ *                      launch fills) into buffer 4; 9 = the rest of phase 1 (diagonal launch, its sums, assemble); 10 = pack
+ *                      part B (everything else + rhs) behind it; 11 = S | rhs from the two parts' all-gather outputs; 12 =
+ *                      query, to be called ONCE per workspace before phases 7..11: VGG_OK if the split is available for this problem (one tile
+ *                      batch, separate tile launches) -- it then also writes the rows' offsets inside the two parts into the
+ *                      workspace --, VGG_ERR_UNSUPPORTED otherwise (nothing is launched).  With a = vgg_ba_reduce_buffer(7) elements in
+ *                      part A, b = count(4) - a, ca = ceil(a / W), cb = ceil(b / W): buffer 4 = [A: W ca | B: W cb] (reduce-
+ *                      scatter inputs), buffer 5 = [A: ca | B: cb + 1] (the rank's slices; the gradient maximum rides behind
+ *                      B's), buffer 6 = [A: W ca | B: W (cb + 1)] (all-gather outputs)
+ * vgg_ba_reduce_buffer returns the device address / element count (doubles) of each reduce buffer (which = 7: buffer 4's address
+ * and the element count of part A). */
 int vgg_ba_begin(const vgg_ba_problem* problem, const vgg_ba_options* options, void* workspace, size_t workspace_bytes,
                  int rank, int world_size, void* stream);
 int vgg_ba_phase(const vgg_ba_problem* problem, const vgg_ba_options* options, void* workspace, int phase,

@@ -4,7 +4,7 @@ every variant = a set of environment switches read by vggsfm_amd.ba.compile_prob
 difference between the rounds of one variant).  A different library (built with other -D switches) is selected for the
 whole process with VGGSFM_AMD_LIB.
 A variant key RCCL=1 (RCCL=2) runs the iteration with the collectives of a ONE-RANK "nccl" communicator between the phases
-(reduce-scatter + all-gather form; 2 = the two-all-reduce form): what the exchange sequence costs on the kernel stream before
+(reduce-scatter + all-gather form; 2 = the two-all-reduce form; 3 = the split exchange, phases 7..11): what the exchange sequence costs on the kernel stream before
 any link time.  --tracks overrides the track count (37500 = one rank's shard of configs[3] at 8 GPUs).
 usage: python scripts/prof/ab_c3.py [--workload c3] [--tracks N] [--steps 25] [--rounds 2] name:ENV=VAL,ENV=VAL ..."""
 import argparse
@@ -58,7 +58,7 @@ def main():
             L.vgg_ba_set_tile_rhs(2)
             L.vgg_ba_set_step_from_factors(0)
             L.vgg_ba_set_tile_dma(0)
-            coll = None
+            coll, split = None, False
             for kv in filter(None, envs.split(",")):
                 k, _, val = kv.partition("=")
                 if k == "TILE_RHS":                        # (process-wide library switch, not an environment variable here)
@@ -78,6 +78,7 @@ def main():
                         torch.cuda.set_device(dev)
                         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
                     coll = Collectives(1, plain_all_reduce=(val == "2"))
+                    split = val == "3"                     # (RCCL=3: the split exchange of round 6, phases 7..11)
                     continue
                 os.environ[k] = val.replace(";", ",")
             prob, _, _ = BA.compile_problem(*args, shared, cam, camera_split=True)
@@ -86,7 +87,8 @@ def main():
             so = opts.solver_options
             so.max_num_iterations = B.EPISODE
             so.function_tolerance = so.gradient_tolerance = so.parameter_tolerance = -1.0
-            solver = ShardedBA(prob, opts, 0, 1, collectives=coll)
+            solver = ShardedBA(prob, opts, 0, 1, collectives=coll, split_exchange=split)
+            assert solver._split == split
             cnt = [0]
 
             def run(n):

@@ -250,3 +250,60 @@ def test_gloo_rank0_rng_is_borrowed_not_kept():
     assert np.array_equal(res[0][1], torch.randperm(1000, generator=g0).numpy())      # rank 0: advanced by the draws
     g1 = torch.Generator().manual_seed(101)
     assert np.array_equal(res[1][1], torch.randperm(1000, generator=g1).numpy())      # rank 1: its own stream, untouched
+
+
+def _split_exchange_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vggsfm_amd.dist import Collectives
+    co = Collectives(world, host_staging=False)
+    res = {}
+    for a, b in ((5, 3), (1000, 77), (4097, 4096)):
+        ca, cb = -(-a // world), -(-b // world)
+        g = torch.Generator().manual_seed(1000 * a + rank)
+        pa, pb = torch.zeros(world * ca, dtype=torch.float64), torch.zeros(world * cb, dtype=torch.float64)
+        pa[:a] = torch.randn(a, dtype=torch.float64, generator=g)
+        pb[:b] = torch.randn(b, dtype=torch.float64, generator=g)
+        ma, mb = torch.empty(ca, dtype=torch.float64), torch.empty(cb + 1, dtype=torch.float64)
+        mb[cb] = float(rank) + 0.25
+        ga, gb = torch.empty(world * ca, dtype=torch.float64), torch.empty(world * (cb + 1), dtype=torch.float64)
+        # both parts in flight at once, waited for in order (what ShardedBA.iteration does around the diagonal tile launch)
+        ha = co.system_scatter_begin(pa, ma, ga, rides=0)
+        hb = co.system_scatter_begin(pb, mb, gb, rides=1)
+        co.system_scatter_end(ha)
+        co.system_scatter_end(hb)
+        res[(a, b)] = (ga[:a].numpy().copy(), gb.view(world, cb + 1)[:, :cb].reshape(-1)[:b].numpy().copy(),
+                       gb.view(world, cb + 1)[:, cb].numpy().copy())
+    out.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world3_split_exchange_two_parts_in_flight():
+    """dist.Collectives.system_scatter_begin / _end (round 6, the split exchange of the reduced system): two reduce-scatter +
+    all-gather pairs begun back to back and ended afterwards (asynchronous on RCCL only: gloo does not order the pair) give every rank the sums of both parts and
+    the riding per-rank maxima, for part sizes that do not divide by the world size."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_split_exchange_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(out.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for a, b in ((5, 3), (1000, 77), (4097, 4096)):
+        ea, eb = 0, 0
+        for r in range(world):
+            g = torch.Generator().manual_seed(1000 * a + r)
+            ea = ea + torch.randn(a, dtype=torch.float64, generator=g).numpy()
+            eb = eb + torch.randn(b, dtype=torch.float64, generator=g).numpy()
+        for r in range(world):
+            ga, gb, rides = res[r][(a, b)]
+            np.testing.assert_allclose(ga, ea, rtol=1e-13, atol=1e-13)
+            np.testing.assert_allclose(gb, eb, rtol=1e-13, atol=1e-13)
+            assert np.array_equal(rides, np.arange(world) + 0.25)
+            assert np.array_equal(ga, res[0][(a, b)][0]) and np.array_equal(gb, res[0][(a, b)][1])

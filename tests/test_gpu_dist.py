@@ -31,13 +31,17 @@ class _LockStep:
             t.copy_(red)
 
 
-@pytest.mark.parametrize("in_place", [False, True])
-@pytest.mark.parametrize("cam,shared,world", [("SIMPLE_RADIAL", True, 2), ("SIMPLE_PINHOLE", False, 3)])
-def test_sharded_equals_single_rank(cam, shared, world, in_place):
+@pytest.mark.parametrize("in_place", [False, True, "split"])
+@pytest.mark.parametrize("cam,shared,world", [("SIMPLE_RADIAL", True, 2), ("SIMPLE_PINHOLE", False, 3), ("SIMPLE_RADIAL", False, 2)])
+def test_sharded_equals_single_rank(cam, shared, world, in_place, monkeypatch):
     """in_place: the exchange of the reduced system as dist.Collectives.system_scatter does it -- a reduce-scatter of the
     padded packed buffer (phase 4 pads it) into every rank's slice buffer and an all-gather of the slices, each with the
     rank's gradient maximum behind it, into the buffer phase 6 unpacks from (no staging copies, no MAX collective);
-    emulated here slice by slice on the solvers' own reduce buffers 4 / 5 / 6."""
+    emulated here slice by slice on the solvers' own reduce buffers 4 / 5 / 6.
+    "split" (round 6): phases 7..11 -- the system exchanged in two parts (the off-diagonal tile launch's share before the
+    diagonal launch has run), each part reduce-scattered and gathered on its own regions of the three buffers."""
+    if in_place == "split":
+        monkeypatch.setattr(BA, "MERGED_TILE_MAX_OBS", 0)      # (the split needs the two tile launches apart: not the small-problem form)
     sc = make_scene(24, 1500, cam, shared_camera=shared, seed=17)
     ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=17)
     opts = prepare_ba_options()
@@ -52,7 +56,8 @@ def test_sharded_equals_single_rank(cam, shared, world, in_place):
         pr, _, _ = BA.compile_problem(pt, D(ext0), D(K0), tr, mk, D(extra0), shared, cam)
         problems.append(pr)
         slices.append(sl)
-        solvers.append(ShardedBA(pr, opts, rank=r, world_size=world, all_reduce=lambda t, op: None))
+        solvers.append(ShardedBA(pr, opts, rank=r, world_size=world, all_reduce=lambda t, op: None,
+                                 split_exchange="emulated" if in_place == "split" else False))
     hub = _LockStep(world)
     for s in solvers:
         s.begin()
@@ -60,10 +65,37 @@ def test_sharded_equals_single_rank(cam, shared, world, in_place):
         for s in solvers:
             s._phase(0)
         hub.exchange([s.bufs[0] for s in solvers], "sum")
+        n = ref["n_reduced"]
+        if in_place == "split":
+            assert all(s._split for s in solvers)
+
+            def scatter_gather(padded, mine, gathered, rides):
+                total = torch.stack(padded).sum(0)
+                c = mine[0].numel() - rides
+                for r, m in enumerate(mine):
+                    m[:c].copy_(total[r * c:(r + 1) * c])
+                allm = torch.cat(mine)
+                for g in gathered:
+                    g.copy_(allm)
+            for s in solvers:
+                s._phase(7)
+                s._phase(8)
+            assert 0 < solvers[0]._padded_a.numel() < n * (n + 1) // 2
+            scatter_gather([s._padded_a for s in solvers], [s._mine_a for s in solvers], [s._gathered_a for s in solvers], 0)
+            for s in solvers:
+                s._phase(9)
+                s._phase(10)
+            scatter_gather([s._padded_b for s in solvers], [s._mine_b for s in solvers], [s._gathered_b for s in solvers], 1)
+            for s in solvers:
+                s._phase(11)
+                s._phase(2)
+            hub.exchange([s.bufs[3] for s in solvers], "sum")
+            for s in solvers:
+                s._phase(3)
+            continue
         for s in solvers:
             s._phase(1)
             s._phase(4)                                     # pack lower triangle + rhs (the real collective's payload)
-        n = ref["n_reduced"]
         assert solvers[0].bufs[4].numel() == n * (n + 1) // 2 + n
         if in_place:
             chunk = -(-solvers[0].bufs[4].numel() // world)
@@ -164,3 +196,77 @@ def test_sharded_triangulation_and_filter_equal_single_rank(world):
                                                      max_reproj_error=4, return_detail=True)
         masks.append(mk), dets.append(dt)
     assert torch.equal(torch.cat(masks), fm) and torch.equal(torch.cat(dets, 1), fd)
+
+
+@pytest.mark.parametrize("cam,shared,frames", [("SIMPLE_RADIAL", False, 56), ("SIMPLE_PINHOLE", False, 40), ("SIMPLE_RADIAL", True, 72),
+                                               ("SIMPLE_PINHOLE", True, 33)])
+def test_split_exchange_rebuilds_the_same_system_as_the_one_piece_exchange(cam, shared, frames, monkeypatch):
+    """Phases 7..11 (include/vggsfm_amd.h) against phases 1 / 4 / 6 with two emulated ranks, over several LM iterations in lock
+    step: S | rhs and the gradient maximum that come out of the exchange are BIT-identical -- every element of the lower
+    triangle is in exactly one of the two parts, the off-diagonal launch fills nothing of part B and the diagonal launch /
+    assemble nothing of part A (3-5 camera groups, the last one partial; 6 x 6, 7 x 7 and 8 x 8 blocks; odd n)."""
+    monkeypatch.setattr(BA, "MERGED_TILE_MAX_OBS", 0)
+    W = 2
+    sc = make_scene(frames, 1200, cam, shared_camera=shared, seed=5)
+    ext0, K0, extra0, pts0 = perturb_for_ba(sc, seed=5)
+    opts = prepare_ba_options()
+    snaps = {}
+
+    def sg(padded, mine, gathered, rides):
+        total = torch.stack(padded).sum(0)
+        c = mine[0].numel() - rides
+        for r, m in enumerate(mine):
+            m[:c].copy_(total[r * c:(r + 1) * c])
+        allm = torch.cat(mine)
+        for g in gathered:
+            g.copy_(allm)
+    for mode in ("one_piece", "split"):
+        solvers = []
+        for r in range(W):
+            tr, mk, pt, _ = shard_slice(D(sc.tracks), D(sc.mask), D(pts0), r, W)
+            pr, _, _ = BA.compile_problem(pt, D(ext0), D(K0), tr, mk, D(extra0), shared, cam)
+            solvers.append(ShardedBA(pr, opts, rank=r, world_size=W, all_reduce=lambda t, op: None,
+                                     split_exchange="emulated" if mode == "split" else False))
+        assert all(s._split == (mode == "split") for s in solvers)
+        for s in solvers:
+            s.begin()
+        snaps[mode] = []
+        for _ in range(5):
+            for s in solvers:
+                s._phase(0)
+            tot = torch.stack([s.bufs[0] for s in solvers]).sum(0)
+            for s in solvers:
+                s.bufs[0].copy_(tot)
+            if mode == "one_piece":
+                for s in solvers:
+                    s._phase(1)
+                    s._phase(4)
+                sg([s._padded for s in solvers], [s._mine for s in solvers], [s._gathered for s in solvers], 1)
+                for s in solvers:
+                    s._phase(6)
+            else:
+                for s in solvers:
+                    s._phase(7)
+                    s._phase(8)
+                a, n = solvers[0]._padded_a.numel(), solvers[0].bufs[4].numel()
+                assert 0 < a < n
+                sg([s._padded_a for s in solvers], [s._mine_a for s in solvers], [s._gathered_a for s in solvers], 0)
+                for s in solvers:
+                    s._phase(9)
+                    s._phase(10)
+                sg([s._padded_b for s in solvers], [s._mine_b for s in solvers], [s._gathered_b for s in solvers], 1)
+                for s in solvers:
+                    s.bufs[1].fill_(float("nan"))           # (phase 11 rebuilds everything that is read)
+                    s._phase(11)
+            for s in solvers:
+                nn = int(round((-1 + (1 + 4 * s.bufs[1].numel()) ** 0.5) / 2))
+                snaps[mode].append((torch.tril(s.bufs[1][:nn * nn].view(nn, nn)).clone(), s.bufs[1][nn * nn:].clone(), s.bufs[2][:1].clone()))
+            for s in solvers:
+                s._phase(2)
+            tot = torch.stack([s.bufs[3] for s in solvers]).sum(0)
+            for s in solvers:
+                s.bufs[3].copy_(tot)
+            for s in solvers:
+                s._phase(3)
+    for (Sa, ra, ga), (Sb, rb, gb) in zip(snaps["one_piece"], snaps["split"]):
+        assert torch.equal(Sa, Sb) and torch.equal(ra, rb) and torch.equal(ga, gb)

@@ -107,10 +107,13 @@ def _one_rank(port, cam, shared, out):
     opts = prepare_ba_options()
     opts.solver_options.max_num_iterations = 10
     res = {}
-    for name in ("plain", "rccl", "rccl_allreduce"):
+    for name in ("plain", "rccl", "rccl_allreduce", "rccl_split"):
+        BA.MERGED_TILE_MAX_OBS = 0 if name == "rccl_split" else 1_000_000     # (the split needs the two tile launches apart)
         pr, _, _ = BA.compile_problem(D(pts0), D(ext0), D(K0), D(sc.tracks), D(sc.mask), D(extra0), shared, cam, camera_split=True)
         co = None if name == "plain" else Collectives(1, plain_all_reduce=(name == "rccl_allreduce"))
-        r = ShardedBA(pr, opts, collectives=co).solve()
+        sb = ShardedBA(pr, opts, collectives=co, split_exchange=(name == "rccl_split"))
+        assert sb._split == (name == "rccl_split")
+        r = sb.solve()
         torch.cuda.synchronize()
         res[name] = dict(its=[(i["successful"], i["cost"]) for i in r["iterations"]], final=r["final_cost"], n_it=r["num_iterations"],
                          cam_t=pr.cam_t.cpu().numpy(), intr=pr.intr.cpu().numpy(), pts=pr.pts.cpu().numpy())
@@ -134,7 +137,9 @@ def test_rccl_one_rank_runs_the_exchange_sequence_on_the_solver_buffers(cam, sha
     p.join(timeout=120)
     assert p.exitcode == 0
     ref = res["plain"]
-    for name in ("rccl", "rccl_allreduce"):
+    # ("rccl_split", round 6: the system in two parts, the first one's reduce-scatter + all-gather enqueued on the communicator's
+    #  stream before the diagonal tile launch -- async_op -- and waited for behind the second's)
+    for name in ("rccl", "rccl_allreduce", "rccl_split"):
         g = res[name]
         assert g["n_it"] == ref["n_it"] and g["its"] == ref["its"] and g["final"] == ref["final"], name
         for k in ("cam_t", "intr", "pts"):

@@ -145,6 +145,7 @@ struct Ws {  // device workspace carve-up (pointers into the caller's buffer)
   // column-major) with E hs = E G z, E Ms_m = E G y_m; per diagonal chunk the sums over its entries of Y_seg Z (96 x 3);
   // per point-pass workgroup the shared-intrinsics terms sum_p Wa_p hs_p (KD) and sum_p Wa_p Ms_p^T (KD x KD)
   double *Zp, *rz_part, *part_Q;
+  unsigned long long* split_off;   // split exchange: [2][n + 2] elements of part A / B in the rows above row i (i = n: the rhs; i = n + 1: the part's total)
   double* rz;                 // [ceil(C / 16)][96 x 3] rz_part summed over the chunks of a group's diagonal tile (tile_reduce_kernel)
   int tile_rhs;               // 1: cam_pass<RHS> is not launched, its sums come from the diagonal tile launch + point_pass
   int step_from_factors;      // 1: point_step_kernel takes E^T F dy from the compressed Schur factors (no Jacobian sweep)
@@ -228,6 +229,7 @@ static Ws carve(const Dims& d, int max_iters, int num_chunks, int num_segments, 
   w.rz_part = (double*)take(8ull * (size_t)(num_chunks > 0 ? num_chunks : 1) * kGroup * 6 * 3);
   w.part_Q = (double*)take(8ull * kMaxWG * 8);
   w.rz = (double*)take(8ull * (size_t)((d.C + kGroup - 1) / kGroup) * kGroup * 6 * 3);
+  w.split_off = (unsigned long long*)take(8ull * 2 * ((size_t)d.n_red + 2));
   w.tile_rhs = 0;
   w.total_bytes = off;
   return w;
@@ -2024,11 +2026,14 @@ __global__ __launch_bounds__(256, VGG_OFFDIAG_OCC) void schur_tile_dma_kernel(Ws
 template <int BD>
 __global__ __launch_bounds__(256) void tile_reduce_kernel(Ws w, int n_red, int C, int KD,
                                                           const int32_t* __restrict__ tile_desc, int tile0,
-                                                          double* __restrict__ dst) {
+                                                          double* __restrict__ dst, int want) {
   constexpr int R = kGroup * BD;
   if (w.ctl->done) return;
   const int tile = tile0 + blockIdx.y;
   const int gI = tile_desc[4 * tile], gJ = tile_desc[4 * tile + 1];
+  // (want: -1 = every tile of the range; 0 / 1 = only its off-diagonal / diagonal tiles -- the split exchange of the sharded
+  //  solve sums the off-diagonal launch's tiles while the diagonal launch has not run yet, phases 7 / 9)
+  if (want >= 0 && (gI == gJ) != (want == 1)) return;
   const int c0 = tile_desc[4 * tile + 2], c1 = tile_desc[4 * tile + 3];
   const int n = n_red;
   if constexpr (BD == 6) {
@@ -2657,6 +2662,113 @@ __global__ __launch_bounds__(256) void pack_lower_kernel(Ws w, int n, int mode) 
   }
 }
 
+// SPLIT exchange of the sharded solve (round 6, phases 7..11): the packed lower triangle is cut into the part the OFF-DIAGONAL
+// tile launch fills (A: elements whose row and column belong to cameras of different 16-camera groups) and the rest (B: the
+// diagonal tiles' blocks, everything assemble_kernel adds, the shared-intrinsics border, the right-hand side), so that the
+// reduce-scatter + all-gather of A can run on the communicator's stream while the diagonal tile launch is still computing B.
+// Row r of S contributes up to three column ranges to A and two to B, in this order; a part is packed row by row.
+struct RowParts { int a0[3], a1[3], b0[2], b1[2]; };   // fixed slots; a range with x1 <= x0 is empty
+__device__ __forceinline__ RowParts row_parts(int r, int n, int C, int KD, int shared) {
+  RowParts p;
+  p.a0[0] = p.a1[0] = p.a0[1] = p.a1[1] = p.a0[2] = p.a1[2] = p.b0[0] = p.b1[0] = p.b0[1] = p.b1[1] = 0;
+  const int P6 = 6 * C, GW = 6 * kGroup;
+  if (r >= n) { p.b1[0] = n; }                                // the right-hand side
+  else if (r < P6) { const int g = r / GW; p.a1[0] = GW * g; p.b0[0] = GW * g; p.b1[0] = r + 1; }
+  else if (shared || KD == 0) { p.b1[0] = r + 1; }            // shared-intrinsics border: assemble_kernel's
+  else {                                                      // intrinsics row of camera a (per-camera intrinsics)
+    const int a = (r - P6) / KD, g = a / kGroup;
+    const int pb0 = GW * g, pb1 = min(GW * (g + 1), P6), ib0 = P6 + kGroup * KD * g;
+    p.a1[0] = pb0; p.b0[0] = pb0; p.b1[0] = pb1; p.a0[1] = pb1; p.a1[1] = P6; p.a0[2] = P6; p.a1[2] = ib0; p.b0[1] = ib0; p.b1[1] = r + 1;
+  }
+  return p;
+}
+__device__ __forceinline__ int parts_count(const RowParts& p, int part) {
+  return part == 0 ? max(p.a1[0] - p.a0[0], 0) + max(p.a1[1] - p.a0[1], 0) + max(p.a1[2] - p.a0[2], 0)
+                   : max(p.b1[0] - p.b0[0], 0) + max(p.b1[1] - p.b0[1], 0);
+}
+// mode 0: S, rhs -> the part's region of `packed` (zero tail up to W equal slices; part B: + this rank's gradient maximum behind
+// its slice);  mode 2: the part's all-gather output -> S, rhs (part B: + the maximum over the ranks -> gmax_pts).
+// Regions: packed = [A: W chunkA | B: W chunkB], pk_mine = [A: chunkA | B: chunkB + 1], pk_gathered = [A: W chunkA | B: W (chunkB + 1)].
+// (the rows' offsets inside their part: one workgroup, once per workspace -- phase 12; the first version had every workgroup of
+//  pack_split_kernel sum the rows above its own: 10 M row classifications per launch at n = 3200, 120 us)
+__global__ __launch_bounds__(256) void split_offsets_kernel(Ws w, int n, int C, int KD, int shared) {
+  __shared__ unsigned long long part_sum[2][256];
+  const int per = (n + 1 + 255) / 256, r0 = threadIdx.x * per, r1 = min(r0 + per, n + 1);
+  unsigned long long sa = 0, sb = 0;
+  for (int r = r0; r < r1; ++r) { const RowParts p = row_parts(r, n, C, KD, shared); sa += parts_count(p, 0); sb += parts_count(p, 1); }
+  part_sum[0][threadIdx.x] = sa; part_sum[1][threadIdx.x] = sb;
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    unsigned long long run = 0;
+    for (int t = 0; t < 256; ++t) { const unsigned long long v = part_sum[threadIdx.x][t]; part_sum[threadIdx.x][t] = run; run += v; }
+    w.split_off[(size_t)threadIdx.x * (n + 2) + n + 1] = run;
+  }
+  __syncthreads();
+  sa = part_sum[0][threadIdx.x]; sb = part_sum[1][threadIdx.x];
+  for (int r = r0; r < r1; ++r) {
+    const RowParts p = row_parts(r, n, C, KD, shared);
+    w.split_off[r] = sa; w.split_off[(size_t)(n + 2) + r] = sb;
+    sa += parts_count(p, 0); sb += parts_count(p, 1);
+  }
+}
+__global__ __launch_bounds__(256) void pack_split_kernel(Ws w, int n, int C, int KD, int shared, int part, int mode) {
+  if (w.ctl->done) return;
+  const int i = blockIdx.x;                                   // row i, or row n = the right-hand side
+  const unsigned long long before = w.split_off[(size_t)part * (n + 2) + i], total = w.split_off[(size_t)part * (n + 2) + n + 1];
+  const unsigned long long total_a = w.split_off[n + 1];
+  const size_t W = w.ctl->world > 0 ? w.ctl->world : 1;
+  const size_t chunk_a = (total_a + W - 1) / W, chunk_b = (w.packed_count - total_a + W - 1) / W;
+  const size_t chunk = part == 0 ? chunk_a : chunk_b, gstride = chunk + (part == 0 ? 0 : 1);
+  double* packed = w.packed + (part == 0 ? 0 : W * chunk_a);
+  const double* gathered = w.pk_gathered + (part == 0 ? 0 : W * chunk_a);
+  double* full = (i < n) ? w.S + (size_t)i * n : w.rhs;
+  const RowParts p = row_parts(i, n, C, KD, shared);
+  size_t e = before;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (part == 1 && k == 2) break;
+    const int x0 = part == 0 ? p.a0[k] : p.b0[k < 2 ? k : 0], x1 = part == 0 ? p.a1[k] : p.b1[k < 2 ? k : 0];
+    if (x1 <= x0) continue;
+    if (mode == 0) {
+      for (int j = x0 + threadIdx.x; j < x1; j += 256) packed[e + (size_t)(j - x0)] = full[j];
+    } else {
+      // (slice of the first element once per thread, then by increments: no 64-bit division per element)
+      size_t ee = e + threadIdx.x, r = ee / chunk, off = ee - r * chunk;
+      for (int j = x0 + threadIdx.x; j < x1; j += 256) {
+        full[j] = gathered[r * gstride + off];
+        off += 256;
+        while (off >= chunk) { off -= chunk; ++r; }
+      }
+    }
+    e += (size_t)(x1 - x0);
+  }
+  if (i == n) {
+    if (mode == 0) {
+      for (size_t j = total + threadIdx.x; j < W * chunk; j += 256) packed[j] = 0.0;
+      if (part == 1 && threadIdx.x == 0) w.pk_mine[chunk_a + chunk_b] = w.gmax_pts[0];
+    } else if (part == 1 && threadIdx.x < 64) {
+      double m = 0.0;
+      for (size_t r = threadIdx.x; r < W; r += 64) m = fmax(m, gathered[r * gstride + chunk]);
+      m = wave_max(m);
+      if (threadIdx.x == 0) w.gmax_pts[0] = m;
+    }
+  }
+}
+// (host: number of elements of part A -- the same sum)
+static size_t split_count_a(const Dims& d) {
+  size_t c = 0;
+  const int P6 = 6 * d.C, GW = 6 * kGroup;
+  for (int r = 0; r < d.n_red; ++r) {
+    if (r < P6) c += (size_t)GW * (r / GW);
+    else if (!(d.shared || d.kd == 0)) {
+      const int a = (r - P6) / d.kd, g = a / kGroup;
+      const int pb0 = GW * g, pb1 = (GW * (g + 1) < P6) ? GW * (g + 1) : P6;
+      c += (size_t)pb0 + (size_t)(P6 - pb1) + (size_t)kGroup * d.kd * g;
+    }
+  }
+  return c;
+}
+
 // workgroups per camera of the camera passes: ~1024 workgroups in total for a large problem (c3: 19 observations per
 // thread; 2048 workgroups cost 0.117 + 0.131 ms, 1024: 0.099 + 0.128, 512: 0.105 + 0.146), at least ~2048 observations per
 // workgroup for a small one (c2: 512 workgroups 0.025 + 0.019 ms, 1024: 0.038 + 0.026).  VGG_CAM_WGS overrides the total.
@@ -2677,13 +2789,15 @@ static void phase_linearize(const Launch& L) {
 // one batch of Schur tiles: the off-diagonal launch, the diagonal launch, and the ordered sum of their chunks into
 // dst (S, or S2 for a batch that runs beside the factorisation)
 template <int BD>
-static void launch_schur_batch(const Launch& L, int batch, hipStream_t st, double* dst) {
+static void launch_schur_batch(const Launch& L, int batch, hipStream_t st, double* dst, int which = 0) {
+  // which: 0 = the whole batch; 1 = the off-diagonal launch and the sums of its tiles; 2 = the diagonal launch and its sums
+  // (1 / 2: the split exchange of the sharded solve; never with the merged launch)
   const int32_t* B = L.batches + 6 * batch;
   const int c0 = B[0], cm = B[1], c1 = B[2], t0 = B[3], t1 = B[4];
   if (L.merged_tile_launch && c1 > c0) {
     ProfScope ps(kProfSchurTile, st);
     schur_tile_merged_kernel<BD><<<c1 - c0, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, c0, L.num_segments);
-  } else if (cm > c0) {
+  } else if (cm > c0 && which != 2) {
     if (BD == 6 && L.w.tile_dma) {                 // round-6 A/B: LDS-DMA staging from the expanded segment image
       {
         ProfScope ps(kProfCamRhs, st);              // (the slot of cam_pass<RHS>, which tile_rhs leaves empty: the expansion, timed apart)
@@ -2697,21 +2811,21 @@ static void launch_schur_batch(const Launch& L, int batch, hipStream_t st, doubl
       schur_tile_kernel<BD, false><<<cm - c0, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, c0, L.num_segments);
     }
   }
-  if (!L.merged_tile_launch && c1 > cm) {
+  if (!L.merged_tile_launch && c1 > cm && which != 1) {
     ProfScope ps(kProfSchurTileDiag, st);
     schur_tile_kernel<BD, true><<<c1 - cm, 256, 0, st>>>(L.w, L.chunk_desc, L.entries, cm, L.num_segments);
   }
   if (t1 > t0)
     tile_reduce_kernel<BD><<<dim3(div_up(kGroup * BD * kGroup * BD, 256) + (L.w.tile_rhs ? (BD == 6 ? div_up(kGroup * BD * 3, 256) : div_up(2 * kGroup * BD, 256)) : 0),
-                                  t1 - t0), 256, 0, st>>>(L.w, L.d.n_red, L.d.C, L.d.kd, L.tile_desc, t0, dst);
+                                  t1 - t0), 256, 0, st>>>(L.w, L.d.n_red, L.d.C, L.d.kd, L.tile_desc, t0, dst, which == 0 ? -1 : which - 1);
 }
 
 template <int KD>
 static void launch_schur_batches(const Launch& L, int b0, int b1, hipStream_t st, double* dst, hipEvent_t* done_events,
-                                 int32_t* done_flags = nullptr) {
+                                 int32_t* done_flags = nullptr, int which = 0) {
   for (int b = b0; b < b1; ++b) {
-    if (L.d.shared || KD == 0) launch_schur_batch<6>(L, b, st, dst);
-    else launch_schur_batch<6 + KD>(L, b, st, dst);
+    if (L.d.shared || KD == 0) launch_schur_batch<6>(L, b, st, dst, which);
+    else launch_schur_batch<6 + KD>(L, b, st, dst, which);
     if (done_events) (void)hipEventRecord(done_events[b], st);
     if (done_flags) dataflow_signal(done_flags + b, st);    // (for the single-launch factorisation, which waits on the device)
   }
@@ -2753,9 +2867,16 @@ static OverlapCtx* overlap_ctx(const Launch& L) {
   return &c;
 }
 
+// which: 0 = the whole phase; 1 = up to the off-diagonal tile launch and the sums of its tiles; 2 = the diagonal launch, its
+// sums and assemble (1 / 2: the split exchange of the sharded solve, phases 7 / 9 -- one tile batch, separate launches)
 template <int KD>
-static void phase_schur(const Launch& L) {
+static void phase_schur(const Launch& L, int which = 0) {
   const Dims& d = L.d;
+  if (which == 2) {
+    if (L.num_chunks > 0) launch_schur_batches<KD>(L, 0, L.num_batches, L.st, L.w.S, nullptr, nullptr, 2);
+    assemble_kernel<KD><<<d.C + 1, 64, 0, L.st>>>(L.dp, L.w, L.tile_desc, L.num_tiles, L.wgB);
+    return;
+  }
   prep_kernel<KD><<<1, 256, 0, L.st>>>(L.dp, L.w, L.opt);
   {
     ProfScope ps(kProfPointPass, L.st);
@@ -2793,6 +2914,10 @@ static void phase_schur(const Launch& L) {
     cam_reduce_kernel<KD, 1><<<d.C, 64, 0, L.st>>>(L.dp, L.w, split, L.wgB);
   }
   // (the reduced system was zeroed by cam_pass_kernel<KD, 1>: no fill launch)
+  if (which == 1) {
+    if (L.num_chunks > 0) launch_schur_batches<KD>(L, 0, L.num_batches, L.st, L.w.S, nullptr, nullptr, 1);
+    return;
+  }
   if (L.num_chunks > 0) {
     if (overlap_ctx(L)) {
       // only the first batch here; the others are enqueued by phase_step beside the factorisation and land in S2
@@ -2956,6 +3081,24 @@ static int run_phase(const Launch& L, int phase) {
     case 4: pack_lower_kernel<<<L.d.n_red + 1, 256, 0, L.st>>>(L.w, L.d.n_red, 0); return VGG_OK;
     case 5: pack_lower_kernel<<<L.d.n_red + 1, 256, 0, L.st>>>(L.w, L.d.n_red, 1); return VGG_OK;
     case 6: pack_lower_kernel<<<L.d.n_red + 1, 256, 0, L.st>>>(L.w, L.d.n_red, 2); return VGG_OK;
+    // split exchange (round 6): 7 = phase 1 up to the sums of the off-diagonal tiles, 8 = pack part A, 9 = the rest of phase 1,
+    // 10 = pack part B, 11 = both parts' gathered slices -> S | rhs; 12 = "is the split available for this problem?" + the rows' offsets inside the parts (call it once per workspace)
+    case 7: case 9: case 12:
+      if (L.num_batches != 1 || L.merged_tile_launch) return VGG_ERR_UNSUPPORTED;
+      if (phase == 12) {                           // (also prepares the rows' offsets inside the two parts: once per workspace)
+        split_offsets_kernel<<<1, 256, 0, L.st>>>(L.w, L.d.n_red, L.d.C, L.d.kd, L.d.shared);
+        return VGG_OK;
+      }
+      return dispatch_kd(L.d.kd, [&] { phase_schur<0>(L, phase == 7 ? 1 : 2); return VGG_OK; },
+                         [&] { phase_schur<1>(L, phase == 7 ? 1 : 2); return VGG_OK; },
+                         [&] { phase_schur<2>(L, phase == 7 ? 1 : 2); return VGG_OK; });
+    case 8: case 10:
+      pack_split_kernel<<<L.d.n_red + 1, 256, 0, L.st>>>(L.w, L.d.n_red, L.d.C, L.d.kd, L.d.shared, phase == 8 ? 0 : 1, 0);
+      return VGG_OK;
+    case 11:
+      pack_split_kernel<<<L.d.n_red + 1, 256, 0, L.st>>>(L.w, L.d.n_red, L.d.C, L.d.kd, L.d.shared, 0, 2);
+      pack_split_kernel<<<L.d.n_red + 1, 256, 0, L.st>>>(L.w, L.d.n_red, L.d.C, L.d.kd, L.d.shared, 1, 2);
+      return VGG_OK;
     default: return VGG_ERR_INVALID_ARGUMENT;
   }
 }
@@ -3098,6 +3241,7 @@ int vgg_ba_reduce_buffer(const vgg_ba_problem* problem, const vgg_ba_options* op
     case 4: *device_ptr = w.packed; *count = w.packed_count; break;
     case 5: *device_ptr = w.pk_mine; *count = w.packed_count + 2; break;
     case 6: *device_ptr = w.pk_gathered; *count = w.packed_count + 2 * kPackPad; break;
+    case 7: *device_ptr = w.packed; *count = split_count_a(d); break;      // (count = elements of part A of the split exchange)
     default: return VGG_ERR_INVALID_ARGUMENT;
   }
   return VGG_OK;

@@ -139,6 +139,9 @@ def filter_all_points3D_sharded(points3D, points2D, extrinsics, intrinsics, rank
     return (mask, det), (0, P)
 
 
+SPLIT_EXCHANGE = False       # default of ShardedBA(split_exchange=None); see ShardedBA.__init__
+
+
 class Collectives:
     """The three exchanges of one LM iteration over ``torch.distributed``.
 
@@ -183,6 +186,36 @@ class Collectives:
         dist.reduce_scatter_tensor(mine[:-1], padded, op=dist.ReduceOp.SUM, group=self.group)
         dist.all_gather_into_tensor(gathered, mine, group=self.group)
 
+    def system_scatter_begin(self, padded, mine, gathered, rides=1):
+        """`system_scatter` without waiting for it: the two collectives are enqueued on the communicator's own stream behind what the
+        current stream holds at this point (torch's async_op), so that kernels launched afterwards run beside them;
+        `system_scatter_end(handle)` makes the current stream wait.  `rides`: elements behind the rank's slice that travel in the
+        gather only (1 = the gradient maximum; 0 for a part without one).  Host-staged transports run it synchronously."""
+        dist = self.dist
+        own = mine[:mine.numel() - rides] if rides else mine
+        if self._staged(padded):
+            hp, hm, hg = padded.cpu(), mine.cpu(), torch.empty(gathered.shape, dtype=gathered.dtype)
+            dist.reduce_scatter_tensor(hm[:hm.numel() - rides] if rides else hm, hp, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_gather_into_tensor(hg, hm, group=self.group)
+            mine.copy_(hm)
+            gathered.copy_(hg)
+            return None
+        if not (dist.is_initialized() and dist.get_backend(self.group) == "nccl"):
+            # (only RCCL orders the two on a stream: with another transport the gather could read the slice before the
+            #  reduce-scatter has written it)
+            dist.reduce_scatter_tensor(own, padded, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_gather_into_tensor(gathered, mine, group=self.group)
+            return None
+        w1 = dist.reduce_scatter_tensor(own, padded, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        w2 = dist.all_gather_into_tensor(gathered, mine, group=self.group, async_op=True)
+        return (w1, w2)
+
+    @staticmethod
+    def system_scatter_end(handle):
+        if handle is not None:
+            handle[0].wait()
+            handle[1].wait()
+
     def system_(self, packed, local_max):
         dist, W = self.dist, self.world
         if not self.scatter:
@@ -222,7 +255,11 @@ class _FunctionCollectives:
 class ShardedBA:
     """LM loop of one rank's DeviceProblem with the collectives interleaved (also used with world_size 1)."""
 
-    def __init__(self, problem, options=None, rank=0, world_size=1, all_reduce=None, collectives=None):
+    def __init__(self, problem, options=None, rank=0, world_size=1, all_reduce=None, collectives=None, split_exchange=None):
+        """split_exchange (round 6; None = `SPLIT_EXCHANGE`): exchange the reduced system in two parts -- the off-diagonal tile
+        launch's share travels on the communicator's stream while the diagonal launch computes the rest (phases 7..11 of
+        include/vggsfm_amd.h).  Needs `Collectives` (reduce-scatter + all-gather) and a problem with one tile batch and separate
+        tile launches; otherwise the one-piece exchange is used."""
         self.L = _lib.lib()
         self.problem = problem
         self.options = options or BundleAdjustmentOptions()
@@ -257,6 +294,24 @@ class ShardedBA:
         self._mine = self.bufs[5][:chunk + 1]
         self._gathered = self.bufs[6][:world_size * (chunk + 1)]
         self._in_place = isinstance(collectives, Collectives) and collectives.scatter
+        # split exchange: [A | B] regions of the same three buffers (include/vggsfm_amd.h, phases 7..11)
+        want_split = SPLIT_EXCHANGE if split_exchange is None else bool(split_exchange)
+        self._split = False
+        if want_split and (self._in_place or split_exchange == "emulated"):
+            rc = self.L.vgg_ba_phase(ctypes.byref(self.cp), ctypes.byref(self.co), _lib.ptr(self.ws), 12, _lib.stream_ptr())
+            if rc == 0:
+                p = ctypes.POINTER(ctypes.c_double)()
+                cnt = ctypes.c_size_t()
+                _lib.check(self.L.vgg_ba_reduce_buffer(ctypes.byref(self.cp), ctypes.byref(self.co), _lib.ptr(self.ws), 7,
+                                                       ctypes.byref(p), ctypes.byref(cnt)), "vgg_ba_reduce_buffer")
+                W = max(world_size, 1)
+                a = int(cnt.value)
+                ca, cb = -(-a // W), -(-(M - a) // W)
+                b4 = self.ws[off4:off4 + 8 * W * (ca + cb)].view(torch.float64)
+                self._padded_a, self._padded_b = b4[:W * ca], b4[W * ca:]
+                self._mine_a, self._mine_b = self.bufs[5][:ca], self.bufs[5][ca:ca + cb + 1]
+                self._gathered_a, self._gathered_b = self.bufs[6][:W * ca], self.bufs[6][W * ca:W * ca + W * (cb + 1)]
+                self._split = True
 
     def begin(self):
         _lib.check(self.L.vgg_ba_begin(ctypes.byref(self.cp), ctypes.byref(self.co), _lib.ptr(self.ws),
@@ -271,6 +326,21 @@ class ShardedBA:
         self._phase(0)
         if co:
             co.sum_(self.bufs[0])
+        if co and self._split:
+            # the off-diagonal tiles' share of the system is on its way while the diagonal tile launch runs
+            self._phase(7)
+            self._phase(8)
+            ha = co.system_scatter_begin(self._padded_a, self._mine_a, self._gathered_a, rides=0)
+            self._phase(9)
+            self._phase(10)
+            hb = co.system_scatter_begin(self._padded_b, self._mine_b, self._gathered_b, rides=1)
+            co.system_scatter_end(ha)
+            co.system_scatter_end(hb)
+            self._phase(11)
+            self._phase(2)
+            co.sum_(self.bufs[3])
+            self._phase(3)
+            return
         self._phase(1)
         if co:
             self._phase(4)                      # lower triangle + rhs -> packed buffer (half the payload), padded to W slices

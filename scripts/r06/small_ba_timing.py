@@ -9,7 +9,8 @@ from vggsfm_amd.scene import make_scene, perturb_for_ba
 import bench as B
 D = lambda x: None if x is None else torch.from_numpy(np.ascontiguousarray(x)).cuda()
 L = _lib.lib()
-for (S, N) in ((17, 1500), (17, 6000), (33, 3000), (50, 20000)):
+SIZES = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(17, 1500), (17, 6000), (33, 3000), (50, 20000)]
+for (S, N) in SIZES:
     sc = make_scene(S, N, "SIMPLE_RADIAL", shared_camera=True, seed=3)
     ext0, K0, xp0, pts0 = perturb_for_ba(sc, seed=3)
     opt = BundleAdjustmentOptions()

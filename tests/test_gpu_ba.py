@@ -52,7 +52,7 @@ def test_cholesky_solve(n):
     np.testing.assert_allclose(np.tril(At.cpu().numpy()), Lr, rtol=1e-9, atol=1e-11)
 
 
-@pytest.mark.parametrize("n", [7, 64, 257, 350, 384, 1202, 3200, 4500])
+@pytest.mark.parametrize("n", [7, 42, 64, 65, 66, 96, 102, 127, 128, 257, 350, 384, 1202, 3200, 4500])
 def test_cholesky_solve_fused_rhs_row(n):
     # b stored directly behind A: the rhs rides through the factorisation as row n (the BA path)
     rng = np.random.default_rng(100 + n)

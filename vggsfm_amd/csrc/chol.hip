@@ -1871,7 +1871,10 @@ size_t cholesky_workspace_bytes(int n) {
 // VGG_CHOL_LEGACY=1 in the environment selects the multi-launch path (A/B measurements)
 static bool use_dataflow(int n) {
   static const bool legacy = [] { const char* e = getenv("VGG_CHOL_LEGACY"); return e && e[0] == '1'; }();
-  return !legacy && n >= 2 * DFB;
+  // (round 6: every size -- rounds 3-5 kept the multi-launch path below two 64-blocks, where it is 1.2-1.9 x slower: 76 -> 39 us
+  //  at the n = 102 of a 17-frame video window, 44 -> 25 at n = 54; VGG_DF_MIN_N restores a threshold for A/B measurements)
+  static const int min_n = [] { const char* e = getenv("VGG_DF_MIN_N"); return e ? atoi(e) : 1; }();
+  return !legacy && n >= min_n;
 }
 
 // raises one overlap flag (a launch of its own behind a tile batch: the batch's stores are then visible device-wide)

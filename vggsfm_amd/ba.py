@@ -271,7 +271,7 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
         return (torch.zeros((0, 6), dtype=torch.int32, device=dev), z, z.clone(), torch.zeros(0, dtype=torch.int32, device=dev), 0,
                 torch.zeros((1, 6), dtype=torch.int32))
     counts = (row_ptr[1:] - row_ptr[:-1]).long()
-    obs_pt = torch.repeat_interleave(torch.arange(P, device=dev), counts)
+    obs_pt = torch.repeat_interleave(torch.arange(P, device=dev), counts, output_size=O)   # (output_size: no host read inside)
     grp = (obs_cam // group).long()
     is_start = torch.ones(O, dtype=torch.bool, device=dev)
     is_start[1:] = (obs_pt[1:] != obs_pt[:-1]) | (grp[1:] != grp[:-1])
@@ -289,7 +289,7 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     idx = torch.arange(nseg, device=dev)
     npair = pseg_ptr[seg_pt + 1] - idx
     total = int(npair.sum().item())
-    A = torch.repeat_interleave(idx, npair)
+    A = torch.repeat_interleave(idx, npair, output_size=total)
     pair_start = torch.cumsum(npair, 0) - npair
     B = A + (torch.arange(total, device=dev) - pair_start[A])
     # batch of a camera group: runs of consecutive groups gI with about equal numbers of entries
@@ -363,7 +363,7 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
         new_start = torch.empty_like(tile_start)
         kc_p = kcounts[perm_units]
         new_start[perm_units] = torch.cumsum(kc_p, 0) - kc_p
-        unit0 = torch.repeat_interleave(torch.arange(kcounts.shape[0], device=dev), kcounts)
+        unit0 = torch.repeat_interleave(torch.arange(kcounts.shape[0], device=dev), kcounts, output_size=total)
         dest = new_start[unit0] + (torch.arange(total, device=dev) - tile_start[unit0])
         inv = torch.empty_like(dest)
         inv[dest] = torch.arange(total, device=dev)
@@ -382,13 +382,13 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
         bits_t = torch.tensor(bits, dtype=torch.long, device=dev)
         pat = lambda m: (((m[:, None] & bits_t[None]) != 0).long() << torch.arange(nt, device=dev)[None]).sum(1)
         pkey = pat(seg_mask[A]) * (1 << nt) + pat(seg_mask[B])
-        unit0 = torch.repeat_interleave(torch.arange(kcounts.shape[0], device=dev), kcounts)
+        unit0 = torch.repeat_interleave(torch.arange(kcounts.shape[0], device=dev), kcounts, output_size=total)
         upos0 = torch.arange(total, device=dev) - tile_start[unit0]
         wkey = (unit0 * (int(kcounts.max().item()) // quad_window + 1) + upos0 // quad_window) * (1 << (2 * nt)) + pkey
         order2 = torch.argsort(wkey, stable=True)
         A, B, epos, emask = A[order2], B[order2], epos[order2], emask[order2]
     # presence of a quad = union over its four entries (quads are aligned to the start of the unit, like the kernel's batches)
-    unit_of_entry = torch.repeat_interleave(torch.arange(kcounts.shape[0], device=dev), kcounts)
+    unit_of_entry = torch.repeat_interleave(torch.arange(kcounts.shape[0], device=dev), kcounts, output_size=total)
     upos = torch.arange(total, device=dev) - tile_start[unit_of_entry]
     nquad = (kcounts + 3) // 4
     quad = (torch.cumsum(nquad, 0) - nquad)[unit_of_entry] + upos // 4

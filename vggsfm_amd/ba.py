@@ -20,6 +20,8 @@ from typing import Optional
 
 import math
 import os
+
+import numpy as np
 import torch
 
 from . import _lib
@@ -302,11 +304,14 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     last_cam = torch.where(has, obs_cam.long()[(row_ptr[1:].long() - 1).clamp(min=0)], torch.zeros_like(counts))
     prank = torch.empty(P, dtype=torch.long, device=dev)
     prank[torch.argsort(first_cam * ncam + last_cam, stable=True)] = torch.arange(P, device=dev)
-    per_group = torch.bincount(gA, minlength=ngroups).double()
     nb = max(1, min(int(num_batches), ngroups))
-    cum = torch.cumsum(per_group, 0) - per_group                    # entries before group g
-    batch_of_group = torch.clamp((cum * nb / max(float(per_group.sum().item()), 1.0)).long(), max=nb - 1)
-    batch_of_group = torch.cummax(batch_of_group, 0).values
+    if nb == 1:                                                     # (one batch: no counts, no host read)
+        batch_of_group = torch.zeros(ngroups, dtype=torch.long, device=dev)
+    else:
+        per_group = torch.bincount(gA, minlength=ngroups).double()
+        cum = torch.cumsum(per_group, 0) - per_group                # entries before group g
+        batch_of_group = torch.clamp((cum * nb / max(float(total), 1.0)).long(), max=nb - 1)   # (per_group.sum() = total)
+        batch_of_group = torch.cummax(batch_of_group, 0).values
     # tile key: batch-major; inside a batch the off-diagonal tiles first, then the diagonal ones (separate launches)
     nn = ngroups * ngroups
     key = batch_of_group[gA] * (2 * nn) + (gA == gB).long() * nn + gA * ngroups + gB
@@ -392,7 +397,9 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     upos = torch.arange(total, device=dev) - tile_start[unit_of_entry]
     nquad = (kcounts + 3) // 4
     quad = (torch.cumsum(nquad, 0) - nquad)[unit_of_entry] + upos // 4
-    qm = torch.zeros((int(nquad.sum().item()), 4), dtype=torch.long, device=dev)
+    # (rows: an upper bound of the quad count that is known on the host -- sum ceil(k / 4) <= (total + 3 units) / 4 -- instead of
+    #  reading the sum back; the rows beyond the last quad are never gathered)
+    qm = torch.zeros(((total + 3 * int(kcounts.shape[0])) // 4 + 1, 4), dtype=torch.long, device=dev)
     qm[quad, upos % 4] = emask
     qm = qm[:, 0] | qm[:, 1] | qm[:, 2] | qm[:, 3]
     # (field 0 = the entry's POINT, row of `pts`: the diagonal tile launch fetches the point's back-substitution block by it --
@@ -429,16 +436,17 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
             if merged_slots is not None:
                 # ONE launch for both kinds of tiles (small problems): its resident slots are shared in proportion to the
                 # staged bytes (two segments per off-diagonal entry, one per diagonal entry)
-                kc0, dg0 = host_tables[0].long(), host_tables[1] != 0
+                kc0, dg0 = ht[0].astype(np.int64), ht[1] != 0
                 e_off, e_diag = float(kc0[~dg0].sum()), float(kc0[dg0].sum())
                 n_off = int(round(merged_slots * 2.0 * e_off / max(2.0 * e_off + e_diag, 1.0)))
                 n_off = min(max(n_off, 1 if e_off else 0), merged_slots - (1 if e_diag else 0))
                 caps = (max(n_off, 1), max(merged_slots - n_off, 1))
-            # (the search runs on host copies of the per-tile counts: one synchronisation instead of one per probe)
-            kc_h, diag_h, tb_h, ns_h = host_tables[0].long(), host_tables[1] != 0, host_tables[2].long(), host_tables[3].long()
-            kw_h = kw.cpu() if kw is not kw_first else host_tables[4]
-            csize_h = torch.full_like(kc_h, chunk)
-            topup_h = torch.zeros_like(kc_h)
+            # (the search runs on host copies of the per-tile counts: one synchronisation instead of one per probe -- and, since
+            #  round 6, in numpy: a dozen probes of a handful of tiny torch CPU tensors cost 0.4 ms of a 2.9 ms window compile)
+            kc_h, diag_h, tb_h, ns_h = ht[0].astype(np.int64), ht[1] != 0, ht[2].astype(np.int64), ht[3].astype(np.int64)
+            kw_h = kw.cpu().numpy() if kw is not kw_first else ht[4]
+            csize_h = np.full_like(kc_h, chunk)
+            topup_h = np.zeros_like(kc_h)
             for b in range(nb):
                 scale = 1.0 if b == 0 else later_scale
                 for sel, cap in ((~diag_h & (tb_h == b), int(caps[0] * scale)), (diag_h & (tb_h == b), int(caps[1] * scale))):
@@ -446,7 +454,7 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
                         continue
                     kc, kwv, nsv = kc_h[sel], kw_h[sel], ns_h[sel]
                     lo, hi = MIN_CHUNK // SUB, max(MIN_CHUNK // SUB, int(-(-int(max(float(kwv.max()), float(kc.max()))) // SUB)))
-                    fits = lambda c: int(torch.minimum(torch.clamp(torch.ceil(kwv / (c * SUB)), min=1).long(), nsv).sum()) <= cap
+                    fits = lambda c: int(np.minimum(np.maximum(np.ceil(kwv / (c * SUB)), 1.0).astype(np.int64), nsv).sum()) <= cap
                     if not fits(hi):
                         lo = hi                         # more tiles than slots: one workgroup per tile
                     while lo < hi:
@@ -455,25 +463,27 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
                     csize_h[sel] = lo * SUB
                     # top-up (round 5): the search stops at the first chunk size that fits, which leaves 1-3 % of the slots of
                     # a launch empty; they go, one by one, to the tile whose workgroups carry the most
-                    n_h = torch.minimum(torch.clamp(torch.ceil(kwv / (lo * SUB)), min=1).long(), nsv)
+                    n_h = np.minimum(np.maximum(np.ceil(kwv / (lo * SUB)), 1.0).astype(np.int64), nsv)
                     spare = cap - int(n_h.sum())
                     if top_up and 0 < spare <= 64:
                         for _ in range(spare):
-                            load = torch.where(n_h < nsv, kwv / n_h.double(), torch.zeros_like(kwv))
-                            i = int(torch.argmax(load))
+                            load = np.where(n_h < nsv, kwv / n_h.astype(np.float64), 0.0)
+                            i = int(np.argmax(load))
                             if float(load[i]) <= 0.0:
                                 break
                             n_h[i] += 1
                         topup_h[sel] = n_h
-            csize = csize_h.to(dev)
+            csize = torch.from_numpy(csize_h).to(dev)
         nchunks = torch.minimum(torch.clamp(torch.ceil(kw / csize.double()), min=1).long(), nsub_t)
         if max_chunks is not None and bool((topup_h > 0).any()):
-            nchunks = torch.where(topup_h.to(dev) > 0, topup_h.to(dev), nchunks)
+            th = torch.from_numpy(topup_h).to(dev)
+            nchunks = torch.where(th > 0, th, nchunks)
         return nchunks
 
     # (the per-tile tables the search reads: ONE copy to the host -- they are exact in float64)
     kw_first = kw
     host_tables = torch.stack([kcounts.double(), is_diag.double(), tbatch.double(), nsub_t.double(), kw]).cpu()
+    ht = host_tables.numpy()
     nchunks = size_chunks(kw)
     # POSITION weight (round 5): the workgroups of a launch are all resident at once, three (four) to a CU, and the SIMDs
     # arbitrate oldest-first -- the workgroup that was dispatched LAST onto a CU gets the issue slots its elders leave.  Per-tile
@@ -506,21 +516,22 @@ def build_schur_tiles(row_ptr, obs_cam, group=GROUP, chunk=CHUNK, max_chunks=Non
     obs_slot = (seg_id * group + obs_cam.long() % group).to(torch.int32)
     # host-side batch table (per tile)
     tbatch, is_diag, ukeys = tbatch[tfirst_unit], is_diag[tfirst_unit], ukeys[tfirst_unit]
-    tt = torch.stack([tbatch, is_diag.long(), t_chunks, t_cfirst, ukeys // ngroups]).cpu()      # (one copy)
+    tt = torch.stack([tbatch, is_diag.long(), t_chunks, t_cfirst, ukeys // ngroups]).cpu().numpy()      # (one copy)
     tb, td, tn, tf, tg = tt[0], tt[1] != 0, tt[2], tt[3], tt[4]
-    batch_desc = torch.zeros((nb, 6), dtype=torch.int32)
+    bd = np.zeros((nb, 6), dtype=np.int32)
     for b in range(nb):
-        ids = torch.nonzero(tb == b).squeeze(1)
-        if ids.numel() == 0:                        # (cannot happen for b = 0; later batches may be empty)
-            prev = int(batch_desc[b - 1, 2]) if b else 0
-            prevt = int(batch_desc[b - 1, 4]) if b else 0
-            batch_desc[b] = torch.tensor([prev, prev, prev, prevt, prevt, ngroups])
+        ids = np.nonzero(tb == b)[0]
+        if ids.size == 0:                           # (cannot happen for b = 0; later batches may be empty)
+            prev = int(bd[b - 1, 2]) if b else 0
+            prevt = int(bd[b - 1, 4]) if b else 0
+            bd[b] = (prev, prev, prev, prevt, prevt, ngroups)
             continue
         c0 = int(tf[ids[0]])
         c1 = int(tf[ids[-1]] + tn[ids[-1]])
         dg = ids[td[ids]]
-        cm = int(tf[dg[0]]) if dg.numel() else c1
-        batch_desc[b] = torch.tensor([c0, cm, c1, int(ids[0]), int(ids[-1]) + 1, int(tg[ids].min())])
+        cm = int(tf[dg[0]]) if dg.size else c1
+        bd[b] = (c0, cm, c1, int(ids[0]), int(ids[-1]) + 1, int(tg[ids].min()))
+    batch_desc = torch.from_numpy(bd)
     return (chunk_desc.contiguous(), entries.contiguous(), tile_desc.contiguous(), obs_slot.contiguous(), int(nseg),
             batch_desc.contiguous())
 

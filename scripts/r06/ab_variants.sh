@@ -15,5 +15,5 @@ python - $OUT <<'PY'
 import json, sys
 for l in open(sys.argv[1]):
     d = json.loads(l); k = d["kernel_ms"]
-    print(d["variant"], d.get("workload", ""), d["ms_per_iteration"], "diag", k["schur_tile<diag>"], "off", k["schur_tile<offdiag>"], "lin", k["cam_pass<linearize>"], "pp", k["point_pass"], "camrhs", k["cam_pass<rhs>"], "cost", d["final_cost"])
+    print(d["variant"], d.get("workload", ""), d["ms_per_iteration"], "diag", k["schur_tile<diag>"], "off", k["schur_tile<offdiag>"], "lin", k["cam_pass<linearize>"], "pp", k["point_pass"], "chol", k["cholesky"], "camrhs", k["cam_pass<rhs>"], "cost", d["final_cost"])
 PY

@@ -883,6 +883,18 @@ __device__ __forceinline__ void st_agent(double* p, double v) {
 __device__ __forceinline__ double ld_agent(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Round 6, backward substitution: x travels between workgroups WITHOUT a flag.  The 64 values of a block are published into a
+// buffer of their own (`xpub`, behind the launch-order map) that the forward launch has filled with a sentinel -- a NaN pattern no
+// solve produces -- and every consumer lane polls ITS element until it is no longer the sentinel: one memory round trip per
+// hand-off instead of two (flag observed, then the values fetched), and no store drain + flag on the producer's side.
+#ifndef VGG_BW_SENTINEL
+#define VGG_BW_SENTINEL 1
+#endif
+constexpr unsigned long long kXSentinel = 0x7FF8C0DEC0DE0001ull;
+__host__ __device__ inline double* df_xpub(int32_t* flags, int nbk) {
+  const size_t ints = (size_t)(nbk + 1) * nbk + 3 * (size_t)nbk + 1 + ((size_t)nbk * (nbk + 1) / 2 + nbk);   // flags | map
+  return reinterpret_cast<double*>(flags + ((ints + 1) & ~(size_t)1));                                        // (8-byte aligned: flags is)
+}
 // all threads: wait until *flag >= want (raised by another workgroup of this launch; flags only grow)
 __device__ __forceinline__ void df_wait_ge(const int32_t* flag, int32_t want, int32_t* fail) {
   if (threadIdx.x == 0) {
@@ -1347,6 +1359,8 @@ __global__ __launch_bounds__(256, df_occupancy(CHAIN)) void chol_dataflow_kernel
     return (split_b > 0 && br < nbk && DFB * br >= split_a && DFB * (br + 1) <= split_a + split_b) ? split_a / DFB : 0;
   };
   if (c < first_of(r)) return;                          // structurally zero tile (block-diagonal leading part)
+  if (VGG_BW_SENTINEL && r == nbk && threadIdx.x < DFB)    // (the backward launch's hand-off buffer: see kXSentinel)
+    reinterpret_cast<unsigned long long*>(df_xpub(flags, nbk))[DFB * c + threadIdx.x] = kXSentinel;
   const bool diag = (r == c);
   // the diagonal tile of column x is finished by the workgroup of tile (x, x - 1)
   auto chained = [&](int x) { return CHAIN && x >= 1 && x < nbk && first_of(x) <= x - 1; };
@@ -1745,6 +1759,7 @@ __global__ __launch_bounds__(256) void chol_backward_dataflow_kernel(const doubl
     if (first_blk) return first_blk[br];
     return (split_b > 0 && DFB * br >= split_a && DFB * (br + 1) <= split_a + split_b) ? split_a / DFB : 0;
   };
+  double* xpub = df_xpub(xready - ((size_t)(nbk + 1) * nbk + nbk), nbk);      // (xready sits at that offset of the flags)
   for (int e = tid; e < DFB * DFB; e += 256) Ts[(e / DFB) * LD + e % DFB] = Tinv[(size_t)c * DFB * DFB + e];
   double acc = 0.0;
   auto load_tile = [&](int r, double (&t)[16]) {
@@ -1763,8 +1778,26 @@ __global__ __launch_bounds__(256) void chol_backward_dataflow_kernel(const doubl
     int rn = r - 1;
     while (rn > c && first_of(rn) > c) --rn;
     if (rn > c) load_tile(rn, nxt);                       // in flight while this workgroup waits for x_r
-    df_wait(&xready[r], fail);
-    if (tid < DFB) xs[tid] = (DFB * r + tid < n) ? ld_agent(&b[DFB * r + tid]) : 0.0;
+    if (VGG_BW_SENTINEL) {
+      if (tid < DFB) {
+        double v = 0.0;
+        if (DFB * r + tid < n) {
+          int spins = 0;
+          for (;;) {
+            v = ld_agent(&xpub[DFB * r + tid]);
+            if ((unsigned long long)__double_as_longlong(v) != kXSentinel) break;
+            __builtin_amdgcn_s_sleep(1);
+            ++spins;
+            const bool lost = fail && (spins & 1023) == 0 && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2;
+            if (spins > kSpinLimit || lost) { if (fail) __hip_atomic_store(fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v = 0.0; break; }
+          }
+        }
+        xs[tid] = v;
+      }
+    } else {
+      df_wait(&xready[r], fail);
+      if (tid < DFB) xs[tid] = (DFB * r + tid < n) ? ld_agent(&b[DFB * r + tid]) : 0.0;
+    }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc += cur[i] * xs[16 * q + i];
@@ -1786,8 +1819,12 @@ __global__ __launch_bounds__(256) void chol_backward_dataflow_kernel(const doubl
     part[q][i] = s0;
   }
   __syncthreads();
-  if (tid < vc) st_agent(&b[c0 + tid], ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid]);
-  df_publish(&xready[c]);
+  if (tid < vc) {
+    const double xv = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
+    if (VGG_BW_SENTINEL) { st_agent(&xpub[c0 + tid], xv); b[c0 + tid] = xv; }
+    else st_agent(&b[c0 + tid], xv);
+  }
+  if (!VGG_BW_SENTINEL) df_publish(&xready[c]);
 }
 
 // LAUNCH ORDER with a row envelope.  In (column, row) order the tiles of a pivot chain that starts late in the matrix
@@ -1855,7 +1892,8 @@ static size_t dataflow_tile_count(int n) {
   return nbk * (nbk + 1) / 2 + nbk;
 }
 static size_t dataflow_workspace_bytes(int n) {     // T blocks | flags | launch-order map (1 + tiles)
-  return (size_t)div_up(n, DFB) * DFB * DFB * sizeof(double) + (dataflow_flag_count(n) + 1 + dataflow_tile_count(n)) * sizeof(int32_t) + 256;
+  return (size_t)div_up(n, DFB) * DFB * DFB * sizeof(double) + (dataflow_flag_count(n) + 1 + dataflow_tile_count(n) + 2) * sizeof(int32_t) +
+         (size_t)div_up(n, DFB) * DFB * sizeof(double) + 256;      // ... | xpub (df_xpub)
 }
 
 static inline int block_size_for(int n) { (void)n; return 32; }

@@ -526,3 +526,37 @@ def test_group_adjacency_without_blas_matches_the_matrix_product():
         seen = []
         got = BA._group_adjacency(masks, 16, lambda t: (seen.append((t.dtype, tuple(t.shape))), t.fill_(1.0)))
         assert seen == [(torch.float32, (G, G))] and bool(got.all())
+
+
+def test_split_exchange_partition_counts_from_the_c_abi():
+    """vgg_ba_reduce_buffer(which = 7) -- host code, no GPU -- returns the number of elements of part A of the split exchange
+    (include/vggsfm_amd.h, phases 7..12): the lower-triangle elements whose row and column belong to cameras of DIFFERENT
+    16-camera groups.  Restated here element by element for 6 x 6 (shared / constant intrinsics), 7 x 7 and 8 x 8 blocks, with a
+    partial last group; together with part B (same group, the shared border, the right-hand side) it is the whole payload."""
+    L = _lib.lib()
+    for C, model, rf, rk, shared in ((40, 1, 1, 1, False), (37, 0, 1, 0, False), (50, 1, 1, 1, True), (33, 0, 0, 0, True), (16, 1, 1, 1, False),
+                                     (17, 1, 0, 1, False)):
+        pb = _lib.BAProblem()
+        pb.num_cams, pb.num_pts, pb.num_obs, pb.num_intr = C, 10, 100, 1 if shared else C
+        pb.camera_model, pb.refine_focal, pb.refine_extra = model, rf, rk
+        pb.num_chunks, pb.num_tile_batches, pb.num_segments, pb.num_tiles = 4, 1, 8, 3
+        op = _lib.BAOptions()
+        op.max_num_iterations = 5
+        kd = rf + (1 if (rk and model == 1) else 0)
+        n = 6 * C + kd * (1 if shared else C)
+        fake = (ctypes.c_char * 64)()                               # (the carve-up only does address arithmetic)
+        cnt, ptr = ctypes.c_size_t(), ctypes.POINTER(ctypes.c_double)()
+        assert L.vgg_ba_reduce_buffer(ctypes.byref(pb), ctypes.byref(op), fake, 4, ctypes.byref(ptr), ctypes.byref(cnt)) == 0
+        assert cnt.value == n * (n + 1) // 2 + n
+        assert L.vgg_ba_reduce_buffer(ctypes.byref(pb), ctypes.byref(op), fake, 7, ctypes.byref(ptr), ctypes.byref(cnt)) == 0
+
+        def group(x):                                               # camera group of a reduced index; -1: shared-intrinsics border
+            if x < 6 * C:
+                return (x // 6) // 16
+            return -1 if (shared or kd == 0) else ((x - 6 * C) // kd) // 16
+        idx = np.arange(n)
+        g = np.array([group(int(x)) for x in idx])
+        r, c = np.meshgrid(idx, idx, indexing="ij")
+        lower = c <= r
+        part_a = lower & (g[r] != g[c]) & (g[r] >= 0) & (g[c] >= 0)
+        assert cnt.value == int(part_a.sum()), (C, model, rf, rk, shared)

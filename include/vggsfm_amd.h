@@ -244,7 +244,7 @@ int vgg_ba_solve(const vgg_ba_problem* problem, const vgg_ba_options* options, v
  *                      launch fills) into buffer 4; 9 = the rest of phase 1 (diagonal launch, its sums, assemble); 10 = pack
  *                      part B (everything else + rhs) behind it; 11 = S | rhs from the two parts' all-gather outputs; 12 =
  *                      query, to be called ONCE per workspace before phases 7..11: VGG_OK if the split is available for this problem (one tile
- *                      batch, separate tile launches) -- it then also writes the rows' offsets inside the two parts into the
+ *                      batch, separate tile launches, more than 16 cameras) -- it then also writes the rows' offsets inside the two parts into the
  *                      workspace --, VGG_ERR_UNSUPPORTED otherwise (nothing is launched).  With a = vgg_ba_reduce_buffer(7) elements in
  *                      part A, b = count(4) - a, ca = ceil(a / W), cb = ceil(b / W): buffer 4 = [A: W ca | B: W cb] (reduce-
  *                      scatter inputs), buffer 5 = [A: ca | B: cb + 1] (the rank's slices; the gradient maximum rides behind

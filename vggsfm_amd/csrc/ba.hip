@@ -3084,7 +3084,7 @@ static int run_phase(const Launch& L, int phase) {
     // split exchange (round 6): 7 = phase 1 up to the sums of the off-diagonal tiles, 8 = pack part A, 9 = the rest of phase 1,
     // 10 = pack part B, 11 = both parts' gathered slices -> S | rhs; 12 = "is the split available for this problem?" + the rows' offsets inside the parts (call it once per workspace)
     case 7: case 9: case 12:
-      if (L.num_batches != 1 || L.merged_tile_launch) return VGG_ERR_UNSUPPORTED;
+      if (L.num_batches != 1 || L.merged_tile_launch || L.d.C <= kGroup) return VGG_ERR_UNSUPPORTED;   // (one camera group: no off-diagonal part)
       if (phase == 12) {                           // (also prepares the rows' offsets inside the two parts: once per workspace)
         split_offsets_kernel<<<1, 256, 0, L.st>>>(L.w, L.d.n_red, L.d.C, L.d.kd, L.d.shared);
         return VGG_OK;
